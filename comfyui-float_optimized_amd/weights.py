@@ -1,0 +1,147 @@
+"""Seeded synthetic weights in the reference's checkpoint layout.
+
+No checkpoint can be downloaded where this is built or benchmarked, so parity tests,
+smoke() and bench.py use weights from this deterministic synthesiser.  Keys and shapes
+are exactly those of the reference state dicts (SURVEY.md appendix B;
+reference FMT.py:218-236, styledecoder.py:447-495), so the same dict loads into the
+reference modules (goldens) and into the HIP handles (product), and a real
+`fmt.safetensors` / `decoder.safetensors` drops in unchanged.
+
+The reference zero-initialises the adaLN and output layers of the FMT
+(FMT.py:260-269), which makes an untrained FMT output identically 0; every tensor is
+therefore re-randomised here with a scale that keeps activations O(1).
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+
+def _rng(seed, name):
+    return np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 32))
+
+
+def _randn(seed, name, shape, std=1.0):
+    a = _rng(seed, name).standard_normal(size=shape).astype(np.float32) * np.float32(std)
+    return torch.from_numpy(a)
+
+
+def sinusoid_table(n_pos, d_hid):
+    """pos_embed[p, j] = sin/cos(p / 10000^(2*(j//2)/d)), even j sin, odd j cos
+    (reference FMT.py:22-40).  Evaluated in float64 then cast, like the reference's
+    python-float list -> torch.Tensor path."""
+    p = np.arange(n_pos, dtype=np.float64)[:, None]
+    j = np.arange(d_hid, dtype=np.float64)[None, :]
+    ang = (p / np.power(10000.0, 2.0 * np.floor(j / 2.0) / d_hid)).astype(np.float32)
+    tab = np.empty_like(ang)
+    tab[:, 0::2] = np.sin(ang[:, 0::2])
+    tab[:, 1::2] = np.cos(ang[:, 1::2])
+    return torch.from_numpy(tab)
+
+
+def band_mask(n, window):
+    """True = blocked, |i-j| > window (reference FMT.py:15-19)."""
+    i = torch.arange(n)
+    return (i[:, None] - i[None, :]).abs() > window
+
+
+def synth_fmt_state(cfg, seed=0):
+    """cfg: FmtConfig.  Returns {key: fp32 tensor} with the `fmt.` prefix stripped."""
+    D, W = cfg.dim_h, cfg.dim_w
+    n_tok = cfg.num_prev_frames + cfg.num_frames_for_clip
+    cdim = cfg.dim_w + cfg.dim_a + cfg.dim_e
+    H = int(cfg.dim_h * cfg.mlp_ratio)
+    sd = {}
+
+    def lin(name, n_out, n_in, gain=1.0, bstd=0.02):
+        sd[name + ".weight"] = _randn(seed, name + ".weight", (n_out, n_in), gain / math.sqrt(n_in))
+        sd[name + ".bias"] = _randn(seed, name + ".bias", (n_out,), bstd)
+
+    sd["pos_embed"] = sinusoid_table(n_tok, D)[None]
+    sd["alignment_mask"] = band_mask(n_tok, cfg.attention_window)
+    lin("x_embedder.proj", D, W)
+    lin("t_embedder.mlp.0", D, 256)
+    lin("t_embedder.mlp.2", D, D)
+    lin("c_embedder", D, cdim)
+    for b in range(cfg.fmt_depth):
+        p = "blocks.%d." % b
+        lin(p + "attn.qkv", 3 * D, D)
+        lin(p + "attn.proj", D, D)
+        lin(p + "mlp.fc1", H, D)
+        lin(p + "mlp.fc2", D, H)
+        lin(p + "adaLN_modulation.1", 6 * D, D, gain=0.5, bstd=0.1)
+    lin("decoder.adaLN_modulation.1", 2 * D, D, gain=0.5, bstd=0.1)
+    lin("decoder.linear", W, D)
+    return sd
+
+
+DEC_CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
+
+
+def synth_decoder_state(size=512, style_dim=512, motion_dim=20, seed=0, flow_gain=0.1, rgb_gain=0.4):
+    """Synthesis (motion-AE decoder) weights, prefix `motion_autoencoder.dec.` stripped.
+    StyleGAN2-style layers carry their 1/sqrt(fan_in) equalised-lr scale in the forward
+    pass, so N(0,1) weights are the natural scale.  `flow_gain` shrinks the ToFlow conv so
+    the synthetic warp stays a moderate displacement (a real checkpoint's flows are smooth;
+    unit-variance random flows make the fp32 reference itself differ from fp64 by 5e-2 per
+    pixel); `rgb_gain` keeps most pixels inside the clamp range so errors are not hidden."""
+    sd = {}
+    log_size = int(math.log2(size))
+    blur = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k2 = blur[None, :] * blur[:, None]
+    k2 = k2 / k2.sum()
+
+    def styled(prefix, cin, cout, up):
+        sd[prefix + ".conv.weight"] = _randn(seed, prefix + ".conv.weight", (1, cout, cin, 3, 3))
+        if up:
+            sd[prefix + ".conv.blur.kernel"] = (k2 * 4.0).clone()
+        sd[prefix + ".conv.modulation.weight"] = _randn(seed, prefix + ".conv.modulation.weight", (cin, style_dim))
+        sd[prefix + ".conv.modulation.bias"] = 1.0 + _randn(seed, prefix + ".conv.modulation.bias", (cin,), 0.1)
+        sd[prefix + ".noise.weight"] = torch.zeros(1)
+        sd[prefix + ".activate.bias"] = _randn(seed, prefix + ".activate.bias", (1, cout, 1, 1), 0.1)
+
+    def to_rgb(prefix, cin, up):
+        sd[prefix + ".bias"] = _randn(seed, prefix + ".bias", (1, 3, 1, 1), 0.1)
+        if up:
+            sd[prefix + ".upsample.kernel"] = (k2 * 4.0).clone()
+        sd[prefix + ".conv.0.weight"] = _randn(seed, prefix + ".conv.0.weight", (3, cin, 1, 1), rgb_gain)
+        sd[prefix + ".conv.1.bias"] = _randn(seed, prefix + ".conv.1.bias", (1, 3, 1, 1), 0.1)
+
+    def to_flow(prefix, cin):
+        sd[prefix + ".bias"] = _randn(seed, prefix + ".bias", (1, 3, 1, 1), 0.1)
+        sd[prefix + ".upsample.kernel"] = (k2 * 4.0).clone()
+        sd[prefix + ".conv.weight"] = _randn(seed, prefix + ".conv.weight", (1, 3, cin, 1, 1), flow_gain)
+        sd[prefix + ".conv.modulation.weight"] = _randn(seed, prefix + ".conv.modulation.weight", (cin, style_dim))
+        sd[prefix + ".conv.modulation.bias"] = 1.0 + _randn(seed, prefix + ".conv.modulation.bias", (cin,), 0.1)
+
+    sd["direction.weight"] = _randn(seed, "direction.weight", (512, motion_dim))
+    sd["input.input"] = _randn(seed, "input.input", (1, DEC_CHANNELS[4], 4, 4))
+    styled("conv1", DEC_CHANNELS[4], DEC_CHANNELS[4], False)
+    to_rgb("to_rgb1", DEC_CHANNELS[4], False)
+    cin = DEC_CHANNELS[4]
+    for li, i in enumerate(range(3, log_size + 1)):
+        cout = DEC_CHANNELS[2 ** i]
+        styled("convs.%d" % (2 * li), cin, cout, True)
+        styled("convs.%d" % (2 * li + 1), cout, cout, False)
+        to_rgb("to_rgbs.%d" % li, cout, True)
+        to_flow("to_flows.%d" % li, cout)
+        cin = cout
+    return sd
+
+
+def synth_feats(size=512, seed=0, smooth=8, hi=0.02):
+    """Appearance skip features in the reference order (encoder.py:220-231): spatial
+    8,16,...,size with the decoder's channel map.  Smooth random fields (low-res noise,
+    bilinearly enlarged) plus a little per-pixel noise, O(1) amplitude."""
+    feats = []
+    r = 8
+    while r <= size:
+        c = DEC_CHANNELS[r]
+        lo = max(2, r // smooth)
+        base = _randn(seed, "feat%d.lo" % r, (1, c, lo, lo))
+        f = torch.nn.functional.interpolate(base, size=(r, r), mode="bilinear", align_corners=False)
+        f = f + _randn(seed, "feat%d.hi" % r, (1, c, r, r), hi)
+        feats.append(f.contiguous())
+        r *= 2
+    return feats

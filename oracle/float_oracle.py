@@ -1,0 +1,328 @@
+"""CPU oracle for the FLOAT hot path (FMT Euler sampling loop + Synthesis decoder).
+
+TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and bench.py's
+`cpu_baseline` leg as the checker / baseline.  The product package never imports it and
+fails loudly when its HIP library is missing.
+
+It is an independent restatement (torch-CPU tensor algebra, fp32 by default, fp64 on
+request) of the reference's algorithm; every function cites the reference lines it
+follows.  Pinning: tests/test_oracle_golden.py checks it against fixtures under
+tests/golden/ that tools/make_goldens.py produced by running the reference itself
+(imported from /root/reference in the build container) on the same seeded weights and
+inputs; when /root/reference is present the same test also runs the reference live.
+
+Third-party arithmetic that is not in /root/reference:
+  * torchdiffeq (unpinned, requirements.txt:3) - only `method='euler'` on a fixed grid is
+    restated: y_{i+1} = y_i + (t_{i+1}-t_i) f(t_i, y_i).  Parity with torchdiffeq itself
+    is unpinned (the package is absent); the stand-in used to make the goldens implements
+    the same published rule.
+  * timm>=1.0.9 Mlp = Linear -> GELU(tanh) -> Linear (FMT.py:160-162); unpinned likewise.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------- FMT
+
+
+def timestep_embedding(t, dim=256, max_period=10000.0):
+    """[cos(t f_k), sin(t f_k)], f_k = exp(-ln(max_period) k / half)  (FMT.py:107-126)."""
+    half = dim // 2
+    k = torch.arange(half, dtype=torch.float32)
+    freqs = torch.exp(-math.log(max_period) * k / half).to(t.dtype)
+    args = t.reshape(-1, 1) * freqs[None, :]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def _linear(x, sd, name):
+    return x @ sd[name + ".weight"].to(x.dtype).T + sd[name + ".bias"].to(x.dtype)
+
+
+def _silu(x):
+    return x * torch.sigmoid(x)
+
+
+def _gelu_tanh(x):
+    return 0.5 * x * (1.0 + torch.tanh(math.sqrt(2.0 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+def _layernorm(x, eps=1e-6):
+    """No affine, biased variance (FMT.py:157,159,185)."""
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps)
+
+
+def band_attention(q, k, v, window):
+    """softmax(q k^T / sqrt(d) + mask) v with mask = -inf where |i-j| > window
+    (FMT.py:15-19, 75-80).  q,k,v: (B, H, N, d)."""
+    n = q.shape[-2]
+    i = torch.arange(n)
+    blocked = (i[:, None] - i[None, :]).abs() > window
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
+    s = s.masked_fill(blocked, float("-inf"))
+    return torch.softmax(s, dim=-1) @ v
+
+
+def fmt_forward(sd, cfg, t, x, wa, wr, we, prev_x, prev_wa, prev_we=None, dtype=torch.float32):
+    """FlowMatchingTransformer.forward with train=False (FMT.py:277-340).
+    t: (1,) or scalar; x, wa: (B,L,dim); wr: (B,dim_w); we: (B,1|L,dim_e);
+    prev_*: (B,L',.).  Returns (B, L'+L, dim_w)."""
+    cv = lambda a: a.to(dtype)  # noqa: E731
+    t = cv(torch.as_tensor(t)).reshape(-1)
+    x, wa, wr, we, prev_x, prev_wa = cv(x), cv(wa), cv(wr), cv(we), cv(prev_x), cv(prev_wa)
+    dynamic_we = we.shape[1] > 1
+    if dynamic_we and prev_we is None:
+        raise ValueError("`we` is dynamic (T>1), but prev_we was not provided with prev_x/prev_wa.")
+    # time embedding MLP (FMT.py:128-131,294)
+    te = _linear(timestep_embedding(t), sd, "t_embedder.mlp.0")
+    te = _linear(_silu(te), sd, "t_embedder.mlp.2")[:, None, :]
+    # sequence assembly (FMT.py:312-326)
+    x = torch.cat([prev_x, x], dim=1)
+    wa = torch.cat([prev_wa, wa], dim=1)
+    n = wa.shape[1]
+    if dynamic_we:
+        we = torch.cat([cv(prev_we), we], dim=1)
+        if we.shape[1] != n:
+            raise ValueError("Dynamic emotion latent `we` time dimension (%d) does not match "
+                             "audio latent `wa` time dimension (%d)." % (we.shape[1], n))
+    else:
+        we = we.expand(-1, n, -1)
+    h = _linear(x, sd, "x_embedder.proj") + cv(sd["pos_embed"])
+    c = torch.cat([wr[:, None, :].expand(-1, n, -1), wa, we], dim=-1)
+    c = te + _linear(c, sd, "c_embedder")
+    sc = _silu(c)
+    B, N, D = h.shape
+    H = cfg.num_heads
+    for b in range(cfg.fmt_depth):
+        p = "blocks.%d." % b
+        mod = _linear(sc, sd, p + "adaLN_modulation.1")
+        sh1, s1, g1, sh2, s2, g2 = mod.chunk(6, dim=-1)  # FMT.py:173
+        a_in = _layernorm(h) * (1 + s1) + sh1
+        qkv = _linear(a_in, sd, p + "attn.qkv").reshape(B, N, 3, H, D // H).permute(2, 0, 3, 1, 4)
+        o = band_attention(qkv[0], qkv[1], qkv[2], cfg.attention_window)
+        o = o.transpose(1, 2).reshape(B, N, D)
+        h = h + g1 * _linear(o, sd, p + "attn.proj")
+        m_in = _layernorm(h) * (1 + s2) + sh2
+        m = _linear(_gelu_tanh(_linear(m_in, sd, p + "mlp.fc1")), sd, p + "mlp.fc2")
+        h = h + g2 * m
+    sh, s = _linear(sc, sd, "decoder.adaLN_modulation.1").chunk(2, dim=-1)  # FMT.py:196
+    return _linear(_layernorm(h) * (1 + s) + sh, sd, "decoder.linear")
+
+
+def fmt_forward_cfv(sd, cfg, t, x, wa, wr, we, prev_x, prev_wa, prev_we=None,
+                    a_cfg_scale=1.0, r_cfg_scale=1.0, e_cfg_scale=1.0, include_r_cfg=False,
+                    dtype=torch.float32):
+    """Classifier-free vector field (FMT.py:342-401)."""
+    if a_cfg_scale == 1.0 and r_cfg_scale == 1.0 and e_cfg_scale == 1.0:
+        return fmt_forward(sd, cfg, t, x, wa, wr, we, prev_x, prev_wa, prev_we, dtype)
+    z = torch.zeros_like
+    pw = prev_we
+    if not include_r_cfg:
+        # rows: [uncond | all | audio-only]  (FMT.py:360-373)
+        out = fmt_forward(sd, cfg, t, torch.cat([x, x, x]), torch.cat([z(wa), wa, wa]),
+                          torch.cat([wr, wr, wr]), torch.cat([z(we), we, z(we)]),
+                          torch.cat([prev_x] * 3), torch.cat([prev_wa] * 3),
+                          None if pw is None else torch.cat([z(pw), pw, z(pw)]), dtype)
+        u, al, au = out.chunk(3, dim=0)
+        return u + a_cfg_scale * (au - u) + e_cfg_scale * (al - au)
+    # 4-way with a null reference row (FMT.py:380-399)
+    out = fmt_forward(sd, cfg, t, torch.cat([x] * 4), torch.cat([z(wa), z(wa), wa, wa]),
+                      torch.cat([z(wr), wr, wr, wr]), torch.cat([z(we), z(we), we, z(we)]),
+                      torch.cat([prev_x] * 4), torch.cat([prev_wa] * 4),
+                      None if pw is None else torch.cat([z(pw), z(pw), pw, z(pw)]), dtype)
+    tu, u, al, au = out.chunk(4, dim=0)
+    return tu + r_cfg_scale * (u - tu) + a_cfg_scale * (au - u) + e_cfg_scale * (al - au)
+
+
+def euler_grid(nfe, dtype=torch.float32):
+    """torch.linspace(0, 1, nfe) (FLOAT.py:188): nfe-1 evaluations, t=1 never evaluated."""
+    return torch.linspace(0, 1, nfe, dtype=dtype)
+
+
+def sample_chunk(sd, cfg, x0, wa_c, wr, we_c, prev_x, prev_wa, prev_we, nfe,
+                 a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg=False, dtype=torch.float32):
+    """Fixed-grid Euler over one 50-frame window (FLOAT.py:229-248, nodes_adv.py:629-659)."""
+    ts = euler_grid(nfe, dtype)
+    x = x0.to(dtype)
+    P = cfg.num_prev_frames
+    for i in range(nfe - 1):
+        v = fmt_forward_cfv(sd, cfg, ts[i].reshape(1), x, wa_c, wr, we_c, prev_x, prev_wa, prev_we,
+                            a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg, dtype)[:, P:]
+        x = x + (ts[i + 1] - ts[i]) * v
+    return x
+
+
+def pad_replicate(a, length):
+    """F.pad(..., mode='replicate') along time (FLOAT.py:226-227)."""
+    if a.shape[1] >= length:
+        return a
+    return torch.cat([a, a[:, -1:].expand(-1, length - a.shape[1], -1)], dim=1)
+
+
+def sample_rd(sd, cfg, r_s, wa, we, noise, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0,
+              include_r_cfg=False, dtype=torch.float32):
+    """The auto-regressive chunk loop (FLOAT.py:209-253; nodes_adv.py:578-694).
+    r_s (B,512); wa (B,T,512); we (B,1,7) static or (B,T,7) dynamic; noise (n_chunks,B,50,512)
+    is the explicit stand-in for the sequential torch.randn draws (FLOAT.py:215).
+    Returns r_d (B,T,512)."""
+    B, T, _ = wa.shape
+    L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
+    n_chunks = int(math.ceil(T / L))
+    dynamic = we.shape[1] > 1
+    prev_x = torch.zeros(B, P, cfg.dim_w, dtype=dtype)
+    prev_wa = torch.zeros(B, P, cfg.dim_a, dtype=dtype)
+    prev_we = torch.zeros(B, P, cfg.dim_e, dtype=dtype)
+    out = []
+    for k in range(n_chunks):
+        wa_c = pad_replicate(wa[:, k * L:(k + 1) * L].to(dtype), L)
+        we_c = pad_replicate(we[:, k * L:(k + 1) * L].to(dtype), L) if dynamic else we.to(dtype)
+        xs = sample_chunk(sd, cfg, noise[k], wa_c, r_s.to(dtype), we_c, prev_x, prev_wa,
+                          prev_we if dynamic else None, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale,
+                          include_r_cfg, dtype)
+        out.append(xs)
+        prev_x, prev_wa = xs[:, -P:], wa_c[:, -P:]
+        if dynamic:
+            prev_we = we_c[:, -P:]
+    return torch.cat(out, dim=1)[:, :T]
+
+
+# ------------------------------------------------------------------------- decoder
+
+_SQRT2 = math.sqrt(2.0)
+
+
+def fir_kernel(gain=1.0, dtype=torch.float32):
+    """[1,3,3,1] x [1,3,3,1] / 64 (styledecoder.py:39-44); x4 when up-sampling (:79,:118)."""
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=dtype)
+    k = k1[:, None] * k1[None, :]
+    return k / k.sum() * gain
+
+
+def upfirdn(x, k, up=1, pad=(0, 0)):
+    """Zero-insert by `up`, pad (pad0 before, pad1 after), correlate with the flipped FIR
+    (styledecoder.py:16-32).  Depth-wise; x (B,C,H,W)."""
+    B, C, H, W = x.shape
+    if up > 1:
+        z = x.new_zeros(B, C, H * up, W * up)
+        z[:, :, ::up, ::up] = x
+        x = z
+    x = F.pad(x, [pad[0], pad[1], pad[0], pad[1]])
+    w = torch.flip(k, [0, 1]).to(x.dtype)[None, None].expand(C, 1, -1, -1)
+    return F.conv2d(x, w, groups=C)
+
+
+def equal_linear(x, w, b):
+    """x (W/sqrt(in))^T + b  (styledecoder.py:168,177; lr_mul = 1)."""
+    return x @ (w.to(x.dtype) * (1.0 / math.sqrt(w.shape[1]))).T + b.to(x.dtype)
+
+
+def modulated_conv(x, style, sd, prefix, demodulate=True, upsample=False):
+    """ModulatedConv2d (styledecoder.py:238-272), one explicit conv per batch item."""
+    w = sd[prefix + ".weight"].to(x.dtype)[0]  # (Cout, Cin, k, k)
+    cout, cin, ks, _ = w.shape
+    s = equal_linear(style, sd[prefix + ".modulation.weight"], sd[prefix + ".modulation.bias"])
+    scale = 1.0 / math.sqrt(cin * ks * ks)
+    outs = []
+    for b in range(x.shape[0]):
+        wb = scale * w * s[b][None, :, None, None]
+        if demodulate:
+            wb = wb * torch.rsqrt((wb ** 2).sum(dim=(1, 2, 3)) + 1e-8)[:, None, None, None]
+        if upsample:
+            # conv_transpose2d stride 2 (styledecoder.py:250-257) then Blur pad (1,1), gain 4
+            y = F.conv_transpose2d(x[b:b + 1], wb.transpose(0, 1), stride=2, padding=0)
+            y = upfirdn(y, fir_kernel(4.0, x.dtype), pad=(1, 1))
+        else:
+            y = F.conv2d(x[b:b + 1], wb, padding=ks // 2)
+        outs.append(y)
+    return torch.cat(outs, dim=0)
+
+
+def styled_conv(x, style, sd, prefix, upsample=False):
+    """StyledConv with noise=None (styledecoder.py:320-325): modconv, + bias, lrelu(0.2) sqrt2."""
+    y = modulated_conv(x, style, sd, prefix + ".conv", True, upsample)
+    return F.leaky_relu(y + sd[prefix + ".activate.bias"].to(x.dtype), 0.2) * _SQRT2
+
+
+def upsample2(x):
+    """Upsample([1,3,3,1]) (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR gain 4."""
+    return upfirdn(x, fir_kernel(4.0, x.dtype), up=2, pad=(2, 1))
+
+
+def to_rgb(x, sd, prefix, skip=None):
+    """ToRGB (styledecoder.py:368-386): 1x1 EqualConv (no bias) -> FusedLeakyReLU(3) -> +bias
+    -> + Upsample(skip)."""
+    w = sd[prefix + ".conv.0.weight"].to(x.dtype)
+    y = F.conv2d(x, w * (1.0 / math.sqrt(w.shape[1])))
+    y = F.leaky_relu(y + sd[prefix + ".conv.1.bias"].to(x.dtype), 0.2) * _SQRT2
+    y = y + sd[prefix + ".bias"].to(x.dtype)
+    if skip is not None:
+        y = y + upsample2(skip)
+    return y
+
+
+def to_flow(x, style, feat, sd, prefix, skip=None):
+    """ToFlow (styledecoder.py:399-425).  Returns (feat_warp, blended, out3, grid)."""
+    out = modulated_conv(x, style, sd, prefix + ".conv", demodulate=False)
+    out = out + sd[prefix + ".bias"].to(x.dtype)
+    if skip is not None:
+        out = out + upsample2(skip)
+    R = x.shape[2]
+    lin = torch.linspace(-1, 1, R, dtype=torch.float64).to(torch.float32).to(x.dtype)  # np.linspace f64 -> f32
+    gx = lin[None, :].expand(R, R)
+    gy = lin[:, None].expand(R, R)
+    ident = torch.stack([gx, gy], dim=-1)[None]  # channel 0 = x (width), 1 = y
+    grid = torch.tanh(out[:, 0:2]).permute(0, 2, 3, 1) + ident
+    mask = torch.sigmoid(out[:, 2:3])
+    fw = F.grid_sample(feat.to(x.dtype).expand(x.shape[0], -1, -1, -1), grid, mode="bilinear",
+                       padding_mode="zeros", align_corners=False) * mask
+    return fw, fw + x * (1.0 - mask), out, grid
+
+
+def synthesis(sd, latent, feats, dtype=torch.float32, return_all=False):
+    """Synthesis.forward with alpha=None (styledecoder.py:497-534).
+    latent (B,512) = s_r + r_d[:,t]; feats: 7 maps (1|B,C,R,R), R = 8..512.
+    Returns rgb (B,3,S,S) (and the 64x64-level flow grid when return_all)."""
+    latent = latent.to(dtype)
+    B = latent.shape[0]
+    x = sd["input.input"].to(dtype).expand(B, -1, -1, -1)
+    x = styled_conv(x, latent, sd, "conv1")
+    skip = None
+    skip_flow = None
+    flow64 = None
+    inter = {}
+    for li, feat in enumerate(feats):
+        x = styled_conv(x, latent, sd, "convs.%d" % (2 * li), upsample=True)
+        x = styled_conv(x, latent, sd, "convs.%d" % (2 * li + 1))
+        fw, x, skip_flow, grid = to_flow(x, latent, feat, sd, "to_flows.%d" % li, skip_flow)
+        skip = to_rgb(fw, sd, "to_rgbs.%d" % li, skip)
+        if x.shape[2] == 64:
+            flow64 = grid
+        if return_all:
+            inter[x.shape[2]] = dict(x=x, flow=skip_flow, rgb=skip)
+    if return_all:
+        return skip, flow64, inter
+    return skip
+
+
+def postprocess(img):
+    """clamp(-1,1), (x+1)/2, CHW -> HWC (FLOAT.py:149-152)."""
+    return ((img.clamp(-1, 1) + 1) / 2).permute(0, 2, 3, 1).contiguous()
+
+
+def decode_frames(sd, s_r, r_d, feats, dtype=torch.float32):
+    """decode_latent_into_processed_images (FLOAT.py:113-169): frame t uses latent
+    s_r + r_d[:,t]; returns (T,H,W,3) fp32 in [0,1]."""
+    T = r_d.shape[1]
+    frames = []
+    for t in range(T):
+        img = synthesis(sd, s_r.to(dtype) + r_d[:, t].to(dtype), feats, dtype)
+        frames.append(postprocess(img)[0].to(torch.float32))
+    return torch.stack(frames, dim=0)
+
+
+def direction(sd, lam, dtype=torch.float32):
+    """Direction.forward (styledecoder.py:434-444): Q from QR(W + 1e-8); out = lam @ Q^T."""
+    q, _ = torch.linalg.qr(sd["direction.weight"].to(dtype) + 1e-8)
+    return lam.to(dtype) @ q.T

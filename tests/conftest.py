@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")
+
+
+def pytest_collection_modifyitems(config, items):
+    import torch
+    has_gpu = torch.cuda.is_available()
+    skip_gpu = pytest.mark.skip(reason="no GPU visible")
+    skip_ref = pytest.mark.skip(reason="/root/reference not present")
+    has_ref = os.path.isdir("/root/reference/src/nodes")
+    for item in items:
+        if "gpu" in item.keywords and not has_gpu:
+            item.add_marker(skip_gpu)
+        if "reference" in item.keywords and not has_ref:
+            item.add_marker(skip_ref)

@@ -1,0 +1,97 @@
+"""Pin the CPU oracle: oracle/float_oracle.py must reproduce what the reference produced
+(tests/golden/*.npz, made by tools/make_goldens.py from the imported reference) on the same
+seeded weights and inputs.  fp32 vs fp32 with different summation orders: tolerance 1e-4 rel."""
+import math
+
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import golden, load_pkg, max_abs, rel_l2
+
+pkg = load_pkg()
+W, C = pkg.weights, pkg.config
+
+TOL_REL = 1e-4  # fp32 restatement vs fp32 reference
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+@pytest.mark.parametrize("case", ["nocfg", "cfg3", "cfg4", "cfg3dyn"])
+def test_fmt_eval(tag, case):
+    g = golden("fmt_eval_" + tag)
+    cfg = C.small_fmt_config() if tag == "small" else C.FmtConfig()
+    sd = W.synth_fmt_state(cfg, g["seed"])
+    a, r, e, rc = [float(v) for v in g[case + "_scales"]]
+    out = O.fmt_forward_cfv(sd, cfg, g["t"], g[case + "_x"], g[case + "_wa"], g[case + "_wr"], g[case + "_we"],
+                            g[case + "_prev_x"], g[case + "_prev_wa"], g.get(case + "_prev_we"),
+                            a, r, e, bool(rc))
+    assert out.shape == g[case + "_out"].shape
+    assert rel_l2(out, g[case + "_out"]) < TOL_REL
+
+
+@pytest.mark.parametrize("tag", ["small_static", "small_dynamic", "full_static"])
+def test_fmt_sample(tag):
+    g = golden("fmt_sample_" + tag)
+    cfg = C.FmtConfig() if tag.startswith("full") else C.small_fmt_config()
+    sd = W.synth_fmt_state(cfg, g["seed"])
+    r_d = O.sample_rd(sd, cfg, g["r_s"], g["wa"], g["we"], g["noise"], g["nfe"], g["a"], 1.0, g["e"])
+    assert r_d.shape == (1, g["T"], cfg.dim_w)
+    assert rel_l2(r_d, g["r_d"]) < TOL_REL
+
+
+def test_dynamic_we_requires_prev_we():
+    cfg = C.small_fmt_config()
+    sd = W.synth_fmt_state(cfg, 1)
+    z = torch.zeros
+    with pytest.raises(ValueError):
+        O.fmt_forward(sd, cfg, torch.tensor([0.1]), z(1, 50, 128), z(1, 50, 128), z(1, 128), z(1, 50, 7),
+                      z(1, 10, 128), z(1, 10, 128), None)
+
+
+def test_dec_units():
+    g = golden("dec_units")
+    st = g["style"]
+    for name, up in (("plain", False), ("up", True)):
+        sd = {"c.weight": g["mc_%s_w" % name], "c.modulation.weight": g["mc_%s_mw" % name],
+              "c.modulation.bias": g["mc_%s_mb" % name]}
+        out = O.modulated_conv(g["mc_%s_x" % name], st, sd, "c", True, up)
+        assert rel_l2(out, g["mc_%s_out" % name]) < TOL_REL
+    sd = {"f.bias": g["tf_bias"], "f.conv.weight": g["tf_w"], "f.conv.modulation.weight": g["tf_mw"],
+          "f.conv.modulation.bias": g["tf_mb"]}
+    fw, bl, o3, grid = O.to_flow(g["tf_x"], st, g["tf_feat"], sd, "f", g["tf_prev"])
+    assert max_abs(fw, g["tf_warp"]) < 1e-5 and max_abs(bl, g["tf_blend"]) < 1e-5
+    assert max_abs(o3, g["tf_out"]) < 1e-5 and max_abs(grid, g["tf_grid"]) < 1e-6
+    sdr = {"r.bias": g["tr_bias"], "r.conv.0.weight": g["tr_w"], "r.conv.1.bias": g["tr_b1"]}
+    assert max_abs(O.to_rgb(g["tf_warp"], sdr, "r", g["tr_prev"]), g["tr_out"]) < 1e-5
+    assert max_abs(O.direction({"direction.weight": g["dir_w"]}, g["dir_lam"]), g["dir_out"]) < 1e-5
+
+
+def test_dec_64():
+    g = golden("dec_64")
+    sd = W.synth_decoder_state(64, seed=g["seed"])
+    feats = W.synth_feats(64, seed=g["seed"])
+    frames = O.decode_frames(sd, g["s_r"], g["r_d"], feats)
+    assert frames.shape == g["frames"].shape == (3, 64, 64, 3)
+    assert max_abs(frames, g["frames"]) < 1e-4
+    raw, flow, _ = O.synthesis(sd, g["s_r"] + g["r_d"][:, 0], feats, return_all=True)
+    assert max_abs(raw, g["raw0"]) < 2e-4 and max_abs(flow, g["flow0"]) < 1e-5
+
+
+def test_dec_512_lattice():
+    g = golden("dec_512")
+    sd = W.synth_decoder_state(512, seed=g["seed"])
+    feats = W.synth_feats(512, seed=g["seed"])
+    frames = O.decode_frames(sd, g["s_r"], g["r_d"][:, :1], feats)
+    assert max_abs(frames[:, ::7, ::5], g["lattice"][:1]) < 1e-4
+    assert max_abs(frames[:, 250:258], g["band"][:1]) < 1e-4
+    assert abs(float(frames.mean()) - float(g["mean"][0])) < 1e-5
+
+
+def test_euler_grid_and_chunking():
+    # "S steps" = S evaluations = nfe - 1 (FLOAT.py:188,247)
+    ts = O.euler_grid(11)
+    assert len(ts) == 11 and float(ts[0]) == 0.0 and float(ts[-1]) == 1.0
+    assert int(math.ceil(125 / 50)) == 3
+    a = torch.arange(6.0).reshape(1, 3, 2)
+    p = O.pad_replicate(a, 5)
+    assert p.shape == (1, 5, 2) and torch.equal(p[0, 3], a[0, 2]) and torch.equal(p[0, 4], a[0, 2])

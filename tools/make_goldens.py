@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE (imported from /root/reference).
+
+BUILD-CONTAINER ONLY (needs /root/reference; see tools/ref_import.py for the stand-ins).
+Weights come from the build's own seeded synthesiser (comfyui-float_optimized_amd/weights.py),
+so fixtures hold only seeds, inputs and the reference's outputs - never reference source.
+
+    python tools/make_goldens.py            # writes tests/golden/*.npz, prints oracle deltas
+"""
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import ref_import  # noqa: E402
+from tests.util import load_pkg  # noqa: E402
+
+pkg = load_pkg()
+weights = pkg.weights
+config = pkg.config
+from oracle import float_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+os.makedirs(GOLD, exist_ok=True)
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def rnd(seed, *shape, std=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * std)
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(GOLD, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("  wrote %-28s %7.1f KB" % (name + ".npz", os.path.getsize(path) / 1024))
+
+
+def maxdiff(a, b):
+    return float((a.double() - b.double()).abs().max()), float(
+        (a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+def ref_fmt(ns, cfg, seed):
+    opt = ns.base_options.BaseOptions()
+    for k in ("dim_w", "dim_a", "dim_e", "dim_h", "fmt_depth", "num_heads", "mlp_ratio",
+              "num_prev_frames", "attention_window"):
+        setattr(opt, k, getattr(cfg, k))
+    opt.wav2vec_sec = cfg.num_frames_for_clip / opt.fps
+    opt.rank = "cpu"
+    m = ns.FMT.FlowMatchingTransformer(opt)
+    sd = weights.synth_fmt_state(cfg, seed)
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    m.eval()
+    return m, sd, opt
+
+
+def fmt_inputs(cfg, seed, dynamic=False):
+    L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
+    d = dict(
+        x=rnd(seed + 1, 1, L, cfg.dim_w),
+        wa=rnd(seed + 2, 1, L, cfg.dim_a),
+        wr=rnd(seed + 3, 1, cfg.dim_w),
+        prev_x=rnd(seed + 5, 1, P, cfg.dim_w),
+        prev_wa=rnd(seed + 6, 1, P, cfg.dim_a),
+    )
+    if dynamic:
+        d["we"] = torch.softmax(rnd(seed + 4, 1, L, cfg.dim_e), -1)
+        d["prev_we"] = torch.softmax(rnd(seed + 7, 1, P, cfg.dim_e), -1)
+    else:
+        d["we"] = torch.softmax(rnd(seed + 4, 1, 1, cfg.dim_e), -1)
+        d["prev_we"] = None
+    return d
+
+
+def gen_fmt_eval(ns, cfg, tag, seed):
+    print("[fmt eval %s]" % tag)
+    m, sd, _ = ref_fmt(ns, cfg, seed)
+    t = torch.tensor([0.37])
+    cases = {
+        "nocfg": dict(a=1.0, r=1.0, e=1.0, rc=False, dyn=False),
+        "cfg3": dict(a=2.0, r=1.0, e=1.0, rc=False, dyn=False),
+        "cfg4": dict(a=2.0, r=1.5, e=1.3, rc=True, dyn=False),
+        "cfg3dyn": dict(a=1.0, r=1.0, e=3.0, rc=False, dyn=True),
+    }
+    arrs = dict(seed=seed, t=t)
+    for cname, c in cases.items():
+        inp = fmt_inputs(cfg, seed + (100 if c["dyn"] else 0), c["dyn"])
+        with torch.no_grad():
+            ref = m.forward_with_cfv(t, inp["x"], inp["wa"], inp["wr"], inp["we"], inp["prev_x"], inp["prev_wa"],
+                                     inp["prev_we"], a_cfg_scale=c["a"], r_cfg_scale=c["r"], e_cfg_scale=c["e"],
+                                     include_r_cfg=c["rc"])
+        orc = O.fmt_forward_cfv(sd, cfg, t, inp["x"], inp["wa"], inp["wr"], inp["we"], inp["prev_x"], inp["prev_wa"],
+                                inp["prev_we"], c["a"], c["r"], c["e"], c["rc"])
+        orc64 = O.fmt_forward_cfv(sd, cfg, t, inp["x"], inp["wa"], inp["wr"], inp["we"], inp["prev_x"],
+                                  inp["prev_wa"], inp["prev_we"], c["a"], c["r"], c["e"], c["rc"],
+                                  dtype=torch.float64)
+        print("  %-8s oracle32-ref max|d| %.3e rel %.3e | ref-oracle64 rel %.3e | |ref| rms %.3f" % (
+            (cname,) + maxdiff(orc, ref) + (maxdiff(ref, orc64)[1], float(ref.pow(2).mean().sqrt()))))
+        for k, v in inp.items():
+            if v is not None:
+                arrs["%s_%s" % (cname, k)] = v
+        arrs["%s_scales" % cname] = np.array([c["a"], c["r"], c["e"], float(c["rc"])], dtype=np.float32)
+        arrs["%s_out" % cname] = ref
+    save("fmt_eval_%s" % tag, **arrs)
+
+
+def gen_fmt_sample(ns, cfg, tag, seed, T, nfe, dynamic, a, e, noise_seed=15):
+    print("[fmt sample %s] T=%d nfe=%d dynamic=%s" % (tag, T, nfe, dynamic))
+    m, sd, opt = ref_fmt(ns, cfg, seed)
+    L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
+    wa = rnd(seed + 11, 1, T, cfg.dim_a)
+    r_s = rnd(seed + 12, 1, cfg.dim_w)
+    if dynamic:
+        # per-2 s windows nearest-upsampled to T (nodes_vadv.py:829-840 output format)
+        nwin = int(math.ceil(T / L))
+        we_w = torch.softmax(rnd(seed + 13, 1, nwin, cfg.dim_e), -1)
+        idx = torch.clamp((torch.arange(T).float() * nwin / T).long(), max=nwin - 1)
+        we = we_w[:, idx]
+    else:
+        we = torch.softmax(rnd(seed + 13, 1, 1, cfg.dim_e), -1)
+    n_chunks = int(math.ceil(T / L))
+    # Noise exactly as the reference draws it: sequential randn from one seeded generator
+    # (FLOAT.py:203-215, nodes_adv.py:606-607), made explicit for the fixture.
+    g = torch.Generator("cpu")
+    g.manual_seed(noise_seed)
+    noise = torch.stack([torch.randn(1, L, cfg.dim_w, generator=g) for _ in range(n_chunks)])
+    g.manual_seed(noise_seed)
+    with torch.no_grad():
+        ref = ns.nodes_adv._perform_ode_sampling_loop(
+            m, r_s, wa, we, T, P, L, cfg.dim_w, nfe, "euler", 1e-5, 1e-5, torch.device("cpu"),
+            a, 1.0, e, False, g)
+    orc = O.sample_rd(sd, cfg, r_s, wa, we, noise, nfe, a, 1.0, e)
+    print("  oracle32-ref max|d| %.3e rel %.3e ; |ref| rms %.3f" % (maxdiff(orc, ref) + (float(ref.pow(2).mean().sqrt()),)))
+    save("fmt_sample_%s" % tag, seed=seed, T=T, nfe=nfe, a=a, e=e, wa=wa, r_s=r_s, we=we, noise=noise, r_d=ref)
+
+
+def ref_dec(ns, size, seed):
+    d = ns.styledecoder.Synthesis(size, 512, 20)
+    sd = weights.synth_decoder_state(size, seed=seed)
+    d.load_state_dict(sd, strict=True)
+    d.eval()
+    return d, sd
+
+
+def gen_dec_units(ns, seed):
+    print("[decoder unit ops]")
+    S = ns.styledecoder
+    arrs = dict(seed=seed)
+    style = rnd(seed + 1, 2, 512)
+    arrs["style"] = style
+    for name, cin, cout, R, up in (("plain", 32, 16, 8, False), ("up", 32, 16, 8, True)):
+        mc = S.ModulatedConv2d(cin, cout, 3, 512, upsample=up)
+        sd = {"c.weight": rnd(seed + 2, 1, cout, cin, 3, 3), "c.modulation.weight": rnd(seed + 3, cin, 512),
+              "c.modulation.bias": 1 + rnd(seed + 4, cin, std=0.1)}
+        mc.weight.data.copy_(sd["c.weight"])
+        mc.modulation.weight.data.copy_(sd["c.modulation.weight"])
+        mc.modulation.bias.data.copy_(sd["c.modulation.bias"])
+        x = rnd(seed + 5, 2, cin, R, R)
+        with torch.no_grad():
+            ref = mc(x, style)
+        orc = O.modulated_conv(x, style, sd, "c", True, up)
+        print("  modconv %-5s oracle-ref max|d| %.3e rel %.3e" % ((name,) + maxdiff(orc, ref)))
+        arrs.update({"mc_%s_x" % name: x, "mc_%s_out" % name: ref, "mc_%s_w" % name: sd["c.weight"],
+                     "mc_%s_mw" % name: sd["c.modulation.weight"], "mc_%s_mb" % name: sd["c.modulation.bias"]})
+    # ToFlow with a previous flow, then ToRGB with a previous rgb
+    C, R = 32, 16
+    tf = S.ToFlow(C, 512)
+    sd = {"f.bias": rnd(seed + 6, 1, 3, 1, 1, std=0.1), "f.conv.weight": rnd(seed + 7, 1, 3, C, 1, 1, std=0.3),
+          "f.conv.modulation.weight": rnd(seed + 8, C, 512), "f.conv.modulation.bias": 1 + rnd(seed + 9, C, std=0.1)}
+    tf.bias.data.copy_(sd["f.bias"])
+    tf.conv.weight.data.copy_(sd["f.conv.weight"])
+    tf.conv.modulation.weight.data.copy_(sd["f.conv.modulation.weight"])
+    tf.conv.modulation.bias.data.copy_(sd["f.conv.modulation.bias"])
+    x = rnd(seed + 10, 2, C, R, R)
+    feat = rnd(seed + 11, 2, C, R, R)
+    pflow = rnd(seed + 12, 2, 3, R // 2, R // 2, std=0.5)
+    with torch.no_grad():
+        fw, bl, o3, grid = tf(x, style, feat, pflow)
+    ofw, obl, oo3, ogrid = O.to_flow(x, style, feat, sd, "f", pflow)
+    print("  toflow feat_warp %.3e blend %.3e out %.3e grid %.3e (max|d|)" % (
+        maxdiff(ofw, fw)[0], maxdiff(obl, bl)[0], maxdiff(oo3, o3)[0], maxdiff(ogrid, grid)[0]))
+    arrs.update(tf_x=x, tf_feat=feat, tf_prev=pflow, tf_warp=fw, tf_blend=bl, tf_out=o3, tf_grid=grid,
+                tf_bias=sd["f.bias"], tf_w=sd["f.conv.weight"], tf_mw=sd["f.conv.modulation.weight"],
+                tf_mb=sd["f.conv.modulation.bias"])
+    tr = S.ToRGB(C, 512)
+    sdr = {"r.bias": rnd(seed + 13, 1, 3, 1, 1, std=0.1), "r.conv.0.weight": rnd(seed + 14, 3, C, 1, 1),
+           "r.conv.1.bias": rnd(seed + 15, 1, 3, 1, 1, std=0.1)}
+    tr.bias.data.copy_(sdr["r.bias"])
+    tr.conv[0].weight.data.copy_(sdr["r.conv.0.weight"])
+    tr.conv[1].bias.data.copy_(sdr["r.conv.1.bias"])
+    prgb = rnd(seed + 16, 2, 3, R // 2, R // 2)
+    with torch.no_grad():
+        ref = tr(fw, prgb)
+    orc = O.to_rgb(fw, sdr, "r", prgb)
+    print("  torgb  oracle-ref max|d| %.3e" % maxdiff(orc, ref)[0])
+    arrs.update(tr_prev=prgb, tr_out=ref, tr_bias=sdr["r.bias"], tr_w=sdr["r.conv.0.weight"], tr_b1=sdr["r.conv.1.bias"])
+    # Direction (QR) - once per clip
+    dw = rnd(seed + 17, 512, 20)
+    dm = S.Direction(20)
+    dm.weight.data.copy_(dw)
+    lam = rnd(seed + 18, 2, 20)
+    with torch.no_grad():
+        ref = dm(lam)
+    orc = O.direction({"direction.weight": dw}, lam)
+    print("  direction oracle-ref max|d| %.3e" % maxdiff(orc, ref)[0])
+    arrs.update(dir_w=dw, dir_lam=lam, dir_out=ref)
+    save("dec_units", **arrs)
+
+
+def gen_dec(ns, size, seed, n_frames, sparse):
+    print("[decoder size %d]" % size)
+    d, sd = ref_dec(ns, size, seed)
+    feats = weights.synth_feats(size, seed=seed)
+    s_r = rnd(seed + 21, 1, 512)
+    r_d = rnd(seed + 22, 1, n_frames, 512, std=0.5)
+    # the reference's own decode loop + post-process, called unbound (FLOAT.py:113-169)
+    FL = ns.FLOAT.FLOAT
+    fake = types.SimpleNamespace(motion_autoencoder=types.SimpleNamespace(dec=d),
+                                 pbar=types.SimpleNamespace(update=lambda n: None))
+    with torch.no_grad():
+        frames = FL.decode_latent_into_processed_images(fake, s_r, feats, r_d)
+        raw0, flow0 = d(s_r + r_d[:, 0], None, feats)
+    orc = O.decode_frames(sd, s_r, r_d, feats)
+    orc64 = O.decode_frames(sd, s_r, r_d, feats, dtype=torch.float64)
+    print("  frames oracle32-ref max|d| %.3e ; ref-oracle64 max|d| %.3e ; frame mean %.3f std %.3f sat %.3f" % (
+        maxdiff(orc, frames)[0], maxdiff(frames, orc64)[0], float(frames.mean()), float(frames.std()),
+        float(((frames == 0) | (frames == 1)).float().mean())))
+    arrs = dict(seed=seed, size=size, s_r=s_r, r_d=r_d, raw0_mean=float(raw0.mean()), raw0_std=float(raw0.std()))
+    if sparse:
+        # full 512x512 frames are 3 MB each: keep a strided lattice that hits every pixel parity,
+        # a full-resolution band, and per-frame statistics
+        arrs["lattice"] = frames[:, ::7, ::5]
+        arrs["band"] = frames[:, 250:258]
+        arrs["mean"] = frames.mean(dim=(1, 2, 3))
+        arrs["sqmean"] = frames.pow(2).mean(dim=(1, 2, 3))
+        arrs["raw0_lattice"] = raw0[0][:, ::7, ::5]
+    else:
+        arrs["frames"] = frames
+        arrs["raw0"] = raw0
+        arrs["flow0"] = flow0
+    save("dec_%d" % size, **arrs)
+
+
+def main():
+    ns = ref_import.load()
+    small = config.small_fmt_config()
+    full = config.FmtConfig()
+    gen_fmt_eval(ns, small, "small", seed=100)
+    gen_fmt_eval(ns, full, "full", seed=200)
+    gen_fmt_sample(ns, small, "small_static", seed=300, T=125, nfe=5, dynamic=False, a=2.0, e=1.0)
+    gen_fmt_sample(ns, small, "small_dynamic", seed=400, T=125, nfe=5, dynamic=True, a=1.0, e=3.0)
+    gen_fmt_sample(ns, full, "full_static", seed=500, T=25, nfe=10, dynamic=False, a=2.0, e=1.0)
+    gen_dec_units(ns, seed=600)
+    gen_dec(ns, 64, seed=700, n_frames=3, sparse=False)
+    gen_dec(ns, 512, seed=800, n_frames=2, sparse=True)
+
+
+if __name__ == "__main__":
+    main()
