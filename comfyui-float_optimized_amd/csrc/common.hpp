@@ -1,0 +1,174 @@
+// Shared device/host helpers for libfloat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/float_hip.h"
+
+// ---------------------------------------------------------------- error plumbing
+void fh_set_error(const char* fmt, ...);
+#define FH_CHECK_HIP(expr)                                                                   \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      fh_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return FLOAT_E_HIP;                                                                    \
+    }                                                                                        \
+  } while (0)
+#define FH_REQUIRE(cond, ...)     \
+  do {                            \
+    if (!(cond)) {                \
+      fh_set_error(__VA_ARGS__);  \
+      return FLOAT_E_INVALID;     \
+    }                             \
+  } while (0)
+
+// ---------------------------------------------------------------- 16-bit operand types
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // one 16-byte MFMA operand fragment
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+
+struct BF16 {
+  typedef bf16x8_t vec8;
+  static __device__ __forceinline__ u16 from_float(float x) {
+    __bf16 b = (__bf16)x;  // RNE; hipcc emits v_cvt_pk_bf16_f32 on gfx950 (keeps NaN a NaN)
+    return __builtin_bit_cast(u16, b);
+  }
+  static __device__ __forceinline__ float to_float(u16 v) {
+    return __builtin_bit_cast(float, ((uint32_t)v) << 16);
+  }
+  static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
+  }
+  static u16 host_from_float(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u16)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (u16)(u >> 16);
+  }
+};
+
+struct FP16 {
+  typedef f16x8_t vec8;
+  static __device__ __forceinline__ u16 from_float(float x) {
+    // saturate instead of overflowing to inf: activations beyond 65504 would poison a frame
+    x = fminf(fmaxf(x, -65504.f), 65504.f);
+    _Float16 h = (_Float16)x;
+    return __builtin_bit_cast(u16, h);
+  }
+  static __device__ __forceinline__ float to_float(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
+  static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
+  }
+  static u16 host_from_float(float x) {
+    // round-to-nearest-even fp32 -> fp16 on the host (weight packing)
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    uint32_t sign = (u >> 16) & 0x8000u;
+    uint32_t ax = u & 0x7fffffffu;
+    if (ax > 0x7f800000u) return (u16)(sign | 0x7e00u);
+    if (ax >= 0x477ff000u) return (u16)(sign | 0x7bffu);  // saturate to 65504
+    if (ax < 0x33000001u) return (u16)sign;               // underflow to 0
+    int e = (int)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u;
+    int shift;
+    uint32_t base;
+    if (e < -14) {  // subnormal half
+      shift = 13 + (-14 - e);
+      base = 0;
+    } else {
+      shift = 13;
+      base = (uint32_t)(e + 15) << 10;
+      m &= 0x7fffffu;
+    }
+    uint32_t r = m >> shift;
+    uint32_t rem = m & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (r & 1u))) r++;
+    return (u16)(sign | (base + r));
+  }
+};
+
+// ---------------------------------------------------------------- small device math
+__device__ __forceinline__ float fh_silu(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float fh_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float fh_gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
+  float u = k0 * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float fh_lrelu_s2(float x) {  // leaky_relu(x, 0.2) * sqrt(2)
+  return (x > 0.f ? x : 0.2f * x) * 1.4142135623730951f;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- host-side tensor table
+struct TensorTable {
+  std::map<std::string, const float_tensor_t*> m;
+  TensorTable(const float_tensor_t* t, int n) {
+    for (int i = 0; i < n; ++i) m[t[i].name] = &t[i];
+  }
+  const float_tensor_t* find(const std::string& k) const {
+    auto it = m.find(k);
+    return it == m.end() ? nullptr : it->second;
+  }
+  static int64_t numel(const float_tensor_t* t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+  }
+};
+
+// Simple owning list of device allocations for a handle.
+struct DevicePool {
+  std::vector<void*> ptrs;
+  size_t total = 0;
+  template <typename T>
+  int alloc(T** out, size_t count, bool zero = true) {
+    void* p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {
+      fh_set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+      return FLOAT_E_NOMEM;
+    }
+    if (zero) {
+      e = hipMemset(p, 0, bytes);
+      if (e != hipSuccess) {
+        fh_set_error("hipMemset failed: %s", hipGetErrorString(e));
+        return FLOAT_E_HIP;
+      }
+    }
+    ptrs.push_back(p);
+    total += bytes;
+    *out = (T*)p;
+    return FLOAT_OK;
+  }
+  void release() {
+    for (void* p : ptrs) (void)hipFree(p);
+    ptrs.clear();
+  }
+};
+
+// Kernel-class profiling (float_profile_ms): events recorded on the caller's stream.
+struct ProfileSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+};
+extern int g_fh_profiling;
+void fh_prof_begin(int which, hipStream_t s);
+void fh_prof_end(int which, hipStream_t s);

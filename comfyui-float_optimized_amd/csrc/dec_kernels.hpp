@@ -1,0 +1,404 @@
+// HIP kernels of the Synthesis decoder (reference styledecoder.py:195-425, 497-534), batched over
+// frames.  Activations are NHWC 16-bit; accumulation, style/demod, flow and rgb pyramids are fp32.
+//
+// ModulatedConv2d is evaluated as "scale the input channels by the style, convolve with the SHARED
+// weight, scale the output channels by the demodulation factor" (identical algebra to modulating
+// the weight per sample, styledecoder.py:241-246), so one weight tensor serves every frame of the
+// batch and the conv becomes an implicit GEMM with M = frames*pixels.
+#pragma once
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------
+// out[f][j] = epi( sum_k in[f][k]^(1|2) * Wt[k][j] ), fp32, Wt stored k-major so lanes read
+// consecutive j.  Used for the 22 EqualLinear style modulations (styledecoder.py:229,241) in one
+// launch and for the demodulation factors rsqrt(scale^2 * sum_i s_i^2 * Wsq[o][i] + 1e-8)
+// (styledecoder.py:244-245 with the weight factored out).
+enum { SG_STYLE = 0, SG_DEMOD = 1 };
+template <int MODE, int FB>
+__global__ __launch_bounds__(256) void dec_small_gemm_kernel(const float* __restrict__ in, int ld_in, const float* __restrict__ in2,
+                                                             const float* __restrict__ Wt, int K, int N,
+                                                             const float* __restrict__ bias, float alpha,
+                                                             float* __restrict__ out, int ld_out, int F) {
+  extern __shared__ float sin_[];  // [FB][K]
+  const int f0 = blockIdx.y * FB;
+  for (int i = threadIdx.x; i < FB * K; i += 256) {
+    const int fl = i / K, k = i % K;
+    float v = 0.f;
+    if (f0 + fl < F) {
+      v = in[(size_t)(f0 + fl) * ld_in + k];
+      if (MODE == SG_STYLE && in2) v += in2[k];  // latent = s_r + r_d[t]  (FLOAT.py:158)
+      if (MODE == SG_DEMOD) v = v * v;
+    }
+    sin_[i] = v;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  float acc[FB];
+#pragma unroll
+  for (int f = 0; f < FB; ++f) acc[f] = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const float w = Wt[(size_t)k * N + j];
+#pragma unroll
+    for (int f = 0; f < FB; ++f) acc[f] += sin_[f * K + k] * w;
+  }
+#pragma unroll
+  for (int f = 0; f < FB; ++f) {
+    if (f0 + f >= F) break;
+    float v;
+    if (MODE == SG_STYLE) v = acc[f] * alpha + bias[j];
+    else v = rsqrtf(acc[f] * alpha + 1e-8f);
+    out[(size_t)(f0 + f) * ld_out + j] = v;
+  }
+}
+
+// ConstantInput repeated over the batch and pre-scaled by conv1's style (styledecoder.py:289-299, 513-514).
+template <class T>
+__global__ void dec_input_kernel(u16* __restrict__ out, const float* __restrict__ cin_hwc, const float* __restrict__ s, int ld_s,
+                                 int F, int HW, int C) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= F * HW * C) return;
+  const int c = idx % C, f = idx / (HW * C);
+  out[idx] = T::from_float(cin_hwc[idx % (HW * C)] * s[(size_t)f * ld_s + c]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Implicit-GEMM convolution over a tap list.  M = output pixels (256 per workgroup: nf frames x
+// th x tw), N = BN output channels, K = taps x Cin in chunks of 32 input channels.  The input halo
+// tile and the weight slab of the chunk are staged in LDS once and re-used by every tap.
+struct ConvArgs {
+  const u16* X;   // [F][Hi][Wi][Cin], already multiplied by the layer's style
+  const u16* Wt;  // [ntaps][Cout][Cin]
+  u16* Y;         // [F][OH][OW][Cout]
+  const float* demod;  // [F][ldd] (offset applied) or nullptr
+  const float* bias;   // [Cout] or nullptr
+  const float* snext;  // [F][lds] (offset applied) or nullptr: style of the consumer layer
+  int F, Hi, Wi, Cin, Cout;
+  int Ho, Wo;          // output grid computed by this launch (per frame)
+  int OH, OW, sy, sx, py, px;  // output pixel (oy*sy+py, ox*sx+px) of the OH x OW image
+  int ldd, lds;
+  int ntaps, dymin, dxmin, hh, hw;  // halo tile = (th + dy range) x (tw + dx range)
+  int lth, ltw, lnf;                // log2 of tile height / width / frames per tile
+  int tiles_x, tiles_y;
+  int act;                          // 1: + bias, leaky_relu(0.2) * sqrt(2)
+  signed char dy[9], dx[9];
+};
+
+template <class T, int NT>
+__global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
+  constexpr int BN = NT * 16;
+  constexpr int KC = 32;
+  constexpr int MAXA = 9;  // halo pixels * 4 chunks / 256 threads, worst case 16 x 6 x 6
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int th = 1 << g.lth, tw = 1 << g.ltw, nf = 1 << g.lnf;
+  int tile = blockIdx.x;
+  const int tx = tile % g.tiles_x;
+  tile /= g.tiles_x;
+  const int ty = tile % g.tiles_y;
+  const int fb = tile / g.tiles_y;
+  const int n0 = blockIdx.y * BN;
+  const int npix = nf * g.hh * g.hw;
+  unsigned char* sA = smem;                 // [npix][64 B]
+  unsigned char* sB = smem + npix * 64;     // [ntaps][BN][64 B]
+
+  // global element offsets of this thread's halo chunks (constant over the channel loop)
+  int aoff[MAXA];
+  const int iy0 = ty * th + g.dymin, ix0 = tx * tw + g.dxmin;
+#pragma unroll
+  for (int i = 0; i < MAXA; ++i) {
+    const int e = tid + i * 256;
+    const int p = e >> 2, ch = e & 3;
+    aoff[i] = -1;
+    if (p < npix) {
+      const int fl = p / (g.hh * g.hw);
+      const int rem = p - fl * g.hh * g.hw;
+      const int hy = rem / g.hw, hx = rem - hy * g.hw;
+      const int f = fb * nf + fl, iy = iy0 + hy, ix = ix0 + hx;
+      if (f < g.F && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) aoff[i] = ((f * g.Hi + iy) * g.Wi + ix) * g.Cin + ch * 8;
+      else aoff[i] = -2;  // in-tile, zero padding
+    }
+  }
+  // LDS pixel index of this lane's row in each of the wave's 4 m-tiles (tap (dymin,dxmin))
+  int pbase[4];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = (w * 4 + mt) * 16 + r16;
+    const int x = m & (tw - 1), y = (m >> g.ltw) & (th - 1), fl = m >> (g.ltw + g.lth);
+    pbase[mt] = fl * g.hh * g.hw + y * g.hw + x;
+  }
+
+  f32x4 acc[4][NT];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nb = g.ntaps * BN * 4;  // 16-byte chunks of the weight slab
+  for (int c0 = 0; c0 < g.Cin; c0 += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < MAXA; ++i) {
+      if (aoff[i] != -1) {
+        u32x4 v = u32x4{0u, 0u, 0u, 0u};
+        if (aoff[i] >= 0) v = *reinterpret_cast<const u32x4*>(g.X + (size_t)aoff[i] + c0);
+        *reinterpret_cast<u32x4*>(sA + (size_t)(tid + i * 256) * 16) = v;
+      }
+    }
+    for (int e = tid; e < nb; e += 256) {
+      const int row = e >> 2, ch = e & 3;   // row = tap * BN + n
+      const int tap = row / BN, n = row - tap * BN;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+      *reinterpret_cast<u32x4*>(sB + (size_t)e * 16) = v;
+    }
+    __syncthreads();
+    for (int t = 0; t < g.ntaps; ++t) {
+      const int shift = (g.dy[t] - g.dymin) * g.hw + (g.dx[t] - g.dxmin);
+      u32x4 a[4], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const u32x4*>(sA + (size_t)(pbase[mt] + shift) * 64 + q * 16);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + (size_t)((t * BN + j * 16 + r16) * 64 + q * 16));
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(a[mt], b[j], acc[mt][j]);
+    }
+  }
+
+  // epilogue: C/D map row = q*4 + r (pixel), col = r16 (channel)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = (w * 4 + mt) * 16 + q * 4 + r;
+      const int x = m & (tw - 1), y = (m >> g.ltw) & (th - 1), fl = m >> (g.ltw + g.lth);
+      const int f = fb * nf + fl, oy = ty * th + y, ox = tx * tw + x;
+      if (f >= g.F || oy >= g.Ho || ox >= g.Wo) continue;
+      u16* yp = g.Y + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + r16;
+        float v = acc[mt][j][r];
+        if (g.demod) v *= g.demod[(size_t)f * g.ldd + co];
+        if (g.act) v = fh_lrelu_s2(v + g.bias[co]);
+        if (g.snext) v *= g.snext[(size_t)f * g.lds + co];
+        yp[co] = T::from_float(v);
+      }
+    }
+  }
+}
+
+// Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4) over the
+// transposed-conv output z (R+1 x R+1), then + bias, leaky-relu*sqrt2, and the style of the next
+// conv (styledecoder.py:209-213,255-258 then 320-325).  8 channels per thread.
+template <class T>
+__global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z, u16* __restrict__ out, int F, int R, int C,
+                                                       const float* __restrict__ bias, const float* __restrict__ snext, int lds) {
+  const int c8 = C >> 3;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)F * R * R * c8) return;
+  const int cg = (int)(idx % c8);
+  size_t p = idx / c8;
+  const int X = (int)(p % R);
+  p /= R;
+  const int Y = (int)(p % R);
+  const int f = (int)(p / R);
+  const int Z = R + 1;
+  const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int zy = Y + a - 1;
+    if (zy < 0 || zy > R) continue;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int zx = X + b - 1;
+      if (zx < 0 || zx > R) continue;
+      const float wgt = k1[a] * k1[b];
+      const uint4 u = *reinterpret_cast<const uint4*>(z + ((size_t)(f * Z + zy) * Z + zx) * C + cg * 8);
+      const u16* e = reinterpret_cast<const u16*>(&u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] += wgt * T::to_float(e[i]);
+    }
+  }
+  uint4 o;
+  u16* oe = reinterpret_cast<u16*>(&o);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cg * 8 + i;
+    oe[i] = T::from_float(fh_lrelu_s2(acc[i] + bias[c]) * snext[(size_t)f * lds + c]);
+  }
+  *reinterpret_cast<uint4*>(out + ((size_t)(f * R + Y) * R + X) * C + cg * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// ToFlow + ToRGB of one level, fused (styledecoder.py:399-425, 378-386, wiring 521-529):
+//   o      = 1x1 modconv(x)(no demod) + bias (+ Upsample(prev flow))           3 channels
+//   grid   = tanh(o[0:2]) + identity(linspace(-1,1,R)),  mask = sigmoid(o[2])
+//   warp   = grid_sample(feat, grid, bilinear, zeros, align_corners=False) * mask
+//   xnext  = (warp + x * (1 - mask)) * style_of_next_conv                       -> next level
+//   rgb    = lrelu(conv1x1(warp)/sqrt(C) + b1)*sqrt2 + b2 (+ Upsample(prev rgb))
+// C/8 lanes share one pixel (8 channels each); `warp` never leaves registers.
+struct FlowArgs {
+  const u16* x;        // [F][R][R][C] conv2 output (unscaled)
+  const u16* feat;     // [R][R][C]
+  const float* pflow;  // [F][R/2][R/2][3] or nullptr
+  const float* prgb;   // [F][R/2][R/2][3] or nullptr
+  const float* wflow;  // [3][C], already * 1/sqrt(C)
+  const float* sflow;  // [F][ld_s] style of the ToFlow conv (offset applied)
+  const float* bflow;  // [3]
+  const float* wrgb;   // [3][C], already * 1/sqrt(C)
+  const float* b1;     // [3] FusedLeakyReLU bias
+  const float* b2;     // [3] ToRGB bias
+  const float* snext;  // [F][ld_s] or nullptr
+  u16* xnext;          // [F][R][R][C] or nullptr (last level)
+  float* flow_out;     // [F][R][R][3]
+  float* rgb_out;      // [F][R][R][3]
+  float* final_out;    // last level: frames
+  int final_mode;      // 0: none, 1: HWC clamp(-1,1)*0.5+0.5 (FLOAT.py:149-152), 2: raw CHW
+  int F, R, C, ld_s;
+};
+
+__device__ __forceinline__ float up2_tap(const float* __restrict__ prev, int f, int Rp, int Y, int X, int j) {
+  // Upsample([1,3,3,1]) of a 3-channel map (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR
+  // gain 4 -> per axis: even 2m: .25*p[m-1] + .75*p[m];  odd 2m+1: .75*p[m] + .25*p[m+1]
+  const int my = Y >> 1, mx = X >> 1;
+  const int y0 = (Y & 1) ? my : my - 1, x0 = (X & 1) ? mx : mx - 1;
+  const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
+  float acc = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int yy = y0 + a;
+    if (yy < 0 || yy >= Rp) continue;
+    const float wy = a ? (1.f - wy0) : wy0;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int xx = x0 + b;
+      if (xx < 0 || xx >= Rp) continue;
+      const float wx = b ? (1.f - wx0) : wx0;
+      acc += wy * wx * prev[((size_t)(f * Rp + yy) * Rp + xx) * 3 + j];
+    }
+  }
+  return acc;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
+  const int lpp = g.C >> 3;          // lanes per pixel (4..64)
+  const int ppb = 256 / lpp;         // pixels per block iteration
+  const int f = blockIdx.y;
+  const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp;
+  const int c0 = sub * 8;
+  float wf[3][8], wr[3][8], sn[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float s = g.sflow[(size_t)f * g.ld_s + c0 + i];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      wf[j][i] = g.wflow[j * g.C + c0 + i] * s;
+      wr[j][i] = g.wrgb[j * g.C + c0 + i];
+    }
+    sn[i] = g.snext ? g.snext[(size_t)f * g.ld_s + c0 + i] : 0.f;
+  }
+  const int R = g.R, npix = R * R;
+  const float fR = (float)R;
+  const double lin_step = R > 1 ? 2.0 / (double)(R - 1) : 0.0;
+  for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
+    const int Y = p / R, X = p - Y * R;
+    const size_t po = ((size_t)f * npix + p);
+    const uint4 xu = *reinterpret_cast<const uint4*>(g.x + po * g.C + c0);
+    const u16* xe = reinterpret_cast<const u16*>(&xu);
+    float xf[8];
+    float o[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      xf[i] = T::to_float(xe[i]);
+      o[0] += wf[0][i] * xf[i];
+      o[1] += wf[1][i] * xf[i];
+      o[2] += wf[2][i] * xf[i];
+    }
+    for (int d = 1; d < lpp; d <<= 1) {
+      o[0] += __shfl_xor(o[0], d, 64);
+      o[1] += __shfl_xor(o[1], d, 64);
+      o[2] += __shfl_xor(o[2], d, 64);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      o[j] += g.bflow[j];
+      if (g.pflow) o[j] += up2_tap(g.pflow, f, R >> 1, Y, X, j);
+    }
+    // identity grid: np.linspace(-1, 1, R) in float64, cast to float32 (styledecoder.py:404-413)
+    const float gx = (X == R - 1) ? 1.f : (float)(-1.0 + (double)X * lin_step);
+    const float gy = (Y == R - 1) ? 1.f : (float)(-1.0 + (double)Y * lin_step);
+    const float sx = tanhf(o[0]) + gx, sy = tanhf(o[1]) + gy;
+    const float mask = fh_sigmoid(o[2]);
+    // grid_sample, align_corners=False: pixel = ((coord + 1) * size - 1) / 2
+    const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const float ax = ix - fx0, ay = iy - fy0;
+    float fw[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fw[i] = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int yy = y0 + a;
+      if (yy < 0 || yy >= R) continue;
+      const float wy = a ? ay : 1.f - ay;
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int xx = x0 + b;
+        if (xx < 0 || xx >= R) continue;
+        const float wgt = wy * (b ? ax : 1.f - ax);
+        const uint4 fu = *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * g.C + c0);
+        const u16* fe = reinterpret_cast<const u16*>(&fu);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fw[i] += wgt * T::to_float(fe[i]);
+      }
+    }
+    float rgb[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      fw[i] *= mask;
+      rgb[0] += wr[0][i] * fw[i];
+      rgb[1] += wr[1][i] * fw[i];
+      rgb[2] += wr[2][i] * fw[i];
+    }
+    if (g.xnext) {
+      uint4 ou;
+      u16* oe = reinterpret_cast<u16*>(&ou);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + xf[i] * (1.f - mask)) * sn[i]);
+      *reinterpret_cast<uint4*>(g.xnext + po * g.C + c0) = ou;
+    }
+    for (int d = 1; d < lpp; d <<= 1) {
+      rgb[0] += __shfl_xor(rgb[0], d, 64);
+      rgb[1] += __shfl_xor(rgb[1], d, 64);
+      rgb[2] += __shfl_xor(rgb[2], d, 64);
+    }
+    if (sub == 0) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        float v = fh_lrelu_s2(rgb[j] + g.b1[j]) + g.b2[j];
+        if (g.prgb) v += up2_tap(g.prgb, f, R >> 1, Y, X, j);
+        g.flow_out[po * 3 + j] = o[j];
+        g.rgb_out[po * 3 + j] = v;
+        if (g.final_mode == 1) g.final_out[po * 3 + j] = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
+        else if (g.final_mode == 2) g.final_out[((size_t)f * 3 + j) * npix + p] = v;
+      }
+    }
+  }
+}
+
+// Encoder skip feature NCHW fp32 -> NHWC 16-bit (once per clip).
+template <class T>
+__global__ void dec_feat_pack_kernel(u16* __restrict__ out, const float* __restrict__ in, int C, int HW) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= C * HW) return;
+  const int c = idx % C, p = idx / C;
+  out[idx] = T::from_float(in[(size_t)c * HW + p]);
+}

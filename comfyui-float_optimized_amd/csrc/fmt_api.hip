@@ -1,0 +1,642 @@
+// C-ABI entry points of the FMT operator (include/float_hip.h) and the host-side launch chain.
+#include <math.h>
+
+#include "fmt_kernels.hpp"
+
+namespace {
+
+struct Lin {
+  u16* W = nullptr;     // [N][K] 16-bit, K padded to 256
+  float* b = nullptr;   // [N]
+  int N = 0, K = 0;
+};
+
+struct Blk {
+  Lin qkv, proj, fc1, fc2;
+};
+
+constexpr int kMaxSteps = 1024;  // FloatAdvancedParameters.nfe max is 1000 (nodes_adv.py:184-190)
+
+}  // namespace
+
+struct float_fmt {
+  float_fmt_cfg_t cfg;
+  DevicePool pool;
+  int D, ntok, Mpad, Kc, Ntot, Kx;
+  Lin x_embed, t0, t2, c_embed, adaln_all, final_lin;
+  std::vector<Blk> blk;
+  float* pos = nullptr;
+  float* freqs = nullptr;
+  // workspace
+  u16 *cond16, *sc16, *h16, *qkv16, *att16, *hid16, *xin16, *tsin16, *th16;
+  float *ccond, *mod, *xres, *xcur, *temb, *ts_dev, *vout;
+  float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
+  // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, scales)
+  struct GraphKey {
+    int nfe, bc, we_len;
+    float a, r, e;
+    bool operator<(const GraphKey& o) const {
+      return memcmp(this, &o, sizeof(GraphKey)) < 0;
+    }
+  };
+  std::map<GraphKey, hipGraphExec_t> graphs;
+  hipStream_t cap_stream = nullptr;
+};
+
+namespace {
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+template <class T>
+int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
+                Lin* out) {
+  // Concatenate the named Linear layers along N (used to fuse every adaLN projection into one GEMM).
+  const int Kp = round_up(K, 256);
+  const int N = N_each * (int)names.size();
+  std::vector<u16> hw((size_t)N * Kp, 0);
+  std::vector<float> hb(N, 0.f);
+  int n0 = 0;
+  for (const std::string& nm : names) {
+    const float_tensor_t* w = tt.find(nm + ".weight");
+    const float_tensor_t* b = tt.find(nm + ".bias");
+    if (!w || !b) {
+      fh_set_error("missing checkpoint tensor '%s.weight/.bias'", nm.c_str());
+      return FLOAT_E_MISSING;
+    }
+    if (w->ndim != 2 || w->shape[0] != N_each || w->shape[1] != K || TensorTable::numel(b) != N_each) {
+      fh_set_error("tensor '%s.weight' has shape (%lld,%lld), expected (%d,%d)", nm.c_str(), (long long)w->shape[0],
+                   (long long)(w->ndim > 1 ? w->shape[1] : 0), N_each, K);
+      return FLOAT_E_INVALID;
+    }
+    for (int n = 0; n < N_each; ++n) {
+      const float* src = w->data + (size_t)n * K;
+      u16* dst = hw.data() + (size_t)(n0 + n) * Kp;
+      for (int k = 0; k < K; ++k) dst[k] = T::host_from_float(src[k]);
+      hb[n0 + n] = b->data[n];
+    }
+    n0 += N_each;
+  }
+  int rc;
+  if ((rc = h->pool.alloc(&out->W, hw.size(), false))) return rc;
+  if ((rc = h->pool.alloc(&out->b, hb.size(), false))) return rc;
+  FH_CHECK_HIP(hipMemcpy(out->W, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipMemcpy(out->b, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+  out->N = N;
+  out->K = Kp;
+  return FLOAT_OK;
+}
+
+template <class T, int MT, int EPI>
+void set_attr() {
+  constexpr int smem = 4 * MT * 16 * 32 * (int)sizeof(float);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fmt_gemm_kernel<T, MT, 2, EPI>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+}
+template <class T, int MT>
+void set_attr_mt() {
+  set_attr<T, MT, EPI_F32>();
+  set_attr<T, MT, EPI_T16>();
+  set_attr<T, MT, EPI_SILU_T16>();
+  set_attr<T, MT, EPI_GELU_T16>();
+  set_attr<T, MT, EPI_GATE_RES>();
+  set_attr<T, MT, EPI_CFG>();
+}
+template <class T>
+void prime_kernels() {
+  set_attr_mt<T, 4>();
+  set_attr_mt<T, 12>();
+  set_attr_mt<T, 15>();
+  set_attr<T, 4, EPI_XEMBED>();
+}
+
+template <class T, int MT, int EPI>
+int launch_gemm_mt(const GemmArgs& g, hipStream_t s) {
+  constexpr int smem = 4 * MT * 16 * 32 * (int)sizeof(float);
+  dim3 grid(g.N / 32, (g.M + MT * 16 - 1) / (MT * 16));
+  fh_prof_begin(0, s);
+  hipLaunchKernelGGL((fmt_gemm_kernel<T, MT, 2, EPI>), grid, dim3(256), smem, s, g);
+  fh_prof_end(0, s);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+template <class T, int EPI>
+int launch_gemm(const GemmArgs& g, int mt, hipStream_t s) {
+  if (g.N % 32 || g.K % 256) {
+    fh_set_error("gemm shape N=%d K=%d not tileable", g.N, g.K);
+    return FLOAT_E_INVALID;
+  }
+  if constexpr (EPI == EPI_XEMBED) {
+    if (mt == 4) return launch_gemm_mt<T, 4, EPI>(g, s);
+  } else {
+    switch (mt) {
+      case 4: return launch_gemm_mt<T, 4, EPI>(g, s);
+      case 12: return launch_gemm_mt<T, 12, EPI>(g, s);
+      case 15: return launch_gemm_mt<T, 15, EPI>(g, s);
+    }
+  }
+  fh_set_error("unsupported m-tile count %d", mt);
+  return FLOAT_E_INVALID;
+}
+
+GemmArgs base_args(const u16* A, int lda, const Lin& L, int M) {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.A = A;
+  g.lda = lda;
+  g.W = L.W;
+  g.bias = L.b;
+  g.K = L.K;
+  g.N = L.N;
+  g.M = M;
+  return g;
+}
+
+template <class T>
+int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s) {
+  const int nv = h->D / 256;
+  dim3 grid((M + 3) / 4);
+#define LN_CASE(NV)                                                                                              \
+  case NV:                                                                                                       \
+    hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV>), grid, dim3(256), 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, \
+                       h->D);                                                                                    \
+    break;
+  switch (nv) {
+    LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8)
+    default:
+      fh_set_error("dim_h %d unsupported (must be 256*{1,2,4,8})", h->D);
+      return FLOAT_E_INVALID;
+  }
+#undef LN_CASE
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+// One evaluation of the velocity field on the rows already staged in the workspace.
+// step: index into temb / ts; euler: update xcur/xin16 with dt, else write vout.
+template <class T>
+int run_eval(float_fmt* h, int bc, int step, bool euler, float dt, float a, float r, float e, hipStream_t s) {
+  const float_fmt_cfg_t& c = h->cfg;
+  const int D = h->D, ntok = h->ntok, M = bc * ntok;
+  const int mt = (M + 15) / 16;
+  int rc;
+  // sc = silu(t_emb + c_cond), once per evaluation, shared by every adaLN projection
+  hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 4 + 255) / 256), dim3(256), 0, s, h->sc16,
+                     h->temb + (size_t)step * D, h->ccond, M, D);
+  // every adaLN modulation of the evaluation in one weight-streaming GEMM: mod[M][depth*6D + 2D]
+  {
+    GemmArgs g = base_args(h->sc16, D, h->adaln_all, M);
+    g.out_f32 = h->mod;
+    g.ldo = h->Ntot;
+    if ((rc = launch_gemm<T, EPI_F32>(g, mt, s))) return rc;
+  }
+  // x_embedder + pos_embed; the CFG rows share x, so 60 rows are computed and broadcast
+  {
+    GemmArgs g = base_args(h->xin16, h->Kx, h->x_embed, ntok);
+    g.out_f32 = h->xres;
+    g.ldo = D;
+    g.pos = h->pos;
+    g.bc = bc;
+    g.ntok = ntok;
+    if ((rc = launch_gemm<T, EPI_XEMBED>(g, 4, s))) return rc;
+  }
+  for (int b = 0; b < c.depth; ++b) {
+    const float* mod = h->mod + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    const Blk& B = h->blk[b];
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
+    {
+      GemmArgs g = base_args(h->h16, D, B.qkv, M);
+      g.out16 = h->qkv16;
+      g.ldo16 = 3 * D;
+      if ((rc = launch_gemm<T, EPI_T16>(g, mt, s))) return rc;
+    }
+    hipLaunchKernelGGL((fmt_attn_kernel<T>), dim3(bc * c.heads), dim3(256), 0, s, h->qkv16, 3 * D, h->att16, D, ntok,
+                       c.heads, D, c.attn_window);
+    {
+      GemmArgs g = base_args(h->att16, D, B.proj, M);
+      g.out_f32 = h->xres;
+      g.ldo = D;
+      g.gate = mod + 2 * D;
+      g.ldg = h->Ntot;
+      if ((rc = launch_gemm<T, EPI_GATE_RES>(g, mt, s))) return rc;
+    }
+    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s))) return rc;
+    {
+      GemmArgs g = base_args(h->h16, D, B.fc1, M);
+      g.out16 = h->hid16;
+      g.ldo16 = c.mlp_hidden;
+      if ((rc = launch_gemm<T, EPI_GELU_T16>(g, mt, s))) return rc;
+    }
+    {
+      GemmArgs g = base_args(h->hid16, c.mlp_hidden, B.fc2, M);
+      g.out_f32 = h->xres;
+      g.ldo = D;
+      g.gate = mod + 5 * D;
+      g.ldg = h->Ntot;
+      if ((rc = launch_gemm<T, EPI_GATE_RES>(g, mt, s))) return rc;
+    }
+  }
+  {
+    const float* mod = h->mod + (size_t)c.depth * 6 * D;  // shift, scale (FMT.py:196)
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
+    GemmArgs g = base_args(h->h16, D, h->final_lin, M);
+    g.bc = bc;
+    g.ntok = ntok;
+    g.n_prev = c.n_prev;
+    g.a_cfg = a;
+    g.r_cfg = r;
+    g.e_cfg = e;
+    g.dt = dt;
+    if (euler) {
+      g.xcur = h->xcur;
+      g.xin16 = h->xin16;
+      g.ldx = h->Kx;
+    } else {
+      g.vout = h->vout;
+    }
+    if ((rc = launch_gemm<T, EPI_CFG>(g, mt, s))) return rc;
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+// torch.linspace(0, 1, n) in fp32: symmetric evaluation around the midpoint.
+void linspace01(int n, std::vector<float>* ts) {
+  ts->resize(n);
+  if (n == 1) {
+    (*ts)[0] = 0.f;
+    return;
+  }
+  const float step = 1.0f / (float)(n - 1);
+  const int half = n / 2;
+  for (int i = 0; i < n; ++i) (*ts)[i] = (i < half) ? (0.f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
+}
+
+// t-embedding MLP for all steps of the grid (FMT.py:128-131), rows = steps.
+template <class T>
+int prepare_time(float_fmt* h, const std::vector<float>& ts, hipStream_t s) {
+  const int n = (int)ts.size();
+  int rc;
+  FH_CHECK_HIP(hipMemcpyAsync(h->ts_dev, ts.data(), n * sizeof(float), hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL((fmt_tsin_kernel<T>), dim3(n), dim3(256), 0, s, h->tsin16, h->ts_dev, h->freqs, n);
+  GemmArgs g = base_args(h->tsin16, 256, h->t0, n);
+  g.out16 = h->th16;
+  g.ldo16 = h->D;
+  if ((rc = launch_gemm<T, EPI_SILU_T16>(g, 4, s))) return rc;
+  GemmArgs g2 = base_args(h->th16, h->D, h->t2, n);
+  g2.out_f32 = h->temb;
+  g2.ldo = h->D;
+  if ((rc = launch_gemm<T, EPI_F32>(g2, 4, s))) return rc;
+  return FLOAT_OK;
+}
+
+struct CfgMode {
+  int bc;
+  unsigned wr_mask, wa_mask, we_mask;
+};
+
+CfgMode cfg_mode(float a, float r, float e, int include_r) {
+  if (a == 1.0f && r == 1.0f && e == 1.0f) return {1, 1u, 1u, 1u};  // FMT.py:346,400-401
+  if (!include_r) return {3, 0b111u, 0b110u, 0b010u};                // [null_wa,wa,wa] [null_we,we,null_we]
+  return {4, 0b1110u, 0b1100u, 0b0100u};                             // FMT.py:382-384
+}
+
+// Stage the conditions of one window (device pointers) and compute c_cond = c_embedder([wr,wa,we]).
+template <class T>
+int stage_window(float_fmt* h, const CfgMode& m, const float* x0, const float* wa, const float* wr, const float* we,
+                 int we_len, const float* prev_x, const float* prev_wa, const float* prev_we, hipStream_t s) {
+  const float_fmt_cfg_t& c = h->cfg;
+  const int M = m.bc * h->ntok;
+  hipLaunchKernelGGL((fmt_build_cond_kernel<T>), dim3(M), dim3(256), 0, s, h->cond16, h->Kc, m.bc, h->ntok, c.n_prev,
+                     c.dim_w, c.dim_a, c.dim_e, wr, wa, prev_wa, we, we_len, prev_we, m.wr_mask, m.wa_mask, m.we_mask);
+  GemmArgs g = base_args(h->cond16, h->Kc, h->c_embed, M);
+  g.out_f32 = h->ccond;
+  g.ldo = h->D;
+  int rc;
+  if ((rc = launch_gemm<T, EPI_F32>(g, (M + 15) / 16, s))) return rc;
+  const int n = h->ntok * c.dim_w;
+  hipLaunchKernelGGL((fmt_init_x_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->xin16, h->Kx, x0, prev_x,
+                     c.n_prev, c.n_cur, c.dim_w);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+int check_common(float_fmt* h, const void* we, int we_len, const void* prev_we) {
+  FH_REQUIRE(h != nullptr, "null FMT handle");
+  FH_REQUIRE(we_len == 1 || we_len == h->cfg.n_cur,
+             "Dynamic emotion latent `we` time dimension (%d) does not match audio latent `wa` time dimension (%d).",
+             we_len, h->cfg.n_cur);
+  FH_REQUIRE(!(we_len > 1 && prev_we == nullptr),
+             "`we` is dynamic (T>1), but prev_we was not provided with prev_x/prev_wa.");
+  (void)we;
+  return FLOAT_OK;
+}
+
+// The Euler chain of one window, eager.
+template <class T>
+int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
+                     hipStream_t s) {
+  for (int i = 0; i < nfe - 1; ++i) {
+    const float dt = ts[i + 1] - ts[i];
+    int rc = run_eval<T>(h, m.bc, i, true, dt, a, r, e, s);
+    if (rc) return rc;
+  }
+  return FLOAT_OK;
+}
+
+// Same chain, replayed from a cached hipGraph (all pointers are workspace-internal, so the graph is
+// reusable across windows and clips for a given (nfe, cfg mode, scales)).
+template <class T>
+int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, const std::vector<float>& ts, float a,
+                           float r, float e, hipStream_t s) {
+  float_fmt::GraphKey key;
+  memset(&key, 0, sizeof(key));
+  key.nfe = nfe;
+  key.bc = m.bc;
+  key.we_len = we_len;
+  key.a = a;
+  key.r = r;
+  key.e = e;
+  auto it = h->graphs.find(key);
+  if (it == h->graphs.end()) {
+    if (!h->cap_stream) FH_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    FH_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream);
+    hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
+    if (rc) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    FH_CHECK_HIP(ce);
+    hipGraphExec_t exec = nullptr;
+    FH_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    it = h->graphs.emplace(key, exec).first;
+  }
+  FH_CHECK_HIP(hipGraphLaunch(it->second, s));
+  return FLOAT_OK;
+}
+
+template <class T>
+int window_impl(float_fmt* h, const float* x0, const float* wa, const float* wr, const float* we, int we_len,
+                const float* prev_x, const float* prev_wa, const float* prev_we, int nfe, const std::vector<float>& ts,
+                float a, float r, float e, int include_r, hipStream_t s) {
+  const CfgMode m = cfg_mode(a, r, e, include_r);
+  int rc = stage_window<T>(h, m, x0, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s);
+  if (rc) return rc;
+  if (h->cfg.use_graph && !g_fh_profiling) return run_window_steps_graph<T>(h, m, we_len, nfe, ts, a, r, e, s);
+  return run_window_steps<T>(h, m, nfe, ts, a, r, e, s);
+}
+
+template <class T>
+int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const float* wr, const float* we, int we_len,
+              const float* prev_x, const float* prev_wa, const float* prev_we, float a, float r, float e, int include_r,
+              float* out, hipStream_t s) {
+  std::vector<float> ts(1, t);
+  int rc = prepare_time<T>(h, ts, s);
+  if (rc) return rc;
+  const CfgMode m = cfg_mode(a, r, e, include_r);
+  if ((rc = stage_window<T>(h, m, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s))) return rc;
+  if ((rc = run_eval<T>(h, m.bc, 0, false, 0.f, a, r, e, s))) return rc;
+  FH_CHECK_HIP(hipMemcpyAsync(out, h->vout, (size_t)h->ntok * h->cfg.dim_w * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return FLOAT_OK;
+}
+
+template <class T>
+int sample_impl(float_fmt* h, const float* wr, const float* wa, int Tn, const float* we, int we_len, const float* noise,
+                int nfe, float a, float r, float e, int include_r, float* r_d, hipStream_t s) {
+  const float_fmt_cfg_t& c = h->cfg;
+  const int L = c.n_cur, P = c.n_prev;
+  const bool dynamic = we_len > 1;
+  std::vector<float> ts;
+  linspace01(nfe, &ts);
+  int rc = prepare_time<T>(h, ts, s);
+  if (rc) return rc;
+  const int n_chunks = (Tn + L - 1) / L;
+  // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
+  FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)P * c.dim_w * sizeof(float), s));
+  FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)P * c.dim_a * sizeof(float), s));
+  FH_CHECK_HIP(hipMemsetAsync(h->prev_we, 0, (size_t)P * c.dim_e * sizeof(float), s));
+  for (int k = 0; k < n_chunks; ++k) {
+    if (k > 0) {
+      // AR hand-off: last P frames of the previous final sample / (padded) wa window / we window
+      FH_CHECK_HIP(hipMemcpyAsync(h->prev_x, h->xcur + (size_t)(L - P) * c.dim_w, (size_t)P * c.dim_w * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+      FH_CHECK_HIP(hipMemcpyAsync(h->prev_wa, h->wa_c + (size_t)(L - P) * c.dim_a, (size_t)P * c.dim_a * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
+      if (dynamic)
+        FH_CHECK_HIP(hipMemcpyAsync(h->prev_we, h->we_c + (size_t)(L - P) * c.dim_e,
+                                    (size_t)P * c.dim_e * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_a + 255) / 256), dim3(256), 0, s, h->wa_c, wa, k * L, Tn, L,
+                       c.dim_a);
+    if (dynamic)
+      hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_e + 255) / 256), dim3(256), 0, s, h->we_c, we, k * L, Tn,
+                         L, c.dim_e);
+    // x0 is copied into the workspace so the window chain only ever sees handle-owned pointers
+    FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, noise + (size_t)k * L * c.dim_w, (size_t)L * c.dim_w * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+    rc = window_impl<T>(h, h->x0_c, h->wa_c, wr, dynamic ? h->we_c : we, dynamic ? L : 1, h->prev_x, h->prev_wa,
+                        dynamic ? h->prev_we : nullptr, nfe, ts, a, r, e, include_r, s);
+    if (rc) return rc;
+    const int rows = (k == n_chunks - 1) ? (Tn - k * L) : L;  // trim to T (FLOAT.py:252)
+    FH_CHECK_HIP(hipMemcpyAsync(r_d + (size_t)k * L * c.dim_w, h->xcur, (size_t)rows * c.dim_w * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+  }
+  return FLOAT_OK;
+}
+
+template <class T>
+int create_impl(float_fmt* h, const TensorTable& tt) {
+  const float_fmt_cfg_t& c = h->cfg;
+  const int D = c.dim_h;
+  int rc;
+  prime_kernels<T>();
+  if ((rc = pack_linear<T>(h, tt, {"x_embedder.proj"}, D, c.dim_w, &h->x_embed))) return rc;
+  if ((rc = pack_linear<T>(h, tt, {"t_embedder.mlp.0"}, D, 256, &h->t0))) return rc;
+  if ((rc = pack_linear<T>(h, tt, {"t_embedder.mlp.2"}, D, D, &h->t2))) return rc;
+  if ((rc = pack_linear<T>(h, tt, {"c_embedder"}, D, c.dim_w + c.dim_a + c.dim_e, &h->c_embed))) return rc;
+  h->blk.resize(c.depth);
+  std::vector<std::string> ada;
+  for (int b = 0; b < c.depth; ++b) {
+    const std::string p = "blocks." + std::to_string(b) + ".";
+    if ((rc = pack_linear<T>(h, tt, {p + "attn.qkv"}, 3 * D, D, &h->blk[b].qkv))) return rc;
+    if ((rc = pack_linear<T>(h, tt, {p + "attn.proj"}, D, D, &h->blk[b].proj))) return rc;
+    if ((rc = pack_linear<T>(h, tt, {p + "mlp.fc1"}, c.mlp_hidden, D, &h->blk[b].fc1))) return rc;
+    if ((rc = pack_linear<T>(h, tt, {p + "mlp.fc2"}, D, c.mlp_hidden, &h->blk[b].fc2))) return rc;
+    ada.push_back(p + "adaLN_modulation.1");
+  }
+  if ((rc = pack_linear<T>(h, tt, ada, 6 * D, D, &h->adaln_all))) return rc;
+  // the head's adaLN (2D outputs) rides at the end of the same fused projection
+  {
+    Lin tail;
+    if ((rc = pack_linear<T>(h, tt, {"decoder.adaLN_modulation.1"}, 2 * D, D, &tail))) return rc;
+    Lin fused;
+    fused.N = h->adaln_all.N + tail.N;
+    fused.K = h->adaln_all.K;
+    if ((rc = h->pool.alloc(&fused.W, (size_t)fused.N * fused.K, false))) return rc;
+    if ((rc = h->pool.alloc(&fused.b, (size_t)fused.N, false))) return rc;
+    FH_CHECK_HIP(hipMemcpy(fused.W, h->adaln_all.W, (size_t)h->adaln_all.N * fused.K * sizeof(u16), hipMemcpyDeviceToDevice));
+    FH_CHECK_HIP(hipMemcpy(fused.W + (size_t)h->adaln_all.N * fused.K, tail.W, (size_t)tail.N * fused.K * sizeof(u16),
+                           hipMemcpyDeviceToDevice));
+    FH_CHECK_HIP(hipMemcpy(fused.b, h->adaln_all.b, (size_t)h->adaln_all.N * sizeof(float), hipMemcpyDeviceToDevice));
+    FH_CHECK_HIP(hipMemcpy(fused.b + h->adaln_all.N, tail.b, (size_t)tail.N * sizeof(float), hipMemcpyDeviceToDevice));
+    h->adaln_all = fused;  // the two source copies stay in the pool until destroy (small: ~100 MB, freed with handle)
+  }
+  if ((rc = pack_linear<T>(h, tt, {"decoder.linear"}, c.dim_w, D, &h->final_lin))) return rc;
+  return FLOAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors, float_fmt_t** out) {
+  FH_REQUIRE(cfg && tensors && out, "null argument to float_fmt_create");
+  FH_REQUIRE(cfg->dim_h % 256 == 0 && cfg->dim_h / 256 <= 8 && ((cfg->dim_h / 256) & (cfg->dim_h / 256 - 1)) == 0,
+             "dim_h=%d unsupported", cfg->dim_h);
+  FH_REQUIRE(cfg->dim_h / cfg->heads == 128, "head_dim must be 128 (dim_h=%d heads=%d)", cfg->dim_h, cfg->heads);
+  FH_REQUIRE(cfg->dim_w % 128 == 0 && cfg->mlp_hidden % 128 == 0, "dim_w / mlp_hidden must be multiples of 128");
+  FH_REQUIRE(cfg->n_prev + cfg->n_cur <= 64, "at most 64 tokens per window (got %d)", cfg->n_prev + cfg->n_cur);
+  FH_REQUIRE(cfg->n_prev >= 0 && cfg->n_prev <= cfg->n_cur, "n_prev must be in [0, n_cur]");
+  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
+  float_fmt* h = new float_fmt();
+  h->cfg = *cfg;
+  h->D = cfg->dim_h;
+  h->ntok = cfg->n_prev + cfg->n_cur;
+  h->Mpad = 16 * ((4 * h->ntok + 15) / 16);
+  h->Kc = round_up(cfg->dim_w + cfg->dim_a + cfg->dim_e, 256);
+  h->Kx = round_up(cfg->dim_w, 256);
+  h->Ntot = cfg->depth * 6 * h->D + 2 * h->D;
+  TensorTable tt(tensors, n_tensors);
+  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);
+  const int D = h->D, Mp = h->Mpad;
+  auto A = [&](auto** p, size_t n) {
+    if (!rc) rc = h->pool.alloc(p, n, true);
+  };
+  A(&h->pos, (size_t)64 * D);
+  A(&h->freqs, 128);
+  A(&h->cond16, (size_t)Mp * h->Kc);
+  A(&h->sc16, (size_t)Mp * D);
+  A(&h->h16, (size_t)Mp * D);
+  A(&h->qkv16, (size_t)Mp * 3 * D);
+  A(&h->att16, (size_t)Mp * D);
+  A(&h->hid16, (size_t)Mp * cfg->mlp_hidden);
+  A(&h->xin16, (size_t)64 * h->Kx);
+  A(&h->tsin16, (size_t)kMaxSteps * 256);
+  A(&h->th16, (size_t)kMaxSteps * D);
+  A(&h->ccond, (size_t)Mp * D);
+  A(&h->mod, (size_t)Mp * h->Ntot);
+  A(&h->xres, (size_t)Mp * D);
+  A(&h->xcur, (size_t)cfg->n_cur * cfg->dim_w);
+  A(&h->temb, (size_t)kMaxSteps * D);
+  A(&h->ts_dev, (size_t)kMaxSteps);
+  A(&h->vout, (size_t)64 * cfg->dim_w);
+  A(&h->wa_c, (size_t)cfg->n_cur * cfg->dim_a);
+  A(&h->we_c, (size_t)cfg->n_cur * cfg->dim_e);
+  A(&h->x0_c, (size_t)cfg->n_cur * cfg->dim_w);
+  A(&h->prev_x, (size_t)cfg->n_cur * cfg->dim_w);
+  A(&h->prev_wa, (size_t)cfg->n_cur * cfg->dim_a);
+  A(&h->prev_we, (size_t)cfg->n_cur * cfg->dim_e);
+  if (!rc) {
+    // pos_embed: from the checkpoint when present, else regenerated like the VA loader does
+    // (nodes_vadv_loader.py:822-840): sin on even, cos on odd feature indices (FMT.py:29-37).
+    std::vector<float> pos((size_t)h->ntok * D);
+    const float_tensor_t* pe = tt.find("pos_embed");
+    if (pe && TensorTable::numel(pe) == (int64_t)h->ntok * D) {
+      memcpy(pos.data(), pe->data, pos.size() * sizeof(float));
+    } else {
+      for (int p = 0; p < h->ntok; ++p)
+        for (int j = 0; j < D; ++j) {
+          const float ang = (float)((double)p / pow(10000.0, 2.0 * (double)(j / 2) / (double)D));
+          pos[(size_t)p * D + j] = (j & 1) ? cosf(ang) : sinf(ang);
+        }
+    }
+    std::vector<float> fr(128);
+    for (int k = 0; k < 128; ++k) fr[k] = expf(-logf(10000.0f) * (float)k / 128.0f);
+    if (hipMemcpy(h->pos, pos.data(), pos.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(h->freqs, fr.data(), fr.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+      fh_set_error("hipMemcpy of FMT tables failed");
+      rc = FLOAT_E_HIP;
+    }
+  }
+  if (rc) {
+    float_fmt_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return FLOAT_OK;
+}
+
+void float_fmt_destroy(float_fmt_t* h) {
+  if (!h) return;
+  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  h->pool.release();
+  delete h;
+}
+
+int float_fmt_eval(float_fmt_t* h, float t, const float* x, const float* wa, const float* wr, const float* we,
+                   int32_t we_len, const float* prev_x, const float* prev_wa, const float* prev_we, float a_cfg,
+                   float r_cfg, float e_cfg, int32_t include_r_cfg, float* out, void* stream) {
+  int rc = check_common(h, we, we_len, prev_we);
+  if (rc) return rc;
+  FH_REQUIRE(x && wa && wr && we && prev_x && prev_wa && out, "null tensor argument to float_fmt_eval");
+  hipStream_t s = (hipStream_t)stream;
+  return h->cfg.dtype == FLOAT_DT_BF16
+             ? eval_impl<BF16>(h, t, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, a_cfg, r_cfg, e_cfg, include_r_cfg, out, s)
+             : eval_impl<FP16>(h, t, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, a_cfg, r_cfg, e_cfg, include_r_cfg, out, s);
+}
+
+int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, const float* wr, const float* we,
+                           int32_t we_len, const float* prev_x, const float* prev_wa, const float* prev_we, int32_t nfe,
+                           float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg, float* out, void* stream) {
+  int rc = check_common(h, we, we_len, prev_we);
+  if (rc) return rc;
+  FH_REQUIRE(x0 && wa && wr && we && prev_x && prev_wa && out, "null tensor argument to float_fmt_sample_chunk");
+  FH_REQUIRE(nfe >= 1 && nfe <= kMaxSteps, "nfe=%d out of range [1,%d]", nfe, kMaxSteps);
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<float> ts;
+  linspace01(nfe, &ts);
+  const float_fmt_cfg_t& c = h->cfg;
+  // stage caller tensors into handle-owned buffers (the graph path needs stable addresses)
+  FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, x0, (size_t)c.n_cur * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
+  FH_CHECK_HIP(hipMemcpyAsync(h->wa_c, wa, (size_t)c.n_cur * c.dim_a * 4, hipMemcpyDeviceToDevice, s));
+  FH_CHECK_HIP(hipMemcpyAsync(h->prev_x, prev_x, (size_t)c.n_prev * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
+  FH_CHECK_HIP(hipMemcpyAsync(h->prev_wa, prev_wa, (size_t)c.n_prev * c.dim_a * 4, hipMemcpyDeviceToDevice, s));
+  if (we_len > 1) {
+    FH_CHECK_HIP(hipMemcpyAsync(h->we_c, we, (size_t)c.n_cur * c.dim_e * 4, hipMemcpyDeviceToDevice, s));
+    FH_CHECK_HIP(hipMemcpyAsync(h->prev_we, prev_we, (size_t)c.n_prev * c.dim_e * 4, hipMemcpyDeviceToDevice, s));
+  }
+  const float* we_p = we_len > 1 ? h->we_c : we;
+  const float* pwe_p = we_len > 1 ? h->prev_we : nullptr;
+  if (c.dtype == FLOAT_DT_BF16) {
+    if ((rc = prepare_time<BF16>(h, ts, s))) return rc;
+    rc = window_impl<BF16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
+  } else {
+    if ((rc = prepare_time<FP16>(h, ts, s))) return rc;
+    rc = window_impl<FP16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
+  }
+  if (rc) return rc;
+  FH_CHECK_HIP(hipMemcpyAsync(out, h->xcur, (size_t)c.n_cur * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
+  return FLOAT_OK;
+}
+
+int float_fmt_sample(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we, int32_t we_len,
+                     const float* noise, int32_t nfe, float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg,
+                     float* r_d, void* stream) {
+  FH_REQUIRE(h != nullptr, "null FMT handle");
+  FH_REQUIRE(wr && wa && we && noise && r_d, "null tensor argument to float_fmt_sample");
+  FH_REQUIRE(T >= 1, "T must be >= 1 (got %d)", T);
+  FH_REQUIRE(we_len == 1 || we_len == T,
+             "Dynamic emotion latent `we` time dimension (%d) does not match audio latent `wa` time dimension (%d).",
+             we_len, T);
+  FH_REQUIRE(nfe >= 1 && nfe <= kMaxSteps, "nfe=%d out of range [1,%d]", nfe, kMaxSteps);
+  hipStream_t s = (hipStream_t)stream;
+  return h->cfg.dtype == FLOAT_DT_BF16
+             ? sample_impl<BF16>(h, wr, wa, T, we, we_len, noise, nfe, a_cfg, r_cfg, e_cfg, include_r_cfg, r_d, s)
+             : sample_impl<FP16>(h, wr, wa, T, we, we_len, noise, nfe, a_cfg, r_cfg, e_cfg, include_r_cfg, r_d, s);
+}
+
+}  // extern "C"

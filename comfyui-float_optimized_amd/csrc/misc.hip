@@ -1,0 +1,94 @@
+// Error string, ABI version and per-kernel-class event profiling for libfloat_hip.so.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+int g_fh_profiling = 0;
+
+void fh_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+constexpr int kClasses = 4;
+struct Slot {
+  std::vector<hipEvent_t> pool;                          // recycled events
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> live;  // recorded pairs not yet read
+  hipEvent_t open = nullptr;
+};
+Slot g_slots[kClasses];
+
+hipEvent_t get_event(Slot& s) {
+  if (!s.pool.empty()) {
+    hipEvent_t e = s.pool.back();
+    s.pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+
+void fh_prof_begin(int which, hipStream_t st) {
+  if (!g_fh_profiling || which < 0 || which >= kClasses) return;
+  Slot& s = g_slots[which];
+  s.open = get_event(s);
+  (void)hipEventRecord(s.open, st);
+}
+
+void fh_prof_end(int which, hipStream_t st) {
+  if (!g_fh_profiling || which < 0 || which >= kClasses) return;
+  Slot& s = g_slots[which];
+  if (!s.open) return;
+  hipEvent_t e = get_event(s);
+  (void)hipEventRecord(e, st);
+  s.live.emplace_back(s.open, e);
+  s.open = nullptr;
+}
+
+extern "C" {
+
+int float_hip_abi_version(void) { return FLOAT_HIP_ABI_VERSION; }
+
+const char* float_last_error(void) { return g_err; }
+
+int float_set_profiling(int32_t on) {
+  g_fh_profiling = on ? 1 : 0;
+  if (on) {
+    for (auto& s : g_slots) {
+      for (auto& p : s.live) {
+        s.pool.push_back(p.first);
+        s.pool.push_back(p.second);
+      }
+      s.live.clear();
+    }
+  }
+  return FLOAT_OK;
+}
+
+double float_profile_ms(int32_t which, int64_t* n_launches) {
+  if (which < 0 || which >= kClasses) return -1.0;
+  Slot& s = g_slots[which];
+  double total = 0.0;
+  int64_t n = 0;
+  for (auto& p : s.live) {
+    float ms = 0.f;
+    (void)hipEventSynchronize(p.second);
+    if (hipEventElapsedTime(&ms, p.first, p.second) == hipSuccess) {
+      total += ms;
+      ++n;
+    }
+    s.pool.push_back(p.first);
+    s.pool.push_back(p.second);
+  }
+  s.live.clear();
+  if (n_launches) *n_launches = n;
+  return n ? total / (double)n : -1.0;
+}
+
+}  // extern "C"

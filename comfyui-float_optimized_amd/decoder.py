@@ -1,0 +1,64 @@
+"""Host mirror of the motion-autoencoder decoder (reference styledecoder.py Synthesis and the
+decode loop FLOAT.py:113-169), running on the HIP operator (`float_dec_*`, include/float_hip.h)."""
+import ctypes as C
+
+import torch
+
+from . import native
+
+
+class SynthesisHIP:
+    def __init__(self, state_dict, size=512, style_dim=512, device="cuda:0", dtype="bf16", max_frames=16):
+        self.size, self.style_dim = size, style_dim
+        self.device = torch.device(device)
+        self.dtype = dtype
+        L = native.lib()
+        pref = "motion_autoencoder.dec."
+        sd = {(k[len(pref):] if k.startswith(pref) else k): v for k, v in state_dict.items()}
+        arr, keep = native.tensor_table(sd)
+        cfg = native.DecCfg(size, style_dim, native.DTYPES[dtype], max_frames)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            native.check(L.float_dec_create(C.byref(cfg), arr, len(sd), C.byref(h)))
+        self._h = h
+        self._feats = None
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            native.lib().float_dec_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def set_feats(self, feats):
+        """feats: the encoder's skip list (encoder.py:220-231), 7 tensors (1,C,R,R), R = 8..size."""
+        fs = [f.to(self.device, torch.float32).reshape(f.shape[-3], f.shape[-2], f.shape[-1]).contiguous() for f in feats]
+        ptrs = (C.c_void_p * len(fs))(*[f.data_ptr() for f in fs])
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_dec_set_feats(self._h, ptrs, len(fs), native.stream_ptr(self.device)))
+        self._feats = fs  # keep alive until the async repack has run
+
+    def _run(self, fn, s_r, r_d, shape):
+        s_r = s_r.to(self.device, torch.float32).reshape(-1).contiguous()
+        r_d = r_d.to(self.device, torch.float32).reshape(-1, self.style_dim).contiguous()
+        if s_r.numel() != self.style_dim:
+            raise ValueError("s_r must have %d elements (decoder batch is 1, FLOAT.py:140)" % self.style_dim)
+        T = r_d.shape[0]
+        out = torch.empty((T,) + shape, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            native.check(fn(self._h, native.dev_ptr(s_r), native.dev_ptr(r_d), T, native.dev_ptr(out),
+                            native.stream_ptr(self.device)))
+        return out
+
+    @torch.no_grad()
+    def decode_latent_into_processed_images(self, s_r, r_d, s_r_feats=None):
+        """FLOAT.py:113-169: (T, H, W, 3) fp32 in [0,1]; stays on the GPU (the caller copies out)."""
+        if s_r_feats is not None:
+            self.set_feats(s_r_feats)
+        return self._run(native.lib().float_dec_frames, s_r, r_d, (self.size, self.size, 3))
+
+    @torch.no_grad()
+    def synthesis_raw(self, s_r, r_d):
+        """Un-clamped Synthesis.forward output (T, 3, H, W) (styledecoder.py:532-534)."""
+        return self._run(native.lib().float_dec_frames_raw, s_r, r_d, (3, self.size, self.size))

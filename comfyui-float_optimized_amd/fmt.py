@@ -1,0 +1,143 @@
+"""Host mirror of the reference's FlowMatchingTransformer sampling interface, running on the HIP
+operator (`float_fmt_*`, include/float_hip.h).  Names and argument meaning follow
+reference FMT.py:342-345 (forward_with_cfv) and nodes_adv.py:545-572 (_perform_ode_sampling_loop)."""
+import ctypes as C
+import math
+
+import torch
+
+from . import native
+from .config import FmtConfig
+
+
+class FlowMatchingTransformerHIP:
+    """Holds packed weights + workspace on one GPU.  Batch items are looped on the host, like the
+    reference's FloatProcess (nodes.py:189-209)."""
+
+    def __init__(self, state_dict, cfg: FmtConfig = None, device="cuda:0", dtype="bf16", use_graph=True):
+        self.cfg = cfg or FmtConfig()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        L = native.lib()
+        c = self.cfg
+        ncfg = native.FmtCfg(c.dim_w, c.dim_a, c.dim_e, c.dim_h, c.fmt_depth, c.num_heads,
+                             int(c.dim_h * c.mlp_ratio), c.num_prev_frames, c.num_frames_for_clip,
+                             c.attention_window, native.DTYPES[dtype], 1 if use_graph else 0)
+        sd = {k[4:] if k.startswith("fmt.") else k: v for k, v in state_dict.items()
+              if k not in ("alignment_mask", "fmt.alignment_mask")}
+        arr, keep = native.tensor_table(sd)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            native.check(L.float_fmt_create(C.byref(ncfg), arr, len(sd), C.byref(h)))
+        self._h = h
+        del keep
+
+    def close(self):
+        if getattr(self, "_h", None):
+            native.lib().float_fmt_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    # ------------------------------------------------------------------ helpers
+    def _f(self, t):
+        return None if t is None else t.to(self.device, torch.float32).contiguous()
+
+    def _check_shapes(self, x, wa, wr, we, prev_x, prev_wa, prev_we):
+        c = self.cfg
+        B = x.shape[0]
+        if x.shape != (B, c.num_frames_for_clip, c.dim_w):
+            raise ValueError("x must be (B,%d,%d), got %s" % (c.num_frames_for_clip, c.dim_w, tuple(x.shape)))
+        if wa.shape != (B, c.num_frames_for_clip, c.dim_a):
+            raise ValueError("wa must be (B,%d,%d), got %s" % (c.num_frames_for_clip, c.dim_a, tuple(wa.shape)))
+        if wr.shape != (B, c.dim_w):
+            raise ValueError("wr must be (B,%d), got %s" % (c.dim_w, tuple(wr.shape)))
+        if prev_x is None or prev_wa is None:
+            raise ValueError("prev_x was provided, but prev_wa was not." if prev_x is not None
+                             else "prev_x / prev_wa are required")
+        if we.dim() != 3 or we.shape[2] != c.dim_e:
+            raise ValueError("we must be (B,1|%d,%d)" % (c.num_frames_for_clip, c.dim_e))
+        if we.shape[1] > 1 and prev_we is None:
+            raise ValueError("`we` is dynamic (T>1), but prev_we was not provided with prev_x/prev_wa.")
+        if we.shape[1] not in (1, c.num_frames_for_clip):
+            raise ValueError("Dynamic emotion latent `we` time dimension (%d) does not match audio latent `wa` "
+                             "time dimension (%d)." % (we.shape[1] + c.num_prev_frames,
+                                                       c.num_frames_for_clip + c.num_prev_frames))
+
+    # ------------------------------------------------------------------ reference-shaped API
+    @torch.no_grad()
+    def forward_with_cfv(self, t, x, wa, wr, we, prev_x, prev_wa, prev_we=None, a_cfg_scale=1.0, r_cfg_scale=1.0,
+                         e_cfg_scale=1.0, include_r_cfg=False, **kwargs):
+        """FMT.py:342-401.  Returns (B, n_prev+n_cur, dim_w) on the GPU."""
+        x, wa, wr, we, prev_x, prev_wa, prev_we = map(self._f, (x, wa, wr, we, prev_x, prev_wa, prev_we))
+        self._check_shapes(x, wa, wr, we, prev_x, prev_wa, prev_we)
+        c, L = self.cfg, native.lib()
+        tval = float(torch.as_tensor(t).reshape(-1)[0])
+        B = x.shape[0]
+        out = torch.empty(B, c.n_tokens, c.dim_w, device=self.device, dtype=torch.float32)
+        dynamic = we.shape[1] > 1
+        with torch.cuda.device(self.device):
+            s = native.stream_ptr(self.device)
+            for b in range(B):
+                native.check(L.float_fmt_eval(
+                    self._h, tval, native.dev_ptr(x[b]), native.dev_ptr(wa[b]), native.dev_ptr(wr[b]),
+                    native.dev_ptr(we[b]), we.shape[1], native.dev_ptr(prev_x[b]), native.dev_ptr(prev_wa[b]),
+                    native.dev_ptr(prev_we[b]) if dynamic else None, a_cfg_scale, r_cfg_scale, e_cfg_scale,
+                    1 if include_r_cfg else 0, native.dev_ptr(out[b]), s))
+        return out
+
+    @torch.no_grad()
+    def sample_chunk(self, x0, wa, wr, we, prev_x, prev_wa, prev_we=None, nfe=10, a_cfg_scale=1.0, r_cfg_scale=1.0,
+                     e_cfg_scale=1.0, include_r_cfg=False):
+        """odeint(euler) over linspace(0,1,nfe) for one window (FLOAT.py:229-248): (B, n_cur, dim_w)."""
+        x0, wa, wr, we, prev_x, prev_wa, prev_we = map(self._f, (x0, wa, wr, we, prev_x, prev_wa, prev_we))
+        self._check_shapes(x0, wa, wr, we, prev_x, prev_wa, prev_we)
+        c, L = self.cfg, native.lib()
+        B = x0.shape[0]
+        out = torch.empty(B, c.num_frames_for_clip, c.dim_w, device=self.device, dtype=torch.float32)
+        dynamic = we.shape[1] > 1
+        with torch.cuda.device(self.device):
+            s = native.stream_ptr(self.device)
+            for b in range(B):
+                native.check(L.float_fmt_sample_chunk(
+                    self._h, native.dev_ptr(x0[b]), native.dev_ptr(wa[b]), native.dev_ptr(wr[b]),
+                    native.dev_ptr(we[b]), we.shape[1], native.dev_ptr(prev_x[b]), native.dev_ptr(prev_wa[b]),
+                    native.dev_ptr(prev_we[b]) if dynamic else None, int(nfe), a_cfg_scale, r_cfg_scale, e_cfg_scale,
+                    1 if include_r_cfg else 0, native.dev_ptr(out[b]), s))
+        return out
+
+    @torch.no_grad()
+    def sample(self, r_s, wa, we, noise, nfe=10, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0,
+               include_r_cfg=False):
+        """The AR window loop (FLOAT.py:209-253; nodes_adv.py:578-694).
+        r_s (B,dim_w); wa (B,T,dim_a); we (B,1|T,dim_e); noise (n_chunks,B,n_cur,dim_w) explicit.
+        Returns r_d (B,T,dim_w) on the GPU."""
+        r_s, wa, we, noise = map(self._f, (r_s, wa, we, noise))
+        c, L = self.cfg, native.lib()
+        B, T = wa.shape[0], wa.shape[1]
+        n_chunks = int(math.ceil(T / c.num_frames_for_clip))
+        if noise.shape != (n_chunks, B, c.num_frames_for_clip, c.dim_w):
+            raise ValueError("noise must be (%d,%d,%d,%d), got %s" % (n_chunks, B, c.num_frames_for_clip, c.dim_w,
+                                                                      tuple(noise.shape)))
+        if we.shape[1] not in (1, T):
+            raise ValueError("Dynamic emotion latent `we` time dimension (%d) does not match audio latent `wa` "
+                             "time dimension (%d)." % (we.shape[1], T))
+        r_d = torch.empty(B, T, c.dim_w, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            s = native.stream_ptr(self.device)
+            for b in range(B):
+                nb = noise[:, b].contiguous()
+                native.check(L.float_fmt_sample(
+                    self._h, native.dev_ptr(r_s[b]), native.dev_ptr(wa[b]), T, native.dev_ptr(we[b]), we.shape[1],
+                    native.dev_ptr(nb), int(nfe), a_cfg_scale, r_cfg_scale, e_cfg_scale, 1 if include_r_cfg else 0,
+                    native.dev_ptr(r_d[b]), s))
+        return r_d
+
+
+def draw_noise(n_chunks, batch, cfg, seed, device="cpu"):
+    """The reference's noise stream made explicit: sequential randn(B, n_cur, dim_w) draws from one
+    generator seeded once per clip (FLOAT.py:203-215)."""
+    g = torch.Generator(device)
+    g.manual_seed(int(seed))
+    return torch.stack([torch.randn(batch, cfg.num_frames_for_clip, cfg.dim_w, generator=g, device=device)
+                        for _ in range(n_chunks)])

@@ -1,0 +1,131 @@
+"""ctypes binding of libfloat_hip.so (include/float_hip.h).  No fallback: if the library is
+missing or fails to load, importing anything that computes raises NativeLibraryError."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfloat_hip.so")
+
+FLOAT_DT_BF16, FLOAT_DT_FP16 = 0, 1
+DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16}
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+class FloatTensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.POINTER(C.c_float)), ("ndim", C.c_int32),
+                ("shape", C.c_int64 * 6)]
+
+
+class FmtCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dim_w", "dim_a", "dim_e", "dim_h", "depth", "heads", "mlp_hidden",
+                                         "n_prev", "n_cur", "attn_window", "dtype", "use_graph")]
+
+
+class DecCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("size", "style_dim", "dtype", "max_frames")]
+
+
+_F = C.POINTER(C.c_float)
+_SIGNATURES = {
+    "float_hip_abi_version": (C.c_int, []),
+    "float_last_error": (C.c_char_p, []),
+    "float_set_profiling": (C.c_int, [C.c_int32]),
+    "float_profile_ms": (C.c_double, [C.c_int32, C.POINTER(C.c_int64)]),
+    "float_fmt_create": (C.c_int, [C.POINTER(FmtCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
+    "float_fmt_destroy": (None, [C.c_void_p]),
+    "float_fmt_eval": (C.c_int, [C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 +
+                       [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "float_fmt_sample_chunk": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 +
+                               [C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "float_fmt_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                   C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "float_dec_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
+    "float_dec_destroy": (None, [C.c_void_p]),
+    "float_dec_set_feats": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "float_dec_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "float_dec_frames_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raises NativeLibraryError if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            "libfloat_hip.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C comfyui-float_optimized_amd/csrc` (there is no CPU fallback)")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (LIB_PATH, e)) from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise NativeLibraryError("libfloat_hip.so does not export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if L.float_hip_abi_version() != 1:
+        raise NativeLibraryError("libfloat_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+_ERR_TYPES = {1: ValueError, 2: KeyError, 3: RuntimeError, 4: MemoryError}
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().float_last_error().decode("utf-8", "replace")
+        raise _ERR_TYPES.get(rc, RuntimeError)(msg)
+
+
+def tensor_table(state):
+    """dict[str, torch.Tensor] -> (ctypes array of float_tensor_t, keep-alive list)."""
+    keep = []
+    arr = (FloatTensor * len(state))()
+    for i, (k, v) in enumerate(state.items()):
+        t = v.detach().to("cpu", torch.float32).contiguous()
+        nm = k.encode()
+        keep.append((t, nm))
+        arr[i].name = nm
+        arr[i].data = C.cast(t.data_ptr(), _F)
+        arr[i].ndim = t.dim()
+        for d in range(t.dim()):
+            arr[i].shape[d] = t.shape[d]
+    return arr, keep
+
+
+def dev_ptr(t, name="tensor"):
+    """fp32 contiguous CUDA(HIP) tensor -> raw device pointer."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU" % name)
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise TypeError("%s must be contiguous float32" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def set_profiling(on):
+    check(lib().float_set_profiling(1 if on else 0))
+
+
+def profile_ms(which):
+    n = C.c_int64(0)
+    ms = lib().float_profile_ms(which, C.byref(n))
+    return ms, n.value

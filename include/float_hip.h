@@ -1,0 +1,141 @@
+/* float_hip.h - C ABI of libfloat_hip.so: the FLOAT hot path on MI355X (gfx950).
+ *
+ * Two operators replace the two loops of the reference (set-soft/ComfyUI-FLOAT_Optimized):
+ *
+ *   FMT  - FlowMatchingTransformer.forward_with_cfv and the fixed-grid Euler loop around it
+ *          (reference src/nodes/models/float/FMT.py:277-401, FLOAT.py:209-253,
+ *          nodes_adv.py:545-694).
+ *   DEC  - Synthesis.forward + per-frame post-process
+ *          (reference src/nodes/models/float/styledecoder.py:497-534, FLOAT.py:113-169,
+ *          nodes_vadv.py:447-464).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a FLOAT_E_* code,
+ *     float_last_error() gives the message (thread-local).  No exception crosses the ABI.
+ *   - all tensor arguments of the run-time calls are DEVICE pointers to contiguous fp32
+ *     (the reference's tensors are fp32 everywhere); `stream` is a hipStream_t passed as void*.
+ *     All work is enqueued on that stream; nothing synchronises the device.
+ *   - batch size is 1 at this level, exactly like the reference decode loop (FLOAT.py:140);
+ *     the host mirror loops over batch items as FloatProcess does (nodes.py:189-209).
+ *   - a handle owns its packed weights and a fixed workspace allocated at create time; no
+ *     allocation happens inside the run-time calls (they are hipGraph-capturable).
+ *   - calls on one handle must be serialised by the caller; different handles are independent.
+ */
+#ifndef FLOAT_HIP_H
+#define FLOAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLOAT_HIP_ABI_VERSION 1
+
+enum {
+  FLOAT_OK = 0,
+  FLOAT_E_INVALID = 1,   /* bad argument / shape mismatch (ValueError in the host mirror) */
+  FLOAT_E_MISSING = 2,   /* a required checkpoint tensor is absent (KeyError) */
+  FLOAT_E_HIP = 3,       /* HIP runtime error (RuntimeError) */
+  FLOAT_E_NOMEM = 4
+};
+
+enum { FLOAT_DT_BF16 = 0, FLOAT_DT_FP16 = 1 }; /* 16-bit MFMA operand type; accumulation is fp32 */
+
+/* One checkpoint tensor, named with the reference's state-dict key (prefix stripped):
+ * e.g. "blocks.0.attn.qkv.weight" (FMT) or "convs.3.conv.weight" (decoder).  `data` is a HOST
+ * pointer to contiguous fp32; it is only read during *_create. */
+typedef struct {
+  const char* name;
+  const float* data;
+  int32_t ndim;
+  int64_t shape[6];
+} float_tensor_t;
+
+/* ---------------------------------------------------------------- FMT ------------- */
+/* Shape contract = reference BaseOptions (options/base_options.py:36-45). */
+typedef struct {
+  int32_t dim_w, dim_a, dim_e, dim_h;
+  int32_t depth, heads;
+  int32_t mlp_hidden;      /* int(dim_h * mlp_ratio) */
+  int32_t n_prev, n_cur;   /* num_prev_frames, int(wav2vec_sec*fps) */
+  int32_t attn_window;     /* |i-j| <= window is visible (FMT.py:15-19) */
+  int32_t dtype;           /* FLOAT_DT_* */
+  int32_t use_graph;       /* 1: replay the per-chunk kernel chain from a cached hipGraph */
+} float_fmt_cfg_t;
+
+typedef struct float_fmt float_fmt_t;
+
+int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors,
+                     float_fmt_t** out);
+void float_fmt_destroy(float_fmt_t* h);
+
+/* forward_with_cfv (FMT.py:342-401), B = 1.
+ *   x, wa: (n_cur, dim)   wr: (dim_w)   we: (we_len, dim_e) with we_len 1 (static) or n_cur
+ *   prev_x, prev_wa: (n_prev, dim)   prev_we: (n_prev, dim_e) - required iff we_len > 1
+ *   out: (n_prev + n_cur, dim_w)
+ * All three scales == 1 -> a single conditional pass (FMT.py:400-401); otherwise the 3-row
+ * batch [uncond | all | audio-only], or the 4-row batch when include_r_cfg != 0. */
+int float_fmt_eval(float_fmt_t* h, float t, const float* x, const float* wa, const float* wr,
+                   const float* we, int32_t we_len, const float* prev_x, const float* prev_wa,
+                   const float* prev_we, float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg,
+                   float* out, void* stream);
+
+/* One window of the ODE loop (FLOAT.py:229-248): Euler over linspace(0,1,nfe), i.e. nfe-1
+ * evaluations starting from x0 (n_cur, dim_w); out = final sample (n_cur, dim_w). */
+int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, const float* wr,
+                           const float* we, int32_t we_len, const float* prev_x, const float* prev_wa,
+                           const float* prev_we, int32_t nfe, float a_cfg, float r_cfg, float e_cfg,
+                           int32_t include_r_cfg, float* out, void* stream);
+
+/* The whole auto-regressive loop (FLOAT.py:209-253; nodes_adv.py:578-694).
+ *   wr: (dim_w)   wa: (T, dim_a)   we: (1|T, dim_e)   noise: (ceil(T/n_cur), n_cur, dim_w),
+ *   the explicit form of the reference's sequential randn draws (FLOAT.py:215)
+ *   r_d: (T, dim_w).  Last window replicate-padded, prev_* handed off on the device. */
+int float_fmt_sample(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we,
+                     int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg,
+                     float e_cfg, int32_t include_r_cfg, float* r_d, void* stream);
+
+/* ---------------------------------------------------------------- decoder --------- */
+typedef struct {
+  int32_t size;        /* output resolution, 64..512 (styledecoder.py:448) */
+  int32_t style_dim;   /* 512 */
+  int32_t dtype;       /* FLOAT_DT_* for activations / conv weights */
+  int32_t max_frames;  /* frames decoded per internal batch (sizes the workspace) */
+} float_dec_cfg_t;
+
+typedef struct float_dec float_dec_t;
+
+int float_dec_create(const float_dec_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors,
+                     float_dec_t** out);
+void float_dec_destroy(float_dec_t* h);
+
+/* Per clip: the encoder's skip features, reference order (encoder.py:220-231):
+ * feats[i] = (C_i, R_i, R_i) fp32 NCHW, R_i = 8 << i.  Repacked to NHWC 16-bit in the handle. */
+int float_dec_set_feats(float_dec_t* h, const float* const* feats, int32_t n_feats, void* stream);
+
+/* decode_latent_into_processed_images (FLOAT.py:113-169) without the host copy:
+ *   s_r: (style_dim)   r_d: (n_frames, style_dim)
+ *   out: (n_frames, size, size, 3) fp32 in [0,1] = clamp(rgb,-1,1)*0.5+0.5, HWC. */
+int float_dec_frames(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames,
+                     float* out_hwc, void* stream);
+
+/* Same, but returns the un-clamped NCHW rgb of Synthesis.forward (styledecoder.py:532-534);
+ * parity tests use it to look under the clamp. */
+int float_dec_frames_raw(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames,
+                         float* out_chw, void* stream);
+
+/* ---------------------------------------------------------------- misc ------------ */
+int float_hip_abi_version(void);
+const char* float_last_error(void);
+/* Average device time (ms) of the kernels launched by the last timed call, by class, measured
+ * with hipEvents on the caller's stream when profiling is on.  which: 0 = FMT GEMMs,
+ * 1 = decoder convs.  Returns <0 when profiling is off. */
+int float_set_profiling(int32_t on);
+double float_profile_ms(int32_t which, int64_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLOAT_HIP_H */

@@ -1,0 +1,94 @@
+"""GPU parity of the decoder operator against the CPU oracle / goldens, through the C ABI.
+16-bit activations with fp32 accumulation.  Stated tolerances (calibrated on MI355X):
+frames in [0,1]: PSNR >= 40 dB and mean |d| <= 2/255 for bf16; fp16 is held 4x tighter."""
+import math
+
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import golden, load_pkg
+
+pkg = load_pkg()
+W = pkg.weights
+pytestmark = pytest.mark.gpu
+
+
+def psnr(a, b):
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    return 99.0 if mse == 0 else 10 * math.log10(1.0 / mse)
+
+
+LIMITS = {"bf16": dict(psnr=40.0, mean=2.0 / 255), "fp16": dict(psnr=52.0, mean=0.5 / 255)}
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_dec_64_golden(dtype):
+    g = golden("dec_64")
+    sd = W.synth_decoder_state(64, seed=g["seed"])
+    feats = W.synth_feats(64, seed=g["seed"])
+    dec = pkg.decoder.SynthesisHIP(sd, 64, 512, "cuda:0", dtype=dtype, max_frames=2)  # 3 frames -> 2 batches
+    frames = dec.decode_latent_into_processed_images(g["s_r"], g["r_d"], feats).cpu()
+    assert frames.shape == g["frames"].shape
+    p, m = psnr(frames, g["frames"]), float((frames - g["frames"]).abs().mean())
+    raw = dec.synthesis_raw(g["s_r"], g["r_d"][:, :1]).cpu()
+    print(dtype, "64px: PSNR %.1f dB mean|d| %.2e max|d| %.2e raw max|d| %.2e" % (
+        p, m, float((frames - g["frames"]).abs().max()), float((raw - g["raw0"]).abs().max())))
+    assert p >= LIMITS[dtype]["psnr"] and m <= LIMITS[dtype]["mean"]
+    assert frames.min() >= 0 and frames.max() <= 1
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_dec_512_golden_lattice(dtype):
+    g = golden("dec_512")
+    sd = W.synth_decoder_state(512, seed=g["seed"])
+    feats = W.synth_feats(512, seed=g["seed"])
+    dec = pkg.decoder.SynthesisHIP(sd, 512, 512, "cuda:0", dtype=dtype, max_frames=4)
+    frames = dec.decode_latent_into_processed_images(g["s_r"], g["r_d"], feats).cpu()
+    assert frames.shape == (2, 512, 512, 3)
+    lat, band = frames[:, ::7, ::5], frames[:, 250:258]
+    p = min(psnr(lat, g["lattice"]), psnr(band, g["band"]))
+    m = float((lat - g["lattice"]).abs().mean())
+    print(dtype, "512px: PSNR %.1f dB mean|d| %.2e max|d| %.2e mean err of means %.2e" % (
+        p, m, float((lat - g["lattice"]).abs().max()), float((frames.mean(dim=(1, 2, 3)) - g["mean"]).abs().max())))
+    assert p >= LIMITS[dtype]["psnr"] and m <= LIMITS[dtype]["mean"]
+
+
+def test_dec_512_vs_oracle_levels():
+    """Per-level check at full size against the live oracle (one frame): flow and rgb pyramids."""
+    sd = W.synth_decoder_state(512, seed=3)
+    feats = W.synth_feats(512, seed=3)
+    gen = torch.Generator().manual_seed(5)
+    s_r, r_d = torch.randn(1, 512, generator=gen), torch.randn(1, 1, 512, generator=gen) * 0.5
+    want = O.synthesis(sd, s_r + r_d[:, 0], feats)
+    dec = pkg.decoder.SynthesisHIP(sd, 512, 512, "cuda:0", dtype="bf16", max_frames=1)
+    dec.set_feats(feats)
+    raw = dec.synthesis_raw(s_r, r_d).cpu()
+    d = (raw - want).abs()
+    print("512 raw: mean|d| %.2e p99.9 %.2e max %.2e (raw std %.2f)" % (
+        float(d.mean()), float(d.flatten().kthvalue(int(d.numel() * 0.999))[0]), float(d.max()), float(want.std())))
+    assert float(d.mean()) < 1e-2
+
+
+def test_frames_independent_of_batching():
+    """Size-independent property: a frame's pixels do not depend on which batch it was decoded in."""
+    sd = W.synth_decoder_state(64, seed=9)
+    feats = W.synth_feats(64, seed=9)
+    gen = torch.Generator().manual_seed(1)
+    s_r, r_d = torch.randn(1, 512, generator=gen), torch.randn(1, 7, 512, generator=gen) * 0.5
+    a = pkg.decoder.SynthesisHIP(sd, 64, 512, "cuda:0", max_frames=7)
+    b = pkg.decoder.SynthesisHIP(sd, 64, 512, "cuda:0", max_frames=3)
+    fa = a.decode_latent_into_processed_images(s_r, r_d, feats).cpu()
+    fb = b.decode_latent_into_processed_images(s_r, r_d, feats).cpu()
+    assert torch.equal(fa, fb)
+
+
+def test_dec_errors():
+    sd = W.synth_decoder_state(64, seed=9)
+    dec = pkg.decoder.SynthesisHIP(sd, 64, 512, "cuda:0")
+    with pytest.raises(ValueError, match="set_feats"):
+        dec.decode_latent_into_processed_images(torch.zeros(1, 512), torch.zeros(1, 1, 512))
+    bad = dict(sd)
+    del bad["to_flows.0.conv.weight"]
+    with pytest.raises(KeyError):
+        pkg.decoder.SynthesisHIP(bad, 64, 512, "cuda:0")

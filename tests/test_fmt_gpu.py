@@ -1,0 +1,97 @@
+"""GPU parity of the FMT operator against the CPU oracle and the committed goldens, through the
+C ABI.  bf16 operands / fp32 accumulation: tolerance 2e-2 rel-L2 on the velocity and on r_d after a
+full window; fp16 operands are held to 4e-3."""
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import golden, load_pkg, rel_l2
+
+pkg = load_pkg()
+W, C = pkg.weights, pkg.config
+pytestmark = pytest.mark.gpu
+
+TOL = {"bf16": 2e-2, "fp16": 4e-3}
+
+
+def _fmt(cfg, seed, dtype, use_graph=True):
+    sd = W.synth_fmt_state(cfg, seed)
+    return sd, pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", dtype=dtype, use_graph=use_graph)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_eval_golden(tag, dtype):
+    g = golden("fmt_eval_" + tag)
+    cfg = C.small_fmt_config() if tag == "small" else C.FmtConfig()
+    sd, fmt = _fmt(cfg, g["seed"], dtype)
+    for case in ("nocfg", "cfg3", "cfg4", "cfg3dyn"):
+        a, r, e, rc = [float(v) for v in g[case + "_scales"]]
+        out = fmt.forward_with_cfv(g["t"], g[case + "_x"], g[case + "_wa"], g[case + "_wr"], g[case + "_we"],
+                                   g[case + "_prev_x"], g[case + "_prev_wa"], g.get(case + "_prev_we"),
+                                   a_cfg_scale=a, r_cfg_scale=r, e_cfg_scale=e, include_r_cfg=bool(rc)).cpu()
+        err = rel_l2(out, g[case + "_out"])
+        print(tag, dtype, case, "rel-L2 %.3e" % err)
+        assert err < TOL[dtype], (case, err)
+
+
+@pytest.mark.parametrize("tag", ["small_static", "small_dynamic", "full_static"])
+def test_sample_golden(tag):
+    g = golden("fmt_sample_" + tag)
+    cfg = C.FmtConfig() if tag.startswith("full") else C.small_fmt_config()
+    for use_graph in (False, True):
+        sd, fmt = _fmt(cfg, g["seed"], "bf16", use_graph)
+        r_d = fmt.sample(g["r_s"], g["wa"], g["we"], g["noise"], g["nfe"], g["a"], 1.0, g["e"]).cpu()
+        assert r_d.shape == g["r_d"].shape
+        err = rel_l2(r_d, g["r_d"])
+        print(tag, "graph" if use_graph else "eager", "rel-L2 %.3e" % err)
+        assert err < TOL["bf16"], err
+        if use_graph:
+            assert torch.equal(r_d, r_eager), "graph replay must be bitwise identical to eager launches"
+        r_eager = r_d
+
+
+def test_window_50_steps_vs_oracle():
+    """One full-size window at the headline setting: nfe = 51 (50 evaluations), a=2, e=1."""
+    cfg = C.FmtConfig()
+    sd, fmt = _fmt(cfg, 11, "bf16")
+    gen = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=gen)  # noqa: E731
+    x0, wa, wr, we = r(1, 50, 512), r(1, 50, 512), r(1, 512), torch.softmax(r(1, 1, 7), -1)
+    px, pwa = r(1, 10, 512), r(1, 10, 512)
+    got = fmt.sample_chunk(x0, wa, wr, we, px, pwa, None, nfe=51, a_cfg_scale=2.0, e_cfg_scale=1.0).cpu()
+    ref = O.sample_chunk(sd, cfg, x0, wa, wr, we, px, pwa, None, 51, 2.0, 1.0, 1.0)
+    err = rel_l2(got, ref)
+    print("50-step window rel-L2 %.3e" % err)
+    assert err < TOL["bf16"]
+    # determinism: same inputs, same bits
+    again = fmt.sample_chunk(x0, wa, wr, we, px, pwa, None, nfe=51, a_cfg_scale=2.0, e_cfg_scale=1.0).cpu()
+    assert torch.equal(got, again)
+
+
+def test_linearity_of_cfg_scales():
+    """Size-independent property: v(a,e) is affine in the scales (FMT.py:379)."""
+    cfg = C.FmtConfig()
+    sd, fmt = _fmt(cfg, 5, "bf16")
+    g = golden("fmt_eval_full")
+    args = [g["t"]] + [g["cfg3_" + k] for k in ("x", "wa", "wr", "we", "prev_x", "prev_wa")]
+    v = lambda a, e: fmt.forward_with_cfv(*args, None, a_cfg_scale=a, e_cfg_scale=e).cpu()  # noqa: E731
+    v11, v21, v31, v12 = v(1.0001, 1.0), v(2.0, 1.0), v(3.0, 1.0), v(1.0001, 2.0)
+    assert rel_l2(v31 - v21, v21 - v11) < 2e-3
+    assert float((v12 - v11).abs().max()) > 0
+
+
+def test_error_behaviour():
+    cfg = C.small_fmt_config()
+    sd, fmt = _fmt(cfg, 1, "bf16")
+    z = torch.zeros
+    with pytest.raises(ValueError, match="prev_we"):
+        fmt.forward_with_cfv(torch.tensor([0.1]), z(1, 50, 128), z(1, 50, 128), z(1, 128), z(1, 50, 7), z(1, 10, 128),
+                             z(1, 10, 128), None)
+    with pytest.raises(ValueError):
+        fmt.forward_with_cfv(torch.tensor([0.1]), z(1, 49, 128), z(1, 50, 128), z(1, 128), z(1, 1, 7), z(1, 10, 128),
+                             z(1, 10, 128), None)
+    bad = dict(sd)
+    del bad["blocks.0.attn.qkv.weight"]
+    with pytest.raises(KeyError):
+        pkg.fmt.FlowMatchingTransformerHIP(bad, cfg, "cuda:0")
