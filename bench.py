@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Benchmark of the FLOAT hot path on MI355X: FMT Euler sampling loop + Synthesis decoder.
+
+One "step" = one clip: `--seconds` of audio at 25 fps (default 10 s -> 250 frames, BASELINE.json
+configs[1]) sampled with `--nfe` grid points (default 51 = 50 Euler evaluations per 50-frame
+window, 3-way CFG a=2,e=1) and decoded to 512x512 frames that stay in HBM.  Conditioning tensors
+(wa, we, r_s, s_r, feats) and the noise are synthetic and resident in HBM before the timed region.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, each decoding its own clip (BASELINE.json configs[3], replicas, weak
+scaling); `--mode shard` instead shards ONE N x `--seconds` clip by audio window (configs[2]).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from tests.util import load_pkg  # noqa: E402
+
+# SURVEY.md section 8(d) algorithmic work per unit
+FMT_WEIGHT_BYTES_PER_EVAL = 313.4e6   # bf16 weights streamed once per evaluation
+FMT_FLOP_PER_EVAL_CFG3 = 55.87e9
+DEC_FLOP_PER_FRAME = 37.79e9
+HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0             # dense bf16/fp16
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--nfe", type=int, default=51, help="Euler grid points; evaluations = nfe-1")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--fmt-dtype", default="bf16")
+    ap.add_argument("--dec-dtype", default="fp16")
+    ap.add_argument("--max-frames", type=int, default=16)
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
+    ap.add_argument("--dynamic-we", action="store_true", help="BASELINE configs[4]: per-window emotion")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--d2h", action="store_true", help="also time the copy of the frames to host memory")
+    return ap.parse_args()
+
+
+def cpu_baseline(pkg, cfg, fmt_sd, dec_sd, feats, cond, nfe_evals):
+    """The oracle (a port of the reference's torch-CPU path) on this host's cores, bounded sample:
+    a few CFG evaluations of the FMT and a few decoded frames; fps = 1 / (evals/frame * t_eval + t_frame)."""
+    from oracle import float_oracle as O
+    n_threads = torch.get_num_threads()
+    L = cfg.num_frames_for_clip
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, L, cfg.dim_w, generator=g)
+    wa, we, r_s, s_r = cond["wa"][:, :L].cpu(), cond["we"][:, :1].cpu(), cond["r_s"].cpu(), cond["s_r"].cpu()
+    px = torch.zeros(1, cfg.num_prev_frames, cfg.dim_w)
+    n_eval, n_frames = 6, 4
+    O.fmt_forward_cfv(fmt_sd, cfg, torch.tensor([0.5]), x, wa, r_s, we, px, px, None, 2.0, 1.0, 1.0)  # warm-up
+    t0 = time.perf_counter()
+    for i in range(n_eval):
+        O.fmt_forward_cfv(fmt_sd, cfg, torch.tensor([i / n_eval]), x, wa, r_s, we, px, px, None, 2.0, 1.0, 1.0)
+    t_eval = (time.perf_counter() - t0) / n_eval
+    cfeats = [f.cpu() for f in feats]
+    t0 = time.perf_counter()
+    O.decode_frames(dec_sd, s_r, x[:, :n_frames] * 0.5, cfeats)
+    t_frame = (time.perf_counter() - t0) / n_frames
+    evals_per_frame = nfe_evals / float(L)
+    fps = 1.0 / (evals_per_frame * t_eval + t_frame)
+    return {"value": round(fps, 4), "unit": "frames/s", "cores": n_threads, "kind": "port",
+            "sample": "%d CFG-3 FMT evaluations (%.3f s each) + %d decoded 512x512 frames (%.3f s each), fp32 oracle"
+                      % (n_eval, t_eval, n_frames, t_frame)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    pkg = load_pkg()
+    cfg = pkg.config.FmtConfig()
+    fps_video = 25.0
+    T = int(math.ceil(args.seconds * fps_video))
+    fmt_sd = pkg.weights.synth_fmt_state(cfg, seed=1)
+    dec_sd = pkg.weights.synth_decoder_state(args.size, seed=1)
+    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, dev, args.size, args.fmt_dtype, args.dec_dtype,
+                                   args.max_frames, use_graph=not args.no_graph)
+    feats = [f.to(dev) for f in pkg.weights.synth_feats(args.size, seed=1 + rank)]
+    hp.dec.set_feats(feats)
+
+    if args.mode == "shard" and world > 1:
+        # one long clip of world*T frames; every rank runs the identical (deterministic) latent chain,
+        # then decodes its contiguous frame range - see comfyui-float_optimized_amd/distributed.py
+        T_total = T * world
+        cond = pkg.pipeline.synth_conditions(cfg, T_total, seed=0, dynamic_we=args.dynamic_we, device=dev)
+    else:
+        T_total = T
+        cond = pkg.pipeline.synth_conditions(cfg, T, seed=rank, dynamic_we=args.dynamic_we, device=dev)
+    noise = pkg.fmt.draw_noise(hp.n_chunks(T_total), 1, cfg, seed=15).to(dev)
+    a_cfg, e_cfg = (1.0, 3.0) if args.dynamic_we else (2.0, 1.0)
+
+    def step():
+        r_d = hp.sample(cond["r_s"], cond["wa"], cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+        if args.mode == "shard" and world > 1:
+            return hp.decode(cond["s_r"], None, r_d, (rank * T, (rank + 1) * T))
+        return hp.decode(cond["s_r"], None, r_d)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frames = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        frames = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert frames.shape == (T, args.size, args.size, 3)
+    total_frames = T * world * args.steps
+    fps = total_frames / elapsed
+
+    extra = {}
+    if rank == 0:
+        # stage split (one more step, not part of `value`)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        ev[0].record()
+        r_d = hp.sample(cond["r_s"], cond["wa"], cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+        ev[1].record()
+        fr = hp.decode(cond["s_r"], None, r_d, (0, T))
+        ev[2].record()
+        torch.cuda.synchronize()
+        extra["stage_ms"] = {"fmt_sample": round(ev[0].elapsed_time(ev[1]), 3), "decode": round(ev[1].elapsed_time(ev[2]), 3)}
+        if args.d2h:
+            host = torch.empty(fr.shape, dtype=torch.float32, pin_memory=True)
+            t1 = time.perf_counter()
+            host.copy_(fr)
+            torch.cuda.synchronize()
+            extra["stage_ms"]["d2h"] = round((time.perf_counter() - t1) * 1e3, 3)
+            extra["fps_incl_d2h"] = round(T / ((sum(extra["stage_ms"].values())) * 1e-3), 2)
+
+    roof = None
+    if rank == 0 and not args.no_roofline:
+        # Per-launch kernel durations: one more identical step with hipEvents around every launch of
+        # the two dominant kernel classes, recorded on the stream they are launched on (eager launches;
+        # the timed region above replays the same kernels from a hipGraph).
+        n_chunks_rank = hp.n_chunks(T_total)
+        pkg.native.set_profiling(True)
+        r_d = hp.sample(cond["r_s"], cond["wa"], cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+        hp.decode(cond["s_r"], None, r_d, (0, T))
+        torch.cuda.synchronize()
+        g_ms, g_n = pkg.native.profile_ms(0)
+        c_ms, c_n = pkg.native.profile_ms(1)
+        pkg.native.set_profiling(False)
+        n_eval = n_chunks_rank * (args.nfe - 1)
+        gemm_total_ms, conv_total_ms = g_ms * g_n, c_ms * c_n
+        gemm_bytes = FMT_WEIGHT_BYTES_PER_EVAL * n_eval
+        conv_flop = DEC_FLOP_PER_FRAME * T
+        gemm_roof = {"kernel": "fmt_gemm_kernel", "bound": "hbm", "achieved": round(gemm_bytes / (gemm_total_ms * 1e-3) / 1e9, 1),
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": g_n, "avg_launch_us": round(g_ms * 1e3, 2),
+                     "algorithmic_bytes_per_launch": round(gemm_bytes / max(g_n, 1)), "traffic": None}
+        gemm_roof["frac"] = round(gemm_roof["achieved"] / HBM_PEAK_GBS, 4)
+        conv_roof = {"kernel": "dec_conv_kernel", "bound": "mfma", "achieved": round(conv_flop / (conv_total_ms * 1e-3) / 1e12, 2),
+                     "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": c_n, "avg_launch_us": round(c_ms * 1e3, 2),
+                     "algorithmic_flop_per_launch": round(conv_flop / max(c_n, 1)), "traffic": None}
+        conv_roof["frac"] = round(conv_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
+        roof = (conv_roof, gemm_roof) if conv_total_ms >= gemm_total_ms else (gemm_roof, conv_roof)
+        extra["kernel_class_ms"] = {"fmt_gemm": round(gemm_total_ms, 2), "dec_conv": round(conv_total_ms, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(pkg, cfg, fmt_sd, dec_sd, feats, cond, args.nfe - 1)
+
+    if rank == 0:
+        out = {
+            "metric": "512x512 frames/sec end-to-end audio->video @50 ODE steps (hot path: FMT sampling + decode)",
+            "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "%s+%s" % (args.fmt_dtype, args.dec_dtype) if args.fmt_dtype != args.dec_dtype else args.fmt_dtype,
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: %.0f s audio -> %d frames %dx%d, %d Euler evaluations/window, CFG a=%.1f e=%.1f%s"
+                                   % (args.seconds, T, args.size, args.size, args.nfe - 1, a_cfg, e_cfg,
+                                      ", dynamic per-window emotion" if args.dynamic_we else ""),
+                       "nfe": args.nfe, "frames_per_clip": T, "fmt_dtype": args.fmt_dtype, "dec_dtype": args.dec_dtype,
+                       "decode_batch": args.max_frames, "hip_graph": not args.no_graph,
+                       "parallelism": ("replicas x%d (one clip per GPU)" % world) if args.mode == "replicas" or world == 1
+                       else "shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world)},
+        }
+        out.update(extra)
+        if roof:
+            out["roofline"] = roof[0]
+            out["roofline_secondary"] = roof[1]
+        if cpu:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

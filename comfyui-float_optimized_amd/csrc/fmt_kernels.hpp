@@ -276,7 +276,10 @@ __global__ void fmt_build_cond_kernel(u16* __restrict__ out, int ld, int bc, int
       v = on_r ? wr[c] : 0.f;
     } else if (c < dim_w + dim_a) {
       const int k = c - dim_w;
-      if (on_a) v = (i < n_prev) ? prev_wa[i * dim_a + k] : wa[(i - n_prev) * dim_a + k];
+      // prev_wa is replicated UN-nulled into every CFG row; only the current window is nulled
+      // (prev_wa_cat = [prev_wa]*3, FMT.py:366 vs audio_cat, FMT.py:360)
+      if (i < n_prev) v = prev_wa[i * dim_a + k];
+      else if (on_a) v = wa[(i - n_prev) * dim_a + k];
     } else if (c < dim_w + dim_a + dim_e) {
       const int k = c - dim_w - dim_a;
       if (on_e) {

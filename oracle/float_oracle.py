@@ -35,8 +35,23 @@ def timestep_embedding(t, dim=256, max_period=10000.0):
     return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
 
 
+_EMULATE = None  # torch.bfloat16 / torch.float16: round GEMM operands like the 16-bit HIP path does
+
+
+def set_emulation(dt):
+    """Diagnostic only: make every Linear round its input and weight to `dt` first (fp32
+    accumulate), which is where the HIP kernels round.  Separates precision effects from logic
+    errors when a parity test fails.  None restores exact arithmetic."""
+    global _EMULATE
+    _EMULATE = dt
+
+
+def _q(t):
+    return t if _EMULATE is None else t.to(_EMULATE).to(t.dtype)
+
+
 def _linear(x, sd, name):
-    return x @ sd[name + ".weight"].to(x.dtype).T + sd[name + ".bias"].to(x.dtype)
+    return _q(x) @ _q(sd[name + ".weight"].to(x.dtype)).T + sd[name + ".bias"].to(x.dtype)
 
 
 def _silu(x):
@@ -101,6 +116,7 @@ def fmt_forward(sd, cfg, t, x, wa, wr, we, prev_x, prev_wa, prev_we=None, dtype=
         sh1, s1, g1, sh2, s2, g2 = mod.chunk(6, dim=-1)  # FMT.py:173
         a_in = _layernorm(h) * (1 + s1) + sh1
         qkv = _linear(a_in, sd, p + "attn.qkv").reshape(B, N, 3, H, D // H).permute(2, 0, 3, 1, 4)
+        qkv = _q(qkv)
         o = band_attention(qkv[0], qkv[1], qkv[2], cfg.attention_window)
         o = o.transpose(1, 2).reshape(B, N, D)
         h = h + g1 * _linear(o, sd, p + "attn.proj")
