@@ -1,12 +1,13 @@
 // C-ABI entry points of the FMT operator (include/float_hip.h) and the host-side launch chain.
 #include <math.h>
+#include <stdlib.h>
 
 #include "fmt_kernels.hpp"
 
 namespace {
 
 struct Lin {
-  u16* W = nullptr;     // [N][K] 16-bit, K padded to 256
+  u16* W = nullptr;     // packed [N/16][K/32][64][8] 16-bit (fmt_pack_off), K padded to 128
   float* b = nullptr;   // [N]
   int N = 0, K = 0;
 };
@@ -51,7 +52,7 @@ template <class T>
 int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
                 Lin* out) {
   // Concatenate the named Linear layers along N (used to fuse every adaLN projection into one GEMM).
-  const int Kp = round_up(K, 256);
+  const int Kp = round_up(K, 128);
   const int N = N_each * (int)names.size();
   std::vector<u16> hw((size_t)N * Kp, 0);
   std::vector<float> hb(N, 0.f);
@@ -70,8 +71,7 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
     }
     for (int n = 0; n < N_each; ++n) {
       const float* src = w->data + (size_t)n * K;
-      u16* dst = hw.data() + (size_t)(n0 + n) * Kp;
-      for (int k = 0; k < K; ++k) dst[k] = T::host_from_float(src[k]);
+      for (int k = 0; k < K; ++k) hw[fmt_pack_off(n0 + n, k, Kp / 32)] = T::host_from_float(src[k]);
       hb[n0 + n] = b->data[n];
     }
     n0 += N_each;
@@ -86,64 +86,119 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
   return FLOAT_OK;
 }
 
-template <class T, int MT, int EPI>
-void set_attr() {
-  constexpr int smem = 4 * MT * 16 * 32 * (int)sizeof(float);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fmt_gemm_kernel<T, MT, 2, EPI>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-}
-template <class T, int MT>
-void set_attr_mt() {
-  set_attr<T, MT, EPI_F32>();
-  set_attr<T, MT, EPI_T16>();
-  set_attr<T, MT, EPI_SILU_T16>();
-  set_attr<T, MT, EPI_GELU_T16>();
-  set_attr<T, MT, EPI_GATE_RES>();
-  set_attr<T, MT, EPI_CFG>();
-}
-template <class T>
-void prime_kernels() {
-  set_attr_mt<T, 4>();
-  set_attr_mt<T, 12>();
-  set_attr_mt<T, 15>();
-  set_attr<T, 4, EPI_XEMBED>();
-}
-
-template <class T, int MT, int EPI>
-int launch_gemm_mt(const GemmArgs& g, hipStream_t s) {
-  constexpr int smem = 4 * MT * 16 * 32 * (int)sizeof(float);
-  dim3 grid(g.N / 32, (g.M + MT * 16 - 1) / (MT * 16));
+// ---- GEMM instantiation table: (row tiles, column tiles, waves splitting K) per workgroup ----
+template <class T, int MTW, int NT, int NW, int EPI>
+int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
+  constexpr int smem = NW * MTW * 16 * NT * 16 * (int)sizeof(float);
+  auto kern = fmt_gemm_kernel<T, MTW, NT, NW, EPI>;
+  if (smem > 160 * 1024) {  // gfx950: 160 KiB of LDS per workgroup
+    if (!prime) fh_set_error("GEMM tiling %dx%d tiles with %d waves needs %d B of LDS", MTW, NT, NW, smem);
+    return FLOAT_E_INVALID;
+  }
+  if (prime) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      (void)hipGetLastError();
+    return FLOAT_OK;
+  }
+  const int mt_total = (g.M + 15) / 16;
+  g.mblk = (mt_total + MTW - 1) / MTW;
+  dim3 grid((g.N / (NT * 16)) * g.mblk);
   fh_prof_begin(0, s);
-  hipLaunchKernelGGL((fmt_gemm_kernel<T, MT, 2, EPI>), grid, dim3(256), smem, s, g);
+  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, g);
   fh_prof_end(0, s);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
 
+// Which tilings exist.  Split tilings (a quarter/third/half of the CFG rows per workgroup) carry every
+// epilogue and 4/8/16 K-splitting waves; full-height tilings (4 waves, LDS bound) only the two
+// epilogues that need them: EPI_CFG (all CFG rows of a token in one workgroup) and EPI_F32.
+#define FMT_SPLIT_SHAPES(X, NW, EPI) \
+  X(3, 1, NW, EPI) X(3, 2, NW, EPI) X(5, 1, NW, EPI) X(5, 2, NW, EPI) X(4, 1, NW, EPI) X(4, 2, NW, EPI) X(6, 2, NW, EPI) \
+  X(2, 1, NW, EPI) X(1, 1, NW, EPI)
+#define FMT_FOR_SPLIT(X, EPI) FMT_SPLIT_SHAPES(X, 4, EPI) FMT_SPLIT_SHAPES(X, 8, EPI) FMT_SPLIT_SHAPES(X, 16, EPI)
+#define FMT_FOR_FULL(X, EPI) X(12, 2, 4, EPI) X(15, 2, 4, EPI)
+
 template <class T, int EPI>
-int launch_gemm(const GemmArgs& g, int mt, hipStream_t s) {
-  if (g.N % 32 || g.K % 256) {
-    fh_set_error("gemm shape N=%d K=%d not tileable", g.N, g.K);
+int launch_gemm(const GemmArgs& g, int mtw, int nt, int nw, bool prime, hipStream_t s) {
+  if (!prime && (g.N % (nt * 16) || g.K % (32 * nw))) {
+    fh_set_error("gemm shape N=%d K=%d not tileable by %d columns / %d waves", g.N, g.K, nt * 16, nw);
     return FLOAT_E_INVALID;
   }
-  if constexpr (EPI == EPI_XEMBED) {
-    if (mt == 4) return launch_gemm_mt<T, 4, EPI>(g, s);
-  } else {
-    switch (mt) {
-      case 4: return launch_gemm_mt<T, 4, EPI>(g, s);
-      case 12: return launch_gemm_mt<T, 12, EPI>(g, s);
-      case 15: return launch_gemm_mt<T, 15, EPI>(g, s);
-    }
+#define FMT_CASE(MTW, NT, NW, E) \
+  if (mtw == MTW && nt == NT && nw == NW) return launch_gemm_t<T, MTW, NT, NW, E>(g, prime, s);
+  FMT_FOR_SPLIT(FMT_CASE, EPI)
+  if constexpr (EPI == EPI_F32 || EPI == EPI_CFG) {
+    FMT_FOR_FULL(FMT_CASE, EPI)
   }
-  fh_set_error("unsupported m-tile count %d", mt);
+#undef FMT_CASE
+  fh_set_error("no GEMM tiling (%d x %d tiles, %d waves) for epilogue %d", mtw, nt, nw, EPI);
   return FLOAT_E_INVALID;
 }
 
-GemmArgs base_args(const u16* A, int lda, const Lin& L, int M) {
+template <class T, int EPI>
+void prime_epi() {
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  static const int shapes[][2] = {{3, 1}, {3, 2}, {5, 1}, {5, 2}, {4, 1}, {4, 2}, {6, 2}, {2, 1}, {1, 1}};
+  for (auto& c : shapes)
+    for (int nw : {4, 8, 16}) (void)launch_gemm<T, EPI>(g, c[0], c[1], nw, true, nullptr);
+  if (EPI == EPI_F32 || EPI == EPI_CFG) {
+    (void)launch_gemm<T, EPI>(g, 12, 2, 4, true, nullptr);
+    (void)launch_gemm<T, EPI>(g, 15, 2, 4, true, nullptr);
+  }
+}
+template <class T>
+void prime_kernels() {
+  prime_epi<T, EPI_F32>();
+  prime_epi<T, EPI_T16>();
+  prime_epi<T, EPI_SILU_P16>();
+  prime_epi<T, EPI_GELU_P16>();
+  prime_epi<T, EPI_GATE_RES>();
+  prime_epi<T, EPI_XEMBED>();
+  prime_epi<T, EPI_CFG>();
+}
+
+// Tiling choice: split the rows over row blocks so that narrow layers still fill the 256 CUs, and
+// split K over as many waves as keeps >= 4 k-steps per wave (one prefetch round per wave).
+struct Tiling {
+  int mtw, nt, nw;
+};
+int g_fmt_plan_override[6] = {0, 0, 0, 0, 0, 0};  // FLOAT_FMT_PLAN="mtw,nt,nw (narrow), mtw,nt,nw (wide)": tuning aid
+int pick_nw(int K, int forced) {
+  const int KB = K / 32;
+  if (forced && KB % forced == 0) return forced;
+  if (KB >= 128 && KB % 16 == 0) return 16;
+  if (KB >= 32 && KB % 8 == 0) return 8;
+  return 4;
+}
+Tiling pick_tiling(int M, int N, int K, bool need_full_rows) {
+  const int mt = (M + 15) / 16;
+  if (need_full_rows) {
+    if (mt <= 4) return {4, 2, pick_nw(K, 0)};
+    return {mt <= 12 ? 12 : 15, 2, 4};
+  }
+  int split = mt <= 4 ? 4 : (mt <= 12 ? 3 : 5);
+  if (mt <= 2) split = mt;
+  const int blocks = (mt + split - 1) / split;
+  const bool wide = N >= 16384;  // the fused adaLN projection
+  if (mt >= 12) {  // tuning overrides only apply to the CFG-batched shapes (buffers hold 240 rows)
+    const int* o = g_fmt_plan_override + (wide ? 3 : 0);
+    if (o[0]) {
+      int nw = o[0] >= 12 ? 4 : pick_nw(K, o[2]);
+      while (nw > 4 && nw * o[0] * 16 * o[1] * 16 * 4 > 160 * 1024) nw >>= 1;
+      return {o[0], o[1], nw};
+    }
+  }
+  if (wide) return {mt <= 4 ? 4 : 6, 2, std::min(8, pick_nw(K, 0))};
+  const int nt = ((N / 16) * blocks <= 512) ? 1 : 2;
+  return {split, nt, pick_nw(K, 0)};
+}
+
+GemmArgs base_args(const u16* A, const Lin& L, int M) {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   g.A = A;
-  g.lda = lda;
   g.W = L.W;
   g.bias = L.b;
   g.K = L.K;
@@ -152,14 +207,19 @@ GemmArgs base_args(const u16* A, int lda, const Lin& L, int M) {
   return g;
 }
 
+template <class T, int EPI>
+int run_gemm(const GemmArgs& g, hipStream_t s, bool need_full_rows = false) {
+  const Tiling t = pick_tiling(g.M, g.N, g.K, need_full_rows);
+  return launch_gemm<T, EPI>(g, t.mtw, t.nt, t.nw, false, s);
+}
+
 template <class T>
 int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s) {
   const int nv = h->D / 256;
   dim3 grid((M + 3) / 4);
 #define LN_CASE(NV)                                                                                              \
   case NV:                                                                                                       \
-    hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV>), grid, dim3(256), 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, \
-                       h->D);                                                                                    \
+    hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV>), grid, dim3(256), 0, s, h->xres, M, shift, scale, h->Ntot, h->h16); \
     break;
   switch (nv) {
     LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8)
@@ -178,68 +238,67 @@ template <class T>
 int run_eval(float_fmt* h, int bc, int step, bool euler, float dt, float a, float r, float e, hipStream_t s) {
   const float_fmt_cfg_t& c = h->cfg;
   const int D = h->D, ntok = h->ntok, M = bc * ntok;
-  const int mt = (M + 15) / 16;
   int rc;
   // sc = silu(t_emb + c_cond), once per evaluation, shared by every adaLN projection
-  hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 4 + 255) / 256), dim3(256), 0, s, h->sc16,
+  hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256), dim3(256), 0, s, h->sc16,
                      h->temb + (size_t)step * D, h->ccond, M, D);
   // every adaLN modulation of the evaluation in one weight-streaming GEMM: mod[M][depth*6D + 2D]
   {
-    GemmArgs g = base_args(h->sc16, D, h->adaln_all, M);
+    GemmArgs g = base_args(h->sc16, h->adaln_all, M);
     g.out_f32 = h->mod;
     g.ldo = h->Ntot;
-    if ((rc = launch_gemm<T, EPI_F32>(g, mt, s))) return rc;
+    if ((rc = run_gemm<T, EPI_F32>(g, s))) return rc;
   }
   // x_embedder + pos_embed; the CFG rows share x, so 60 rows are computed and broadcast
   {
-    GemmArgs g = base_args(h->xin16, h->Kx, h->x_embed, ntok);
+    GemmArgs g = base_args(h->xin16, h->x_embed, ntok);
     g.out_f32 = h->xres;
     g.ldo = D;
     g.pos = h->pos;
     g.bc = bc;
     g.ntok = ntok;
-    if ((rc = launch_gemm<T, EPI_XEMBED>(g, 4, s))) return rc;
+    if ((rc = run_gemm<T, EPI_XEMBED>(g, s))) return rc;
   }
   for (int b = 0; b < c.depth; ++b) {
     const float* mod = h->mod + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
     if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
     {
-      GemmArgs g = base_args(h->h16, D, B.qkv, M);
+      GemmArgs g = base_args(h->h16, B.qkv, M);
       g.out16 = h->qkv16;
       g.ldo16 = 3 * D;
-      if ((rc = launch_gemm<T, EPI_T16>(g, mt, s))) return rc;
+      if ((rc = run_gemm<T, EPI_T16>(g, s))) return rc;
     }
-    hipLaunchKernelGGL((fmt_attn_kernel<T>), dim3(bc * c.heads), dim3(256), 0, s, h->qkv16, 3 * D, h->att16, D, ntok,
+    hipLaunchKernelGGL((fmt_attn_kernel<T>), dim3(bc * c.heads), dim3(512), 0, s, h->qkv16, 3 * D, h->att16, ntok,
                        c.heads, D, c.attn_window);
     {
-      GemmArgs g = base_args(h->att16, D, B.proj, M);
+      GemmArgs g = base_args(h->att16, B.proj, M);
       g.out_f32 = h->xres;
       g.ldo = D;
       g.gate = mod + 2 * D;
       g.ldg = h->Ntot;
-      if ((rc = launch_gemm<T, EPI_GATE_RES>(g, mt, s))) return rc;
+      if ((rc = run_gemm<T, EPI_GATE_RES>(g, s))) return rc;
     }
     if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s))) return rc;
     {
-      GemmArgs g = base_args(h->h16, D, B.fc1, M);
+      GemmArgs g = base_args(h->h16, B.fc1, M);
       g.out16 = h->hid16;
-      g.ldo16 = c.mlp_hidden;
-      if ((rc = launch_gemm<T, EPI_GELU_T16>(g, mt, s))) return rc;
+      g.ldo16 = B.fc2.K / 32;  // packed for fc2
+      if ((rc = run_gemm<T, EPI_GELU_P16>(g, s))) return rc;
     }
     {
-      GemmArgs g = base_args(h->hid16, c.mlp_hidden, B.fc2, M);
+      GemmArgs g = base_args(h->hid16, B.fc2, M);
       g.out_f32 = h->xres;
       g.ldo = D;
       g.gate = mod + 5 * D;
       g.ldg = h->Ntot;
-      if ((rc = launch_gemm<T, EPI_GATE_RES>(g, mt, s))) return rc;
+      if ((rc = run_gemm<T, EPI_GATE_RES>(g, s))) return rc;
     }
   }
   {
     const float* mod = h->mod + (size_t)c.depth * 6 * D;  // shift, scale (FMT.py:196)
     if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
-    GemmArgs g = base_args(h->h16, D, h->final_lin, M);
+    GemmArgs g = base_args(h->h16, h->final_lin, M);
     g.bc = bc;
     g.ntok = ntok;
     g.n_prev = c.n_prev;
@@ -250,11 +309,11 @@ int run_eval(float_fmt* h, int bc, int step, bool euler, float dt, float a, floa
     if (euler) {
       g.xcur = h->xcur;
       g.xin16 = h->xin16;
-      g.ldx = h->Kx;
+      g.ldx = h->Kx / 32;
     } else {
       g.vout = h->vout;
     }
-    if ((rc = launch_gemm<T, EPI_CFG>(g, mt, s))) return rc;
+    if ((rc = run_gemm<T, EPI_CFG>(g, s, true))) return rc;
   }
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
@@ -279,14 +338,14 @@ int prepare_time(float_fmt* h, const std::vector<float>& ts, hipStream_t s) {
   int rc;
   FH_CHECK_HIP(hipMemcpyAsync(h->ts_dev, ts.data(), n * sizeof(float), hipMemcpyHostToDevice, s));
   hipLaunchKernelGGL((fmt_tsin_kernel<T>), dim3(n), dim3(256), 0, s, h->tsin16, h->ts_dev, h->freqs, n);
-  GemmArgs g = base_args(h->tsin16, 256, h->t0, n);
+  GemmArgs g = base_args(h->tsin16, h->t0, n);
   g.out16 = h->th16;
-  g.ldo16 = h->D;
-  if ((rc = launch_gemm<T, EPI_SILU_T16>(g, 4, s))) return rc;
-  GemmArgs g2 = base_args(h->th16, h->D, h->t2, n);
+  g.ldo16 = h->t2.K / 32;
+  if ((rc = launch_gemm<T, EPI_SILU_P16>(g, 4, 1, pick_nw(g.K, 0), false, s))) return rc;
+  GemmArgs g2 = base_args(h->th16, h->t2, n);
   g2.out_f32 = h->temb;
   g2.ldo = h->D;
-  if ((rc = launch_gemm<T, EPI_F32>(g2, 4, s))) return rc;
+  if ((rc = launch_gemm<T, EPI_F32>(g2, 4, 1, pick_nw(g2.K, 0), false, s))) return rc;
   return FLOAT_OK;
 }
 
@@ -309,13 +368,13 @@ int stage_window(float_fmt* h, const CfgMode& m, const float* x0, const float* w
   const int M = m.bc * h->ntok;
   hipLaunchKernelGGL((fmt_build_cond_kernel<T>), dim3(M), dim3(256), 0, s, h->cond16, h->Kc, m.bc, h->ntok, c.n_prev,
                      c.dim_w, c.dim_a, c.dim_e, wr, wa, prev_wa, we, we_len, prev_we, m.wr_mask, m.wa_mask, m.we_mask);
-  GemmArgs g = base_args(h->cond16, h->Kc, h->c_embed, M);
+  GemmArgs g = base_args(h->cond16, h->c_embed, M);
   g.out_f32 = h->ccond;
   g.ldo = h->D;
   int rc;
-  if ((rc = launch_gemm<T, EPI_F32>(g, (M + 15) / 16, s))) return rc;
+  if ((rc = run_gemm<T, EPI_F32>(g, s))) return rc;
   const int n = h->ntok * c.dim_w;
-  hipLaunchKernelGGL((fmt_init_x_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->xin16, h->Kx, x0, prev_x,
+  hipLaunchKernelGGL((fmt_init_x_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->xin16, h->Kx / 32, x0, prev_x,
                      c.n_prev, c.n_cur, c.dim_w);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
@@ -506,8 +565,11 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   h->D = cfg->dim_h;
   h->ntok = cfg->n_prev + cfg->n_cur;
   h->Mpad = 16 * ((4 * h->ntok + 15) / 16);
-  h->Kc = round_up(cfg->dim_w + cfg->dim_a + cfg->dim_e, 256);
-  h->Kx = round_up(cfg->dim_w, 256);
+  h->Kc = round_up(cfg->dim_w + cfg->dim_a + cfg->dim_e, 128);
+  h->Kx = round_up(cfg->dim_w, 128);
+  if (const char* pl = getenv("FLOAT_FMT_PLAN"))
+    sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],
+           &g_fmt_plan_override[3], &g_fmt_plan_override[4], &g_fmt_plan_override[5]);
   h->Ntot = cfg->depth * 6 * h->D + 2 * h->D;
   TensorTable tt(tensors, n_tensors);
   int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);

@@ -1,32 +1,44 @@
 // HIP kernels of the Flow-Matching-Transformer evaluation (reference FMT.py:277-401).
 //
 // Shapes: M = Bc * n_tok rows (Bc = 1/3/4 CFG rows x 60 tokens), so every linear layer is a
-// weight-streaming GEMM with a short M.  One workgroup owns ALL rows of a 32-column slab of the
-// output and its 4 waves split K; the weights are therefore read from HBM exactly once (non-temporal),
-// partial sums meet in LDS, and the epilogue (bias / GELU / gate*residual / CFG+Euler) is applied once
-// per output element, in a fixed order -> bitwise reproducible, no atomics.
+// weight-streaming GEMM with a short M.  Both operands live in HBM in MFMA-FRAGMENT-MAJOR order:
+//   packed[tile16][kb][lane(64)][8]   tile16 = row/16 (A) or n/16 (W), kb = k/32,
+//                                     lane = (row%16) + 16*((k/8)%4), 8 consecutive k per lane
+// so the 16-byte-per-lane operand of v_mfma_f32_16x16x32 for one (tile, kb) is ONE contiguous 1 KiB
+// wave load (8 full 128-B lines) and consecutive k-steps are consecutive KiBs - no LDS staging, no
+// strided rows hitting one L2 channel.  A workgroup owns MTW row tiles x NT column tiles; its 4 waves
+// split K, partial sums meet in LDS, and the epilogue (bias / SiLU / GELU / gate*residual / CFG+Euler)
+// is applied once per output element in a fixed order -> bitwise reproducible, no atomics.  Weights
+// are read from HBM once (non-temporal); workgroups that share a weight column block differ only in
+// blockIdx.y, i.e. by a multiple of gridDim.x (a multiple of 8), so they sit on one XCD's L2.
 #pragma once
 #include "common.hpp"
 
 enum {
-  EPI_F32 = 0,       // out_f32 = acc + bias
-  EPI_T16 = 1,       // out16   = T(acc + bias)
-  EPI_SILU_T16 = 2,  // out16   = T(silu(acc + bias))
-  EPI_GELU_T16 = 3,  // out16   = T(gelu_tanh(acc + bias))
-  EPI_GATE_RES = 4,  // out_f32 += gate * (acc + bias)                       (FMT.py:174-175)
-  EPI_XEMBED = 5,    // out_f32[b*ntok + r] = acc + bias + pos[r], b < bc     (FMT.py:319-320)
-  EPI_CFG = 6        // CFG combine (+ Euler update) on the final linear      (FMT.py:375-399)
+  EPI_F32 = 0,       // out_f32 = acc + bias                                   (row-major fp32)
+  EPI_T16 = 1,       // out16   = T(acc + bias)                                (row-major, feeds attention)
+  EPI_SILU_P16 = 2,  // out16   = T(silu(acc + bias))                          (packed, feeds a GEMM)
+  EPI_GELU_P16 = 3,  // out16   = T(gelu_tanh(acc + bias))                     (packed, feeds a GEMM)
+  EPI_GATE_RES = 4,  // out_f32 += gate * (acc + bias)                         (FMT.py:174-175)
+  EPI_XEMBED = 5,    // out_f32[b*ntok + r] = acc + bias + pos[r], b < bc       (FMT.py:319-320)
+  EPI_CFG = 6        // CFG combine (+ Euler update) on the final linear        (FMT.py:375-399)
 };
 
+// element offset of (row, k) in a packed operand with KB = K/32 k-blocks
+__host__ __device__ __forceinline__ size_t fmt_pack_off(int row, int k, int KB) {
+  return ((size_t)((row >> 4) * KB + (k >> 5)) * 64 + (row & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
+}
+
 struct GemmArgs {
-  const u16* A;   // [rows][lda], K contiguous, rows padded to a multiple of 16 (pad rows are zero)
-  const u16* W;   // [N][K]  (torch Linear layout), K padded to a multiple of 256
+  const u16* A;   // packed [row tiles][KB][64][8]; pad rows/columns are zero
+  const u16* W;   // packed [N/16][KB][64][8]
   const float* bias;
-  int lda, K, M, N;
+  int K, M, N;    // K padded to a multiple of 128
+  int mblk;       // number of row blocks (grid = N/BN * mblk workgroups)
   float* out_f32;
   int ldo;
   u16* out16;
-  int ldo16;
+  int ldo16;      // row-major leading dim (EPI_T16) or KB of the consumer (packed epilogues)
   const float* gate;
   int ldg;
   const float* pos;
@@ -35,58 +47,84 @@ struct GemmArgs {
   float a_cfg, r_cfg, e_cfg, dt;
   float* vout;   // (ntok, N) combined velocity (float_fmt_eval) or nullptr
   float* xcur;   // (ntok - n_prev, N) Euler state or nullptr
-  u16* xin16;    // next evaluation's x_embedder input rows (ntok, ldx) or nullptr
+  u16* xin16;    // next evaluation's x_embedder input, packed with KB = ldx
   int ldx;
 };
 
-template <class T, int MT, int NT, int EPI>
-__global__ __launch_bounds__(256) void fmt_gemm_kernel(GemmArgs g) {
+template <class T, int MTW, int NT, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   constexpr int BN = NT * 16;
-  constexpr int ROWS = MT * 16;
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][ROWS][BN]
+  constexpr int ROWS = MTW * 16;
+  constexpr int NTHR = NW * 64;
+  constexpr int PF = (MTW + NT <= 5) ? 4 : ((MTW + NT <= 8) ? 3 : 2);  // k-steps of operands in flight per wave
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][BN]
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
-  const int n0 = blockIdx.x * BN;
-  const int m0 = blockIdx.y * ROWS;
+  // 1-D grid of (column blocks) x (row blocks).  Row blocks of one column block read the same
+  // weights: give them consecutive slots on ONE XCD (ids congruent mod 8 share an XCD's L2).
+  int bx, by;
+  {
+    const int nbx = g.N / BN, id = blockIdx.x;
+    if ((nbx & 7) == 0) {
+      const int slot = id >> 3;
+      by = slot % g.mblk;
+      bx = (slot / g.mblk) * 8 + (id & 7);
+    } else {
+      bx = id % nbx;
+      by = id / nbx;
+    }
+  }
+  const int nb0 = bx * NT;
+  const int mt0 = by * MTW;
+  const int n0 = nb0 * 16, m0 = mt0 * 16;
 
-  f32x4 acc[MT][NT];
+  f32x4 acc[MTW][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int kw = g.K >> 2;
-  const u16* Ap = g.A + (size_t)(m0 + r16) * g.lda + w * kw + q * 8;
-  const u16* Wp = g.W + (size_t)(n0 + r16) * g.K + w * kw + q * 8;
-  // Two k-steps of fragments in flight per wave (kw is a multiple of 64): the loads of step k+1 are
-  // issued before the MFMAs of step k, so ~28 x 16 B per lane are outstanding against HBM/L2.
-  u32x4 a0[MT], b0[NT], a1[MT], b1[NT];
-  auto load = [&](u32x4 (&a)[MT], u32x4 (&b)[NT], int k) {
+  const int KB = g.K >> 5;
+  const int KBw = KB / NW;  // k-blocks per wave
+  const u16* Ap = g.A + ((size_t)mt0 * KB + w * KBw) * 512 + lane * 8;
+  const u16* Wp = g.W + ((size_t)nb0 * KB + w * KBw) * 512 + lane * 8;
+  const size_t tstride = (size_t)KB * 512;
+
+  u32x4 a[PF][MTW], b[PF][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
-      b[j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + (size_t)j * 16 * g.K + k));
+  for (int p = 0; p < PF; ++p) {
+    if (p < KBw) {
 #pragma unroll
-    for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const u32x4*>(Ap + (size_t)i * 16 * g.lda + k);
-  };
-  auto mma = [&](const u32x4 (&a)[MT], const u32x4 (&b)[NT]) {
+      for (int j = 0; j < NT; ++j) b[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + j * tstride + (size_t)p * 512));
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MTW; ++i) a[p][i] = *reinterpret_cast<const u32x4*>(Ap + i * tstride + (size_t)p * 512);
+    }
+  }
+  for (int kb0 = 0; kb0 < KBw; kb0 += PF) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) acc[i][j] = T::mfma(a[i], b[j], acc[i][j]);
-  };
-  load(a0, b0, 0);
-  for (int k = 0; k < kw; k += 64) {
-    load(a1, b1, k + 32);
-    mma(a0, b0);
-    if (k + 64 < kw) load(a0, b0, k + 64);
-    mma(a1, b1);
+    for (int p = 0; p < PF; ++p) {
+      const int kb = kb0 + p;
+      if (kb < KBw) {
+#pragma unroll
+        for (int i = 0; i < MTW; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = T::mfma(a[p][i], b[p][j], acc[i][j]);
+        if (kb + PF < KBw) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            b[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + j * tstride + (size_t)(kb + PF) * 512));
+#pragma unroll
+          for (int i = 0; i < MTW; ++i) a[p][i] = *reinterpret_cast<const u32x4*>(Ap + i * tstride + (size_t)(kb + PF) * 512);
+        }
+      }
+    }
   }
 
   // C/D map of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
   float* my = red + w * (ROWS * BN);
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MTW; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -94,19 +132,26 @@ __global__ __launch_bounds__(256) void fmt_gemm_kernel(GemmArgs g) {
   __syncthreads();
 
   constexpr int S = ROWS * BN;
+  constexpr int CG = BN / 8;  // 8-column groups per row
+  auto slab_sum = [&](int o) {
+    float a = red[o];
+#pragma unroll
+    for (int ww = 1; ww < NW; ++ww) a += red[ww * S + o];
+    return a;
+  };
   if constexpr (EPI == EPI_CFG) {
     // rows of the tile: b * ntok + i.  Combine the CFG rows of token i, then (optionally) Euler.
-    for (int idx = threadIdx.x; idx < g.ntok * BN; idx += 256) {
+    for (int idx = threadIdx.x; idx < g.ntok * BN; idx += NTHR) {
       const int i = idx / BN, c = idx % BN, n = n0 + c;
       const float bias = g.bias[n];
       float v[4];
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        if (b < g.bc) {
-          const int o = (b * g.ntok + i) * BN + c;
-          v[b] = red[o] + red[S + o] + red[2 * S + o] + red[3 * S + o] + bias;
+      for (int b2 = 0; b2 < 4; ++b2) {
+        if (b2 < g.bc) {
+          const int o = (b2 * g.ntok + i) * BN + c;
+          v[b2] = slab_sum(o) + bias;
         } else {
-          v[b] = 0.f;
+          v[b2] = 0.f;
         }
       }
       float out;
@@ -122,141 +167,213 @@ __global__ __launch_bounds__(256) void fmt_gemm_kernel(GemmArgs g) {
         const size_t xo = (size_t)(i - g.n_prev) * g.N + n;
         const float xn = g.xcur[xo] + g.dt * out;  // x_{k+1} = x_k + dt * v  (fixed-grid Euler)
         g.xcur[xo] = xn;
-        g.xin16[(size_t)i * g.ldx + n] = T::from_float(xn);
+        g.xin16[fmt_pack_off(i, n, g.ldx)] = T::from_float(xn);
       }
     }
   } else {
-    for (int idx = threadIdx.x; idx < S; idx += 256) {
-      const int r = idx / BN, c = idx % BN;
-      const int row = m0 + r, n = n0 + c;
+    for (int idx = threadIdx.x; idx < ROWS * CG; idx += NTHR) {
+      const int r = idx / CG, cg = idx % CG;
+      const int row = m0 + r, nb = n0 + cg * 8;
       if (row >= g.M) continue;
-      const float v = red[idx] + red[S + idx] + red[2 * S + idx] + red[3 * S + idx] + g.bias[n];
+      float v[8];
+      {
+        const float* p0 = red + r * BN + cg * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          float4 a4 = *reinterpret_cast<const float4*>(p0 + e);
+#pragma unroll
+          for (int ww = 1; ww < NW; ++ww) {
+            const float4 t4 = *reinterpret_cast<const float4*>(p0 + ww * S + e);
+            a4.x += t4.x;
+            a4.y += t4.y;
+            a4.z += t4.z;
+            a4.w += t4.w;
+          }
+          const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb + e);
+          v[e + 0] = a4.x + bb.x;
+          v[e + 1] = a4.y + bb.y;
+          v[e + 2] = a4.z + bb.z;
+          v[e + 3] = a4.w + bb.w;
+        }
+      }
       if constexpr (EPI == EPI_F32) {
-        g.out_f32[(size_t)row * g.ldo + n] = v;
-      } else if constexpr (EPI == EPI_T16) {
-        g.out16[(size_t)row * g.ldo16 + n] = T::from_float(v);
-      } else if constexpr (EPI == EPI_SILU_T16) {
-        g.out16[(size_t)row * g.ldo16 + n] = T::from_float(fh_silu(v));
-      } else if constexpr (EPI == EPI_GELU_T16) {
-        g.out16[(size_t)row * g.ldo16 + n] = T::from_float(fh_gelu_tanh(v));
+        float* o = g.out_f32 + (size_t)row * g.ldo + nb;
+        *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
+      } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16) {
+        uint4 u;
+        u16* e = reinterpret_cast<u16*>(&u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          float x = v[i];
+          if constexpr (EPI == EPI_SILU_P16) x = fh_silu(x);
+          if constexpr (EPI == EPI_GELU_P16) x = fh_gelu_tanh(x);
+          e[i] = T::from_float(x);
+        }
+        if constexpr (EPI == EPI_T16) *reinterpret_cast<uint4*>(g.out16 + (size_t)row * g.ldo16 + nb) = u;
+        else *reinterpret_cast<uint4*>(g.out16 + fmt_pack_off(row, nb, g.ldo16)) = u;
       } else if constexpr (EPI == EPI_GATE_RES) {
-        const size_t o = (size_t)row * g.ldo + n;
-        g.out_f32[o] = g.out_f32[o] + g.gate[(size_t)row * g.ldg + n] * v;
+        float* o = g.out_f32 + (size_t)row * g.ldo + nb;
+        const float* gt = g.gate + (size_t)row * g.ldg + nb;
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+          float4 x = *reinterpret_cast<const float4*>(o + e);
+          const float4 gg = *reinterpret_cast<const float4*>(gt + e);
+          x.x += gg.x * v[e + 0];
+          x.y += gg.y * v[e + 1];
+          x.z += gg.z * v[e + 2];
+          x.w += gg.w * v[e + 3];
+          *reinterpret_cast<float4*>(o + e) = x;
+        }
       } else if constexpr (EPI == EPI_XEMBED) {
-        const float val = v + g.pos[(size_t)row * g.N + n];
-        for (int b = 0; b < g.bc; ++b) g.out_f32[(size_t)(b * g.ntok + row) * g.ldo + n] = val;
+        const float* ps = g.pos + (size_t)row * g.N + nb;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += ps[i];
+        for (int b2 = 0; b2 < g.bc; ++b2) {
+          float* o = g.out_f32 + (size_t)(b2 * g.ntok + row) * g.ldo + nb;
+          *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
+          *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
+        }
       }
     }
   }
 }
 
 // LayerNorm (no affine, biased variance, eps 1e-6) + framewise modulate, one wave per token row
-// (FMT.py:157,168-169,174-175,197).  out = T( (x-mu)*rstd * (1 + scale[row]) + shift[row] ).
+// (FMT.py:157,168-169,174-175,197).  out = T( (x-mu)*rstd * (1 + scale[row]) + shift[row] ), written in
+// the packed A-operand order of the consuming GEMM (K = D).
 template <class T, int NV>
 __global__ __launch_bounds__(256) void fmt_lnmod_kernel(const float* __restrict__ x, int M, const float* __restrict__ shift,
-                                                        const float* __restrict__ scale, int ldm, u16* __restrict__ out,
-                                                        int ldo) {
+                                                        const float* __restrict__ scale, int ldm, u16* __restrict__ out) {
   constexpr int D = NV * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const float* xr = x + (size_t)row * D;
-  float4 v[NV];
+  const float* sh = shift + (size_t)row * ldm;
+  const float* sc = scale + (size_t)row * ldm;
+  float4 v[NV], a[NV], b[NV];
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    v[i] = *reinterpret_cast<const float4*>(xr + i * 256 + lane * 4);
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const int c = i * 256 + lane * 4;
+    v[i] = *reinterpret_cast<const float4*>(xr + c);
+    a[i] = *reinterpret_cast<const float4*>(sh + c);
+    b[i] = *reinterpret_cast<const float4*>(sc + c);
   }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
   const float mu = wave_sum(s) * (1.f / D);
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const float a = v[i].x - mu, b = v[i].y - mu, c = v[i].z - mu, d = v[i].w - mu;
-    s2 += (a * a + b * b) + (c * c + d * d);
+    const float d0 = v[i].x - mu, d1 = v[i].y - mu, d2 = v[i].z - mu, d3 = v[i].w - mu;
+    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
   }
   const float rstd = rsqrtf(wave_sum(s2) * (1.f / D) + 1e-6f);
-  const float* sh = shift + (size_t)row * ldm;
-  const float* sc = scale + (size_t)row * ldm;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
-    const float4 a = *reinterpret_cast<const float4*>(sh + c);
-    const float4 b = *reinterpret_cast<const float4*>(sc + c);
     ushort4 o;
-    o.x = T::from_float((v[i].x - mu) * rstd * (1.f + b.x) + a.x);
-    o.y = T::from_float((v[i].y - mu) * rstd * (1.f + b.y) + a.y);
-    o.z = T::from_float((v[i].z - mu) * rstd * (1.f + b.z) + a.z);
-    o.w = T::from_float((v[i].w - mu) * rstd * (1.f + b.w) + a.w);
-    *reinterpret_cast<ushort4*>(out + (size_t)row * ldo + c) = o;
+    o.x = T::from_float((v[i].x - mu) * rstd * (1.f + b[i].x) + a[i].x);
+    o.y = T::from_float((v[i].y - mu) * rstd * (1.f + b[i].y) + a[i].y);
+    o.z = T::from_float((v[i].z - mu) * rstd * (1.f + b[i].z) + a[i].z);
+    o.w = T::from_float((v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w);
+    *reinterpret_cast<ushort4*>(out + fmt_pack_off(row, c, D / 32)) = o;
   }
 }
 
 // Banded attention (FMT.py:71-88 with the mask of FMT.py:15-19): query i sees keys |i-j| <= window.
-// One workgroup per (cfg row b, head h); 4 lanes per query, 32 of the 128 head dims each.  With at
-// most 2*window+1 keys per query this is 0.3 % of the evaluation's flops - LDS/MFMA tiling would
-// only add latency, so q/k/v are read straight from L2 in 64-byte pieces and the softmax is online.
+// One workgroup per (cfg row b, head h); 8 lanes per query, 16 of the 128 head dims each.  With at
+// most 2*window+1 keys per query this is 0.3 % of the evaluation's flops - MFMA/LDS tiling would only
+// add latency - so q/k/v come straight from L2 in 32-byte pieces.  For window <= 2 every load of the
+// query's band is issued before the first use (one memory round trip); wider windows loop.
+// Output is written in the packed A-operand order of the proj GEMM (K = D).
 template <class T>
-__global__ __launch_bounds__(256) void fmt_attn_kernel(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ldo,
-                                                       int ntok, int heads, int D, int window) {
-  constexpr int HD = 128, PD = 32;
+__global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ntok,
+                                                       int heads, int D, int window) {
+  constexpr int HD = 128, PD = 16, LPQ = 8;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const int qi = threadIdx.x >> 2, part = threadIdx.x & 3;
-  if (qi >= ntok) return;  // whole quads leave together
+  const int qi = threadIdx.x / LPQ, part = threadIdx.x % LPQ;
+  if (qi >= ntok) return;  // whole 8-lane groups leave together
   const int d0 = h * HD + part * PD;
-  const u16* qp = qkv + (size_t)(b * ntok + qi) * ld + d0;
-  float qf[PD];
-#pragma unroll
-  for (int i = 0; i < PD / 8; ++i) {
-    const uint4 u = *reinterpret_cast<const uint4*>(qp + i * 8);
-    const u16* e = reinterpret_cast<const u16*>(&u);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qf[i * 8 + j] = T::to_float(e[j]);
-  }
   const float scale = rsqrtf((float)HD);
-  float m = -INFINITY, l = 0.f;
-  float o[PD];
+  const u16* base = qkv + (size_t)(b * ntok) * ld + d0;
+  float qf[PD], o[PD];
+  {
+    const uint4 u0 = *reinterpret_cast<const uint4*>(base + (size_t)qi * ld);
+    const uint4 u1 = *reinterpret_cast<const uint4*>(base + (size_t)qi * ld + 8);
+    const u16* e0 = reinterpret_cast<const u16*>(&u0);
+    const u16* e1 = reinterpret_cast<const u16*>(&u1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qf[j] = T::to_float(e0[j]) * scale;
+      qf[8 + j] = T::to_float(e1[j]) * scale;
+    }
+  }
 #pragma unroll
   for (int i = 0; i < PD; ++i) o[i] = 0.f;
-  const int j0 = max(0, qi - window), j1 = min(ntok - 1, qi + window);
-  for (int kj = j0; kj <= j1; ++kj) {
-    const u16* kp = qkv + (size_t)(b * ntok + kj) * ld + D + d0;
-    const u16* vp = kp + D;
+  float m = -INFINITY, l = 0.f;
+  auto fold = [&](const uint4& k0, const uint4& k1, const uint4& v0, const uint4& v1, bool valid) {
+    const u16* ka = reinterpret_cast<const u16*>(&k0);
+    const u16* kb = reinterpret_cast<const u16*>(&k1);
     float dot = 0.f;
-    uint4 vu[PD / 8];
 #pragma unroll
-    for (int i = 0; i < PD / 8; ++i) {
-      const uint4 u = *reinterpret_cast<const uint4*>(kp + i * 8);
-      vu[i] = *reinterpret_cast<const uint4*>(vp + i * 8);
-      const u16* e = reinterpret_cast<const u16*>(&u);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) dot += qf[i * 8 + j] * T::to_float(e[j]);
-    }
+    for (int j = 0; j < 8; ++j) dot += qf[j] * T::to_float(ka[j]) + qf[8 + j] * T::to_float(kb[j]);
     dot += __shfl_xor(dot, 1, 64);
     dot += __shfl_xor(dot, 2, 64);
-    const float s = dot * scale;
-    const float mn = fmaxf(m, s);
-    const float alpha = __expf(m - mn);
-    const float p = __expf(s - mn);
+    dot += __shfl_xor(dot, 4, 64);
+    if (!valid) return;
+    const float mn = fmaxf(m, dot);
+    const float alpha = __expf(m - mn), p = __expf(dot - mn);
     l = l * alpha + p;
     m = mn;
+    const u16* va = reinterpret_cast<const u16*>(&v0);
+    const u16* vb = reinterpret_cast<const u16*>(&v1);
 #pragma unroll
-    for (int i = 0; i < PD / 8; ++i) {
-      const u16* e = reinterpret_cast<const u16*>(&vu[i]);
+    for (int j = 0; j < 8; ++j) {
+      o[j] = o[j] * alpha + p * T::to_float(va[j]);
+      o[8 + j] = o[8 + j] * alpha + p * T::to_float(vb[j]);
+    }
+  };
+  if (window <= 2) {
+    uint4 kk[5][2], vv[5][2];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[i * 8 + j] = o[i * 8 + j] * alpha + p * T::to_float(e[j]);
+    for (int t = 0; t < 5; ++t) {
+      const int kj = min(max(qi + t - 2, 0), ntok - 1);
+      const u16* kp = base + (size_t)kj * ld + D;
+      kk[t][0] = *reinterpret_cast<const uint4*>(kp);
+      kk[t][1] = *reinterpret_cast<const uint4*>(kp + 8);
+      vv[t][0] = *reinterpret_cast<const uint4*>(kp + D);
+      vv[t][1] = *reinterpret_cast<const uint4*>(kp + D + 8);
+    }
+#pragma unroll
+    for (int t = 0; t < 5; ++t) {
+      const int kj = qi + t - 2;
+      const bool valid = kj >= 0 && kj < ntok && (t - 2 >= -window) && (t - 2 <= window);
+      fold(kk[t][0], kk[t][1], vv[t][0], vv[t][1], valid);
+    }
+  } else {
+    for (int kj = qi - window; kj <= qi + window; ++kj) {
+      const int kc = min(max(kj, 0), ntok - 1);
+      const u16* kp = base + (size_t)kc * ld + D;
+      const uint4 k0 = *reinterpret_cast<const uint4*>(kp), k1 = *reinterpret_cast<const uint4*>(kp + 8);
+      const uint4 v0 = *reinterpret_cast<const uint4*>(kp + D), v1 = *reinterpret_cast<const uint4*>(kp + D + 8);
+      fold(k0, k1, v0, v1, kj >= 0 && kj < ntok);
     }
   }
   const float inv = 1.f / l;
-  u16* op = out + (size_t)(b * ntok + qi) * ldo + d0;
+  uint4 u0, u1;
+  u16* e0 = reinterpret_cast<u16*>(&u0);
+  u16* e1 = reinterpret_cast<u16*>(&u1);
 #pragma unroll
-  for (int i = 0; i < PD / 8; ++i) {
-    uint4 u;
-    u16* e = reinterpret_cast<u16*>(&u);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = T::from_float(o[i * 8 + j] * inv);
-    *reinterpret_cast<uint4*>(op + i * 8) = u;
+  for (int j = 0; j < 8; ++j) {
+    e0[j] = T::from_float(o[j] * inv);
+    e1[j] = T::from_float(o[8 + j] * inv);
   }
+  const int row = b * ntok + qi;
+  *reinterpret_cast<uint4*>(out + fmt_pack_off(row, d0, D / 32)) = u0;
+  *reinterpret_cast<uint4*>(out + fmt_pack_off(row, d0 + 8, D / 32)) = u1;
 }
 
 // Condition rows for c_embedder: [wr | wa | we | 0-pad] per (cfg row b, token i) with the CFG nulling
@@ -287,7 +404,7 @@ __global__ void fmt_build_cond_kernel(u16* __restrict__ out, int ld, int bc, int
         else v = (i < n_prev) ? prev_we[i * dim_e + k] : we[(i - n_prev) * dim_e + k];
       }
     }
-    out[(size_t)row * ld + c] = T::from_float(v);
+    out[fmt_pack_off(row, c, ld / 32)] = T::from_float(v);
   }
 }
 
@@ -299,24 +416,29 @@ __global__ void fmt_tsin_kernel(u16* __restrict__ out, const float* __restrict__
   if (s >= n_steps) return;
   const int k = threadIdx.x;  // 0..255
   const float arg = ts[s] * freqs[k & 127];
-  out[(size_t)s * 256 + k] = T::from_float(k < 128 ? cosf(arg) : sinf(arg));
+  out[fmt_pack_off(s, k, 8)] = T::from_float(k < 128 ? cosf(arg) : sinf(arg));
 }
 
 // sc16[row] = T(silu(t_emb + c_cond[row]))   (c = t + c_embedder(.), FMT.py:335; SiLU of FMT.py:164,187)
+// written packed: the A operand of the fused adaLN projection.  8 columns per thread.
 template <class T>
 __global__ void fmt_silu_c_kernel(u16* __restrict__ out, const float* __restrict__ temb, const float* __restrict__ ccond,
                                   int M, int D) {
-  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (idx >= M * D) return;
-  const int c = idx % D;
-  const float4 a = *reinterpret_cast<const float4*>(ccond + idx);
-  const float4 t = *reinterpret_cast<const float4*>(temb + c);
-  ushort4 o;
-  o.x = T::from_float(fh_silu(a.x + t.x));
-  o.y = T::from_float(fh_silu(a.y + t.y));
-  o.z = T::from_float(fh_silu(a.z + t.z));
-  o.w = T::from_float(fh_silu(a.w + t.w));
-  *reinterpret_cast<ushort4*>(out + idx) = o;
+  const int row = idx / D, c = idx % D;
+  uint4 u;
+  u16* e = reinterpret_cast<u16*>(&u);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float4 a = *reinterpret_cast<const float4*>(ccond + idx + 4 * h);
+    const float4 t = *reinterpret_cast<const float4*>(temb + c + 4 * h);
+    e[4 * h + 0] = T::from_float(fh_silu(a.x + t.x));
+    e[4 * h + 1] = T::from_float(fh_silu(a.y + t.y));
+    e[4 * h + 2] = T::from_float(fh_silu(a.z + t.z));
+    e[4 * h + 3] = T::from_float(fh_silu(a.w + t.w));
+  }
+  *reinterpret_cast<uint4*>(out + fmt_pack_off(row, c, D / 32)) = u;
 }
 
 // Euler state and x_embedder input rows for a new window: xcur = x0; xin16 = [prev_x ; x0].
@@ -334,7 +456,7 @@ __global__ void fmt_init_x_kernel(float* __restrict__ xcur, u16* __restrict__ xi
     v = x0[(i - n_prev) * dim_w + c];
     xcur[(i - n_prev) * dim_w + c] = v;
   }
-  xin16[(size_t)i * ldx + c] = T::from_float(v);
+  xin16[fmt_pack_off(i, c, ldx)] = T::from_float(v);
 }
 
 // Window slice with replicate padding along time (FLOAT.py:224-227): dst[i] = src[min(t0+i, T-1)].
