@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
     ap.add_argument("--dynamic-we", action="store_true", help="BASELINE configs[4]: per-window emotion")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-mode", type=int, default=2, help="2: single-branch hipGraph per window, 1: adaLN GEMM on a parallel branch")
+    ap.add_argument("--fmt-priority", type=int, default=-1)
+    ap.add_argument("--overlap", action="store_true", help="pipeline FMT sampling of window k+1 with the decode of window k on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--d2h", action="store_true", help="also time the copy of the frames to host memory")
@@ -101,7 +104,8 @@ def main():
     fmt_sd = pkg.weights.synth_fmt_state(cfg, seed=1)
     dec_sd = pkg.weights.synth_decoder_state(args.size, seed=1)
     hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, dev, args.size, args.fmt_dtype, args.dec_dtype,
-                                   args.max_frames, use_graph=not args.no_graph)
+                                   args.max_frames, use_graph=0 if args.no_graph else args.graph_mode)
+    hp.fmt_stream_priority = args.fmt_priority
     feats = [f.to(dev) for f in pkg.weights.synth_feats(args.size, seed=1 + rank)]
     hp.dec.set_feats(feats)
 
@@ -117,10 +121,9 @@ def main():
     a_cfg, e_cfg = (1.0, 3.0) if args.dynamic_we else (2.0, 1.0)
 
     def step():
-        r_d = hp.sample(cond["r_s"], cond["wa"], cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
-        if args.mode == "shard" and world > 1:
-            return hp.decode(cond["s_r"], None, r_d, (rank * T, (rank + 1) * T))
-        return hp.decode(cond["s_r"], None, r_d)
+        fr = (rank * T, (rank + 1) * T) if (args.mode == "shard" and world > 1) else None
+        return hp.generate(cond["r_s"], cond["wa"], cond["we"], cond["s_r"], None, args.nfe, a_cfg, 1.0, e_cfg, noise=noise,
+                           overlap=args.overlap, frame_range=fr)
 
     def barrier():
         torch.cuda.synchronize()
@@ -210,6 +213,7 @@ def main():
                                       ", dynamic per-window emotion" if args.dynamic_we else ""),
                        "nfe": args.nfe, "frames_per_clip": T, "fmt_dtype": args.fmt_dtype, "dec_dtype": args.dec_dtype,
                        "decode_batch": args.max_frames, "hip_graph": not args.no_graph,
+                       "stage_overlap": args.overlap,
                        "parallelism": ("replicas x%d (one clip per GPU)" % world) if args.mode == "replicas" or world == 1
                        else "shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world)},
         }

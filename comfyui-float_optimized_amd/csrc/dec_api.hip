@@ -18,6 +18,7 @@ struct Styled {  // one StyledConv (styledecoder.py:302-325)
 struct Level {  // ToFlow + ToRGB of one resolution
   int R = 0, C = 0;
   float *wflow = nullptr, *bflow = nullptr, *wrgb = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float* lin = nullptr;  // [R] np.linspace(-1, 1, R) as float32
   int style_off = 0;
   u16* feat = nullptr;  // [R][R][C]
 };
@@ -30,6 +31,8 @@ int ilog2(int v) {
 
 }  // namespace
 
+constexpr int kStyleCap = 256;
+
 struct float_dec {
   float_dec_cfg_t cfg;
   DevicePool pool;
@@ -40,10 +43,17 @@ struct float_dec {
   float* bm = nullptr;    // [Stot]
   float* cin_hwc = nullptr;  // ConstantInput as [4][4][512]
   bool feats_set = false;
-  // workspace (max_frames)
+  // workspace.  Frames go through the decoder in three nested batches:
+  //   style batch (<= kStyleCap frames): every style modulation + demod factor in two launches;
+  //   low batch   (<= lo_frames): levels up to 32x32, where one frame is only 16..1024 pixels and
+  //                               the 512-channel weights dominate, so many frames share a launch;
+  //   high batch  (<= max_frames): levels 64..size, where activations are 17 MB per frame.
+  int lo_levels = 0, lo_frames = 0;
   float *styles = nullptr, *demod = nullptr;
-  u16 *bufP = nullptr, *bufQ = nullptr, *bufZ = nullptr;
-  float *flowA = nullptr, *flowB = nullptr, *rgbA = nullptr, *rgbB = nullptr;
+  u16 *loA = nullptr, *loB = nullptr, *loZ = nullptr, *loX = nullptr;  // low phase ping/pong/z + hand-over tensor
+  u16 *hiA = nullptr, *hiB = nullptr, *hiZ = nullptr;
+  float *loFlow[2] = {nullptr, nullptr}, *loRgb[2] = {nullptr, nullptr};
+  float *hiFlow[2] = {nullptr, nullptr}, *hiRgb[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -207,6 +217,14 @@ int create_impl(float_dec* h, const TensorTable& tt) {
     for (int i = 0; i < L.C; ++i) bm_host.push_back(fmb->data[i]);
     wm_rows.insert(wm_rows.end(), fmw->data, fmw->data + (size_t)L.C * sdim);
     if ((rc = h->pool.alloc(&L.feat, (size_t)L.R * L.R * L.C, true))) return rc;
+    {
+      // np.linspace(-1, 1, R): start + i*step in float64, last element forced to stop, cast to f32
+      std::vector<float> lin(L.R);
+      const double step = 2.0 / (double)(L.R - 1);
+      for (int i = 0; i < L.R; ++i) lin[i] = (float)(-1.0 + (double)i * step);
+      lin[L.R - 1] = 1.0f;
+      if ((rc = upload32(h, lin, &L.lin))) return rc;
+    }
   }
   h->Stot = (int)bm_host.size();
   std::vector<float> wmT((size_t)sdim * h->Stot);
@@ -222,23 +240,38 @@ int create_impl(float_dec* h, const TensorTable& tt) {
     for (int p = 0; p < 16; ++p) hwc[(size_t)p * chan[2] + c] = ci->data[(size_t)c * 16 + p];
   if ((rc = upload32(h, hwc, &h->cin_hwc))) return rc;
   // workspace
-  const size_t F = (size_t)h->cfg.max_frames;
-  size_t act = 0;
+  h->lo_levels = 0;
+  for (int li = 0; li < h->n_levels - 1; ++li)
+    if ((8 << li) <= 32) h->lo_levels = li + 1;  // levels 8,16,32 (never the last level)
+  h->lo_frames = std::min(128, std::max(h->cfg.max_frames, 8 * h->cfg.max_frames));
+  const size_t FH = (size_t)h->cfg.max_frames, FL = (size_t)h->lo_frames;
+  size_t act_lo = 16 * (size_t)chan[2], act_hi = 0, x_lo = 0;
   for (int li = 0; li < h->n_levels; ++li) {
     const size_t R = 8u << li;
-    act = std::max(act, (R + 1) * (R + 1) * (size_t)chan[li + 3]);
-    act = std::max(act, (R / 2) * (R / 2) * (size_t)chan[li + 2]);
+    const size_t need = std::max((R + 1) * (R + 1) * (size_t)chan[li + 3], (R / 2) * (R / 2) * (size_t)chan[li + 2]);
+    if (li < h->lo_levels) {
+      act_lo = std::max(act_lo, need);
+      x_lo = R * R * (size_t)chan[li + 3];
+    } else {
+      act_hi = std::max(act_hi, need);
+    }
   }
-  if ((rc = h->pool.alloc(&h->styles, F * h->Stot, true))) return rc;
-  if ((rc = h->pool.alloc(&h->demod, F * h->Dtot, true))) return rc;
-  if ((rc = h->pool.alloc(&h->bufP, F * act, true))) return rc;
-  if ((rc = h->pool.alloc(&h->bufQ, F * act, true))) return rc;
-  if ((rc = h->pool.alloc(&h->bufZ, F * act, true))) return rc;
-  const size_t sk = F * (size_t)size * size * 3;
-  if ((rc = h->pool.alloc(&h->flowA, sk, true))) return rc;
-  if ((rc = h->pool.alloc(&h->flowB, sk, true))) return rc;
-  if ((rc = h->pool.alloc(&h->rgbA, sk, true))) return rc;
-  if ((rc = h->pool.alloc(&h->rgbB, sk, true))) return rc;
+  if ((rc = h->pool.alloc(&h->styles, (size_t)kStyleCap * h->Stot, true))) return rc;
+  if ((rc = h->pool.alloc(&h->demod, (size_t)kStyleCap * h->Dtot, true))) return rc;
+  if ((rc = h->pool.alloc(&h->loA, FL * act_lo, true))) return rc;
+  if ((rc = h->pool.alloc(&h->loB, FL * act_lo, true))) return rc;
+  if ((rc = h->pool.alloc(&h->loZ, FL * act_lo, true))) return rc;
+  if ((rc = h->pool.alloc(&h->loX, FL * std::max(x_lo, (size_t)16 * chan[2]), true))) return rc;
+  if ((rc = h->pool.alloc(&h->hiA, FH * act_hi, true))) return rc;
+  if ((rc = h->pool.alloc(&h->hiB, FH * act_hi, true))) return rc;
+  if ((rc = h->pool.alloc(&h->hiZ, FH * act_hi, true))) return rc;
+  const size_t sk_lo = FL * 32 * 32 * 3, sk_hi = FH * (size_t)size * size * 3;
+  for (int i = 0; i < 2; ++i) {
+    if ((rc = h->pool.alloc(&h->loFlow[i], sk_lo, true))) return rc;
+    if ((rc = h->pool.alloc(&h->loRgb[i], sk_lo, true))) return rc;
+    if ((rc = h->pool.alloc(&h->hiFlow[i], sk_hi, true))) return rc;
+    if ((rc = h->pool.alloc(&h->hiRgb[i], sk_hi, true))) return rc;
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   return FLOAT_OK;
@@ -308,116 +341,178 @@ int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, in
   return FLOAT_OK;
 }
 
-// Decode `n` frames (n <= max_frames) whose latents are s_r + r_d[i].
+static const int kDy9[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, kDx9[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
+
+// One resolution level for `n` frames: x_in (R/2, scaled by the up-conv's style) -> z -> U -> V ->
+// flow/warp/blend/rgb.  U and the next level's input may alias (U is dead once conv2 has run).
 template <class T>
-int decode_batch(float_dec* h, const float* s_r, const float* r_d, int n, float* out, int final_mode, hipStream_t st) {
-  const int sdim = h->cfg.style_dim;
+int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16* V, u16* xnext, const float* styles,
+              const float* demod, const float* flow_prev, const float* rgb_prev, float* flow_cur, float* rgb_cur,
+              float* final_out, int final_mode, hipStream_t st) {
+  const Level& L = h->levels[li];
+  const Styled& up = h->convs[1 + 2 * li];
+  const Styled& c2 = h->convs[2 + 2 * li];
+  const int R = L.R, Ri = R / 2;
   int rc;
-  // 1. every style modulation of every layer: styles[n][Stot]
-  {
-    constexpr int FB = 8;
-    dim3 grid((h->Stot + 255) / 256, (n + FB - 1) / FB);
-    hipLaunchKernelGGL((dec_small_gemm_kernel<SG_STYLE, FB>), grid, dim3(256), FB * sdim * sizeof(float), st, r_d, sdim, s_r,
-                       h->WmT, sdim, h->Stot, h->bm, 1.0f / sqrtf((float)sdim), h->styles, h->Stot, n);
-  }
-  // 2. demodulation factors of the 15 StyledConvs: demod[n][Dtot]
-  for (const Styled& s : h->convs) {
-    constexpr int FB = 8;
-    dim3 grid((s.cout + 255) / 256, (n + FB - 1) / FB);
-    hipLaunchKernelGGL((dec_small_gemm_kernel<SG_DEMOD, FB>), grid, dim3(256), FB * s.cin * sizeof(float), st,
-                       h->styles + s.style_off, h->Stot, (const float*)nullptr, s.WsqT, s.cin, s.cout, (const float*)nullptr,
-                       1.0f / (float)(s.cin * 9), h->demod + s.demod_off, h->Dtot, n);
-  }
-  // 3. constant input * style(conv1), conv1 @ 4x4
-  u16 *P = h->bufP, *Q = h->bufQ, *Z = h->bufZ;
-  {
-    const Styled& c1 = h->convs[0];
-    const int tot = n * 16 * c1.cin;
-    hipLaunchKernelGGL((dec_input_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, Q, h->cin_hwc, h->styles + c1.style_off,
-                       h->Stot, n, 16, c1.cin);
-    static const int dy9[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, dx9[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
-    const Styled& nx = h->convs[1];
-    if ((rc = launch_conv<T>(Q, 4, 4, c1, c1.W, 9, dy9, dx9, P, 4, 4, 4, 4, 1, 1, 0, 0, n, h->demod + c1.demod_off, h->Dtot,
-                             c1.abias, 1, h->styles + nx.style_off, h->Stot, st)))
-      return rc;
-  }
-  float *flow_prev = nullptr, *rgb_prev = nullptr, *flow_cur = h->flowA, *rgb_cur = h->rgbA;
-  for (int li = 0; li < h->n_levels; ++li) {
-    const Level& L = h->levels[li];
-    const Styled& up = h->convs[1 + 2 * li];
-    const Styled& c2 = h->convs[2 + 2 * li];
-    const int R = L.R, Ri = R / 2;
-    // 3a. transposed conv (stride 2) as four parity-class convolutions into z (R+1 x R+1), demodulated
-    size_t t0 = 0;
-    for (int pu = 0; pu < 2; ++pu)
-      for (int pv = 0; pv < 2; ++pv) {
-        const ClassTaps c = class_taps(pu, pv);
-        if ((rc = launch_conv<T>(P, Ri, Ri, up, up.W + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Z, Ri + 1 - pu, Ri + 1 - pv, R + 1,
-                                 R + 1, 2, 2, pu, pv, n, h->demod + up.demod_off, h->Dtot, nullptr, 0, nullptr, 0, st)))
-          return rc;
-        t0 += c.n;
-      }
-    // 3b. FIR blur + bias + lrelu, scaled by conv2's style
-    {
-      const size_t tot = (size_t)n * R * R * (up.cout / 8);
-      hipLaunchKernelGGL((dec_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Z, Q, n, R, up.cout, up.abias,
-                         h->styles + c2.style_off, h->Stot);
-    }
-    // 3c. conv2 (plain 3x3), unscaled output feeds ToFlow
-    {
-      static const int dy9[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, dx9[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
-      if ((rc = launch_conv<T>(Q, R, R, c2, c2.W, 9, dy9, dx9, P, R, R, R, R, 1, 1, 0, 0, n, h->demod + c2.demod_off, h->Dtot,
-                               c2.abias, 1, nullptr, 0, st)))
+  // transposed conv (stride 2) as four parity-class convolutions into z (R+1 x R+1), demodulated
+  size_t t0 = 0;
+  for (int pu = 0; pu < 2; ++pu)
+    for (int pv = 0; pv < 2; ++pv) {
+      const ClassTaps c = class_taps(pu, pv);
+      if ((rc = launch_conv<T>(x_in, Ri, Ri, up, up.W + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Zb, Ri + 1 - pu, Ri + 1 - pv,
+                               R + 1, R + 1, 2, 2, pu, pv, n, demod + up.demod_off, h->Dtot, nullptr, 0, nullptr, 0, st)))
         return rc;
+      t0 += c.n;
     }
-    // 3d. ToFlow + warp + blend + ToRGB
-    {
-      const bool last = (li == h->n_levels - 1);
-      FlowArgs g;
-      memset(&g, 0, sizeof(g));
-      g.x = P;
-      g.feat = L.feat;
-      g.pflow = flow_prev;
-      g.prgb = rgb_prev;
-      g.wflow = L.wflow;
-      g.sflow = h->styles + L.style_off;
-      g.bflow = L.bflow;
-      g.wrgb = L.wrgb;
-      g.b1 = L.b1;
-      g.b2 = L.b2;
-      g.snext = last ? nullptr : h->styles + h->convs[1 + 2 * (li + 1)].style_off;
-      g.xnext = last ? nullptr : Q;
-      g.flow_out = flow_cur;
-      g.rgb_out = rgb_cur;
-      g.final_out = last ? out : nullptr;
-      g.final_mode = last ? final_mode : 0;
-      g.F = n;
-      g.R = R;
-      g.C = L.C;
-      g.ld_s = h->Stot;
-      const int ppb = 256 / (L.C / 8);
-      int bx = (R * R + ppb - 1) / ppb;
-      bx = std::min(bx, 2048);
-      hipLaunchKernelGGL((dec_flow_kernel<T>), dim3(bx, n), dim3(256), 0, st, g);
-    }
-    std::swap(P, Q);  // next level's input is the blended tensor just written to Q
-    flow_prev = flow_cur;
-    rgb_prev = rgb_cur;
-    flow_cur = (flow_cur == h->flowA) ? h->flowB : h->flowA;
-    rgb_cur = (rgb_cur == h->rgbA) ? h->rgbB : h->rgbA;
+  // FIR blur + bias + lrelu, scaled by conv2's style
+  {
+    const size_t tot = (size_t)n * R * (R / 4) * (up.cout / 8);
+    hipLaunchKernelGGL((dec_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Zb, U, n, R, up.cout, up.abias,
+                       styles + c2.style_off, h->Stot);
+  }
+  // conv2 (plain 3x3); its unscaled output feeds ToFlow
+  if ((rc = launch_conv<T>(U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
+                           c2.abias, 1, nullptr, 0, st)))
+    return rc;
+  // ToFlow + warp + blend + ToRGB
+  const bool last = (li == h->n_levels - 1);
+  FlowArgs g;
+  memset(&g, 0, sizeof(g));
+  g.x = V;
+  g.feat = L.feat;
+  g.pflow = flow_prev;
+  g.prgb = rgb_prev;
+  g.wflow = L.wflow;
+  g.sflow = styles + L.style_off;
+  g.bflow = L.bflow;
+  g.wrgb = L.wrgb;
+  g.b1 = L.b1;
+  g.b2 = L.b2;
+  g.lin = L.lin;
+  g.snext = last ? nullptr : styles + h->convs[1 + 2 * (li + 1)].style_off;
+  g.xnext = last ? nullptr : xnext;
+  g.flow_out = flow_cur;
+  g.rgb_out = rgb_cur;
+  g.final_out = last ? final_out : nullptr;
+  g.final_mode = last ? final_mode : 0;
+  g.F = n;
+  g.R = R;
+  g.C = L.C;
+  g.ld_s = h->Stot;
+  const int lpp = L.C / 8, gpb = 256 / lpp;
+  if (lpp <= 8) {
+    const int bx = std::min((R * R / 4 + gpb - 1) / gpb, 1024);
+    hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx, n), dim3(256), 0, st, g);
+  } else {
+    const int bx = std::min((R * R / 2 + gpb - 1) / gpb, 1024);
+    hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx, n), dim3(256), 0, st, g);
   }
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
 
+// Low phase for `n` frames (n <= lo_frames): constant input, conv1, levels 8..32.  Leaves the
+// next level's (scaled) input in loX and the flow / rgb pyramids in loFlow[k] / loRgb[k]; returns k.
+template <class T>
+int run_low(float_dec* h, int n, const float* styles, const float* demod, int* skip_idx, hipStream_t st) {
+  int rc;
+  const Styled& c1 = h->convs[0];
+  const int tot = n * 16 * c1.cin;
+  hipLaunchKernelGGL((dec_input_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, h->loB, h->cin_hwc, styles + c1.style_off,
+                     h->Stot, n, 16, c1.cin);
+  u16* first_out = h->lo_levels > 0 ? h->loA : h->loX;
+  if ((rc = launch_conv<T>(h->loB, 4, 4, c1, c1.W, 9, kDy9, kDx9, first_out, 4, 4, 4, 4, 1, 1, 0, 0, n, demod + c1.demod_off,
+                           h->Dtot, c1.abias, 1, styles + h->convs[1].style_off, h->Stot, st)))
+    return rc;
+  int cur = 0;
+  const float *fp = nullptr, *rp = nullptr;
+  for (int li = 0; li < h->lo_levels; ++li) {
+    u16* xnext = (li == h->lo_levels - 1) ? h->loX : h->loA;
+    if ((rc = run_level<T>(h, li, n, h->loA, h->loZ, h->loA, h->loB, xnext, styles, demod, fp, rp, h->loFlow[cur], h->loRgb[cur],
+                           nullptr, 0, st)))
+      return rc;
+    fp = h->loFlow[cur];
+    rp = h->loRgb[cur];
+    cur ^= 1;
+  }
+  *skip_idx = cur ^ 1;  // buffers holding the last written pyramids (unused when lo_levels == 0)
+  return FLOAT_OK;
+}
+
+// High phase for `n` frames (n <= max_frames) that sit at frame offset `off` inside the low batch.
+template <class T>
+int run_high(float_dec* h, int n, int off, const float* styles, const float* demod, int skip_idx, float* out, int final_mode,
+             hipStream_t st) {
+  int rc;
+  const int l0 = h->lo_levels;
+  const u16* x_in;
+  const float *fp = nullptr, *rp = nullptr;
+  if (l0 > 0) {
+    const Level& P = h->levels[l0 - 1];
+    x_in = h->loX + (size_t)off * P.R * P.R * P.C;
+    fp = h->loFlow[skip_idx] + (size_t)off * P.R * P.R * 3;
+    rp = h->loRgb[skip_idx] + (size_t)off * P.R * P.R * 3;
+  } else {
+    x_in = h->loX + (size_t)off * 16 * h->convs[0].cout;
+  }
+  int cur = 0;
+  for (int li = l0; li < h->n_levels; ++li) {
+    if ((rc = run_level<T>(h, li, n, x_in, h->hiZ, h->hiA, h->hiB, h->hiA, styles, demod, fp, rp, h->hiFlow[cur], h->hiRgb[cur],
+                           out, final_mode, st)))
+      return rc;
+    x_in = h->hiA;
+    fp = h->hiFlow[cur];
+    rp = h->hiRgb[cur];
+    cur ^= 1;
+  }
+  return FLOAT_OK;
+}
+
 template <class T>
 int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, float* out, int final_mode, hipStream_t st) {
-  const int F = h->cfg.max_frames, S = h->cfg.size, sdim = h->cfg.style_dim;
-  for (int f0 = 0; f0 < n_frames; f0 += F) {
-    const int n = std::min(F, n_frames - f0);
-    int rc = decode_batch<T>(h, s_r, r_d + (size_t)f0 * sdim, n, out + (size_t)f0 * S * S * 3, final_mode, st);
-    if (rc) return rc;
+  const int S = h->cfg.size, sdim = h->cfg.style_dim, FH = h->cfg.max_frames, FL = h->lo_frames;
+  for (int s0 = 0; s0 < n_frames; s0 += kStyleCap) {
+    const int ns = std::min(kStyleCap, n_frames - s0);
+    // every style modulation (22 EqualLinears) and every demod factor for `ns` frames: 2 launches
+    {
+      constexpr int FB = 8;
+      dim3 grid((h->Stot + 255) / 256, (ns + FB - 1) / FB);
+      hipLaunchKernelGGL((dec_small_gemm_kernel<SG_STYLE, FB>), grid, dim3(256), FB * sdim * sizeof(float), st,
+                         r_d + (size_t)s0 * sdim, sdim, s_r, h->WmT, sdim, h->Stot, h->bm, 1.0f / sqrtf((float)sdim), h->styles,
+                         h->Stot, ns);
+      DemodArgs d;
+      memset(&d, 0, sizeof(d));
+      int maxc = 0, maxcin = 0;
+      FH_REQUIRE(h->convs.size() <= 16, "too many styled convs");
+      for (size_t i = 0; i < h->convs.size(); ++i) {
+        d.L[i] = {h->convs[i].WsqT, h->convs[i].cin, h->convs[i].cout, h->convs[i].style_off, h->convs[i].demod_off};
+        maxc = std::max(maxc, h->convs[i].cout);
+        maxcin = std::max(maxcin, h->convs[i].cin);
+      }
+      d.styles = h->styles;
+      d.demod = h->demod;
+      d.ld_s = h->Stot;
+      d.ld_d = h->Dtot;
+      d.F = ns;
+      dim3 g2((maxc + 255) / 256, (ns + FB - 1) / FB, (unsigned)h->convs.size());
+      hipLaunchKernelGGL((dec_demod_all_kernel<FB>), g2, dim3(256), FB * maxcin * sizeof(float), st, d);
+    }
+    for (int a0 = 0; a0 < ns; a0 += FL) {
+      const int na = std::min(FL, ns - a0);
+      const float* st_a = h->styles + (size_t)a0 * h->Stot;
+      const float* dm_a = h->demod + (size_t)a0 * h->Dtot;
+      int skip_idx = 0;
+      int rc = run_low<T>(h, na, st_a, dm_a, &skip_idx, st);
+      if (rc) return rc;
+      for (int b0 = 0; b0 < na; b0 += FH) {
+        const int nb = std::min(FH, na - b0);
+        rc = run_high<T>(h, nb, b0, st_a + (size_t)b0 * h->Stot, dm_a + (size_t)b0 * h->Dtot, skip_idx,
+                         out + (size_t)(s0 + a0 + b0) * S * S * 3, final_mode, st);
+        if (rc) return rc;
+      }
+    }
   }
+  FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
 

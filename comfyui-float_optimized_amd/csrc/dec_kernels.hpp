@@ -52,6 +52,47 @@ __global__ __launch_bounds__(256) void dec_small_gemm_kernel(const float* __rest
   }
 }
 
+// Demodulation factors of every StyledConv in ONE launch (blockIdx.z = layer):
+// d[f][o] = rsqrt( 1/(Cin*9) * sum_i s[f][i]^2 * Wsq[o][i] + 1e-8 )   (styledecoder.py:244-245)
+struct DemodLayer {
+  const float* WsqT;  // [Cin][Cout]
+  int cin, cout, style_off, demod_off;
+};
+struct DemodArgs {
+  DemodLayer L[16];
+  const float* styles;
+  float* demod;
+  int ld_s, ld_d, F;
+};
+template <int FB>
+__global__ __launch_bounds__(256) void dec_demod_all_kernel(DemodArgs g) {
+  extern __shared__ float s2[];  // [FB][cin]
+  const DemodLayer L = g.L[blockIdx.z];
+  if ((int)blockIdx.x * 256 >= L.cout) return;
+  const int f0 = blockIdx.y * FB;
+  for (int i = threadIdx.x; i < FB * L.cin; i += 256) {
+    const int fl = i / L.cin, k = i - fl * L.cin;
+    float v = 0.f;
+    if (f0 + fl < g.F) v = g.styles[(size_t)(f0 + fl) * g.ld_s + L.style_off + k];
+    s2[i] = v * v;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= L.cout) return;
+  float acc[FB];
+#pragma unroll
+  for (int f = 0; f < FB; ++f) acc[f] = 0.f;
+  for (int k = 0; k < L.cin; ++k) {
+    const float w = L.WsqT[(size_t)k * L.cout + j];
+#pragma unroll
+    for (int f = 0; f < FB; ++f) acc[f] += s2[f * L.cin + k] * w;
+  }
+  const float alpha = 1.0f / (float)(L.cin * 9);
+#pragma unroll
+  for (int f = 0; f < FB; ++f)
+    if (f0 + f < g.F) g.demod[(size_t)(f0 + f) * g.ld_d + L.demod_off + j] = rsqrtf(acc[f] * alpha + 1e-8f);
+}
+
 // ConstantInput repeated over the batch and pre-scaled by conv1's style (styledecoder.py:289-299, 513-514).
 template <class T>
 __global__ void dec_input_kernel(u16* __restrict__ out, const float* __restrict__ cin_hwc, const float* __restrict__ s, int ld_s,
@@ -192,47 +233,69 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
 
 // Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4) over the
 // transposed-conv output z (R+1 x R+1), then + bias, leaky-relu*sqrt2, and the style of the next
-// conv (styledecoder.py:209-213,255-258 then 320-325).  8 channels per thread.
+// conv (styledecoder.py:209-213,255-258 then 320-325).  A thread makes 4 consecutive pixels x 8
+// channels: 4 rows x 7 columns of z are read once (7 loads per output instead of 16) and filtered
+// separably (horizontal per row, then vertical).
 template <class T>
 __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z, u16* __restrict__ out, int F, int R, int C,
                                                        const float* __restrict__ bias, const float* __restrict__ snext, int lds) {
-  const int c8 = C >> 3;
+  const int c8 = C >> 3, xq = R >> 2;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)F * R * R * c8) return;
+  if (idx >= (size_t)F * R * xq * c8) return;
   const int cg = (int)(idx % c8);
   size_t p = idx / c8;
-  const int X = (int)(p % R);
-  p /= R;
+  const int X0 = (int)(p % xq) * 4;
+  p /= xq;
   const int Y = (int)(p % R);
   const int f = (int)(p / R);
   const int Z = R + 1;
   const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-  float acc[8];
+  float acc[4][8];
 #pragma unroll
-  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
 #pragma unroll
   for (int a = 0; a < 4; ++a) {
     const int zy = Y + a - 1;
     if (zy < 0 || zy > R) continue;
+    uint4 u[7];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int zx = X + b - 1;
-      if (zx < 0 || zx > R) continue;
-      const float wgt = k1[a] * k1[b];
-      const uint4 u = *reinterpret_cast<const uint4*>(z + ((size_t)(f * Z + zy) * Z + zx) * C + cg * 8);
-      const u16* e = reinterpret_cast<const u16*>(&u);
+    for (int b = 0; b < 7; ++b) {
+      const int zx = X0 + b - 1;
+      u[b] = (zx >= 0 && zx <= R) ? *reinterpret_cast<const uint4*>(z + ((size_t)(f * Z + zy) * Z + zx) * C + cg * 8)
+                                  : uint4{0u, 0u, 0u, 0u};
+    }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += wgt * T::to_float(e[i]);
+    for (int b = 0; b < 7; ++b) {
+      const u16* e = reinterpret_cast<const u16*>(&u[b]);
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = T::to_float(e[i]) * k1[a];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int t = b - j;  // horizontal tap index for output j
+        if (t >= 0 && t < 4) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[j][i] += k1[t] * v[i];
+        }
+      }
     }
   }
-  uint4 o;
-  u16* oe = reinterpret_cast<u16*>(&o);
+  float bs[8], sn[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    const int c = cg * 8 + i;
-    oe[i] = T::from_float(fh_lrelu_s2(acc[i] + bias[c]) * snext[(size_t)f * lds + c]);
+    bs[i] = bias[cg * 8 + i];
+    sn[i] = snext[(size_t)f * lds + cg * 8 + i];
   }
-  *reinterpret_cast<uint4*>(out + ((size_t)(f * R + Y) * R + X) * C + cg * 8) = o;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint4 o;
+    u16* oe = reinterpret_cast<u16*>(&o);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) oe[i] = T::from_float(fh_lrelu_s2(acc[j][i] + bs[i]) * sn[i]);
+    *reinterpret_cast<uint4*>(out + ((size_t)(f * R + Y) * R + X0 + j) * C + cg * 8) = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -258,6 +321,7 @@ struct FlowArgs {
   u16* xnext;          // [F][R][R][C] or nullptr (last level)
   float* flow_out;     // [F][R][R][3]
   float* rgb_out;      // [F][R][R][3]
+  const float* lin;    // [R] identity grid: np.linspace(-1, 1, R) (float64) cast to float32
   float* final_out;    // last level: frames
   int final_mode;      // 0: none, 1: HWC clamp(-1,1)*0.5+0.5 (FLOAT.py:149-152), 2: raw CHW
   int F, R, C, ld_s;
@@ -286,12 +350,19 @@ __device__ __forceinline__ float up2_tap(const float* __restrict__ prev, int f, 
   return acc;
 }
 
-template <class T>
+__device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x}); saturates cleanly at +-1
+  return 1.f - 2.f / (1.f + __expf(2.f * x));
+}
+
+// PIX consecutive pixels of a row per lane group and iteration: every x load of the iteration is
+// issued before the first flow is reduced, and every feature gather before the first blend, so a
+// wave keeps PIX (x) then 4*PIX (feat) 16-byte loads in flight instead of one dependent pair.
+template <class T, int PIX>
 __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   const int lpp = g.C >> 3;          // lanes per pixel (4..64)
-  const int ppb = 256 / lpp;         // pixels per block iteration
+  const int gpb = 256 / lpp;         // lane groups per block
   const int f = blockIdx.y;
-  const int sub = threadIdx.x % lpp, pl = threadIdx.x / lpp;
+  const int sub = threadIdx.x % lpp, grp = threadIdx.x / lpp;
   const int c0 = sub * 8;
   float wf[3][8], wr[3][8], sn[8];
 #pragma unroll
@@ -304,91 +375,122 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     }
     sn[i] = g.snext ? g.snext[(size_t)f * g.ld_s + c0 + i] : 0.f;
   }
-  const int R = g.R, npix = R * R;
+  // lane `sub` < 3 owns output channel `sub` of the 3-channel maps (bias, pyramid taps, stores)
+  const int jch = sub < 3 ? sub : 0;
+  const float bfl = sub < 3 ? g.bflow[jch] : 0.f;
+  const float b1 = g.b1[jch], b2 = g.b2[jch];
+  const int R = g.R, npix = R * R, Rp = R >> 1;
   const float fR = (float)R;
-  const double lin_step = R > 1 ? 2.0 / (double)(R - 1) : 0.0;
-  for (int p = blockIdx.x * ppb + pl; p < npix; p += gridDim.x * ppb) {
-    const int Y = p / R, X = p - Y * R;
-    const size_t po = ((size_t)f * npix + p);
-    const uint4 xu = *reinterpret_cast<const uint4*>(g.x + po * g.C + c0);
-    const u16* xe = reinterpret_cast<const u16*>(&xu);
-    float xf[8];
-    float o[3] = {0.f, 0.f, 0.f};
+  for (int p0 = (blockIdx.x * gpb + grp) * PIX; p0 < npix; p0 += gridDim.x * gpb * PIX) {
+    const int Y = p0 / R, X0 = p0 - Y * R;  // R % PIX == 0: the PIX pixels share a row
+    const size_t po0 = (size_t)f * npix + p0;
+    uint4 xu[PIX];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      xf[i] = T::to_float(xe[i]);
-      o[0] += wf[0][i] * xf[i];
-      o[1] += wf[1][i] * xf[i];
-      o[2] += wf[2][i] * xf[i];
+    for (int k = 0; k < PIX; ++k) xu[k] = *reinterpret_cast<const uint4*>(g.x + (po0 + k) * g.C + c0);
+    float upf[PIX];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) upf[k] = (g.pflow && sub < 3) ? up2_tap(g.pflow, f, Rp, Y, X0 + k, jch) : 0.f;
+    const float gy = g.lin[Y];
+    float xf[PIX][8], o[PIX][3];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) {
+      const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
+      o[k][0] = o[k][1] = o[k][2] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        xf[k][i] = T::to_float(xe[i]);
+        o[k][0] += wf[0][i] * xf[k][i];
+        o[k][1] += wf[1][i] * xf[k][i];
+        o[k][2] += wf[2][i] * xf[k][i];
+      }
+      // bias + up-sampled previous flow enter the sum once, in the lane that owns the channel
+      const float add = upf[k] + bfl;
+      o[k][0] += sub == 0 ? add : 0.f;
+      o[k][1] += sub == 1 ? add : 0.f;
+      o[k][2] += sub == 2 ? add : 0.f;
     }
     for (int d = 1; d < lpp; d <<= 1) {
-      o[0] += __shfl_xor(o[0], d, 64);
-      o[1] += __shfl_xor(o[1], d, 64);
-      o[2] += __shfl_xor(o[2], d, 64);
-    }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      o[j] += g.bflow[j];
-      if (g.pflow) o[j] += up2_tap(g.pflow, f, R >> 1, Y, X, j);
-    }
-    // identity grid: np.linspace(-1, 1, R) in float64, cast to float32 (styledecoder.py:404-413)
-    const float gx = (X == R - 1) ? 1.f : (float)(-1.0 + (double)X * lin_step);
-    const float gy = (Y == R - 1) ? 1.f : (float)(-1.0 + (double)Y * lin_step);
-    const float sx = tanhf(o[0]) + gx, sy = tanhf(o[1]) + gy;
-    const float mask = fh_sigmoid(o[2]);
-    // grid_sample, align_corners=False: pixel = ((coord + 1) * size - 1) / 2
-    const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;
-    const float fx0 = floorf(ix), fy0 = floorf(iy);
-    const int x0 = (int)fx0, y0 = (int)fy0;
-    const float ax = ix - fx0, ay = iy - fy0;
-    float fw[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) fw[i] = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int yy = y0 + a;
-      if (yy < 0 || yy >= R) continue;
-      const float wy = a ? ay : 1.f - ay;
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int xx = x0 + b;
-        if (xx < 0 || xx >= R) continue;
-        const float wgt = wy * (b ? ax : 1.f - ax);
-        const uint4 fu = *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * g.C + c0);
-        const u16* fe = reinterpret_cast<const u16*>(&fu);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fw[i] += wgt * T::to_float(fe[i]);
+      for (int k = 0; k < PIX; ++k) {
+        o[k][0] += __shfl_xor(o[k][0], d, 64);
+        o[k][1] += __shfl_xor(o[k][1], d, 64);
+        o[k][2] += __shfl_xor(o[k][2], d, 64);
       }
     }
-    float rgb[3] = {0.f, 0.f, 0.f};
+    float mask[PIX], ax[PIX], ay[PIX];
+    uint4 fu[PIX][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      fw[i] *= mask;
-      rgb[0] += wr[0][i] * fw[i];
-      rgb[1] += wr[1][i] * fw[i];
-      rgb[2] += wr[2][i] * fw[i];
+    for (int k = 0; k < PIX; ++k) {
+      const float sx = fh_tanh_fast(o[k][0]) + g.lin[X0 + k], sy = fh_tanh_fast(o[k][1]) + gy;
+      mask[k] = fh_sigmoid(o[k][2]);
+      // grid_sample, align_corners=False: pixel = ((coord + 1) * size - 1) / 2
+      const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;
+      const float fx0 = floorf(ix), fy0 = floorf(iy);
+      const int x0 = (int)fx0, y0 = (int)fy0;  // |ix| <= R + 1: tanh bounds the sample position
+      ax[k] = ix - fx0;
+      ay[k] = iy - fy0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int yy = y0 + a, xx = x0 + b;
+          const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
+          fu[k][a * 2 + b] = in ? *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * g.C + c0) : uint4{0u, 0u, 0u, 0u};
+        }
     }
-    if (g.xnext) {
-      uint4 ou;
-      u16* oe = reinterpret_cast<u16*>(&ou);
+    float upr[PIX];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + xf[i] * (1.f - mask)) * sn[i]);
-      *reinterpret_cast<uint4*>(g.xnext + po * g.C + c0) = ou;
+    for (int k = 0; k < PIX; ++k) upr[k] = (g.prgb && sub < 3) ? up2_tap(g.prgb, f, Rp, Y, X0 + k, jch) : 0.f;
+    float rgb[PIX][3];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) {
+      float fw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fw[i] = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]);
+          const u16* fe = reinterpret_cast<const u16*>(&fu[k][a * 2 + b]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) fw[i] += wgt * T::to_float(fe[i]);
+        }
+      rgb[k][0] = rgb[k][1] = rgb[k][2] = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        fw[i] *= mask[k];
+        rgb[k][0] += wr[0][i] * fw[i];
+        rgb[k][1] += wr[1][i] * fw[i];
+        rgb[k][2] += wr[2][i] * fw[i];
+      }
+      if (g.xnext) {
+        uint4 ou;
+        u16* oe = reinterpret_cast<u16*>(&ou);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + xf[k][i] * (1.f - mask[k])) * sn[i]);
+        *reinterpret_cast<uint4*>(g.xnext + (po0 + k) * g.C + c0) = ou;
+      }
     }
     for (int d = 1; d < lpp; d <<= 1) {
-      rgb[0] += __shfl_xor(rgb[0], d, 64);
-      rgb[1] += __shfl_xor(rgb[1], d, 64);
-      rgb[2] += __shfl_xor(rgb[2], d, 64);
-    }
-    if (sub == 0) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        float v = fh_lrelu_s2(rgb[j] + g.b1[j]) + g.b2[j];
-        if (g.prgb) v += up2_tap(g.prgb, f, R >> 1, Y, X, j);
-        g.flow_out[po * 3 + j] = o[j];
-        g.rgb_out[po * 3 + j] = v;
-        if (g.final_mode == 1) g.final_out[po * 3 + j] = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
-        else if (g.final_mode == 2) g.final_out[((size_t)f * 3 + j) * npix + p] = v;
+      for (int k = 0; k < PIX; ++k) {
+        rgb[k][0] += __shfl_xor(rgb[k][0], d, 64);
+        rgb[k][1] += __shfl_xor(rgb[k][1], d, 64);
+        rgb[k][2] += __shfl_xor(rgb[k][2], d, 64);
+      }
+    }
+    if (sub < 3) {
+#pragma unroll
+      for (int k = 0; k < PIX; ++k) {
+        const float rs = sub == 0 ? rgb[k][0] : (sub == 1 ? rgb[k][1] : rgb[k][2]);
+        const float os = sub == 0 ? o[k][0] : (sub == 1 ? o[k][1] : o[k][2]);
+        const float v = fh_lrelu_s2(rs + b1) + b2 + upr[k];
+        const size_t po = po0 + k;
+        g.flow_out[po * 3 + sub] = os;
+        g.rgb_out[po * 3 + sub] = v;
+        if (g.final_mode == 1) g.final_out[po * 3 + sub] = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
+        else if (g.final_mode == 2) g.final_out[((size_t)f * 3 + sub) * npix + p0 + k] = v;
       }
     }
   }

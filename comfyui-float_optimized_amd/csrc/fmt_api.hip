@@ -41,7 +41,18 @@ struct float_fmt {
     }
   };
   std::map<GraphKey, hipGraphExec_t> graphs;
-  hipStream_t cap_stream = nullptr;
+  hipStream_t cap_stream = nullptr, side_stream = nullptr;
+  std::vector<hipEvent_t> events;
+  float* mod2 = nullptr;
+  // state of an incremental sample (float_fmt_sample_begin / _next)
+  struct {
+    const float *wr, *wa, *we, *noise;
+    float* r_d;
+    int T, we_len, nfe, include_r, next, n_chunks;
+    float a, r, e;
+    std::vector<float> ts;
+    bool active = false;
+  } job;
 };
 
 namespace {
@@ -232,23 +243,28 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   return FLOAT_OK;
 }
 
-// One evaluation of the velocity field on the rows already staged in the workspace.
-// step: index into temb / ts; euler: update xcur/xin16 with dt, else write vout.
+// Modulation half of an evaluation: depends only on t and the window's conditions, NOT on x, so
+// inside a captured window it runs on a side branch one step ahead of the block chain.
+//   sc = silu(t_emb + c_cond)  ->  mod[M][depth*6D + 2D] = every adaLN projection in one
+//   weight-streaming GEMM (105 MB of the 313 MB an evaluation reads).
 template <class T>
-int run_eval(float_fmt* h, int bc, int step, bool euler, float dt, float a, float r, float e, hipStream_t s) {
+int run_mod(float_fmt* h, int bc, int step, float* modbuf, hipStream_t s) {
+  const int D = h->D, M = bc * h->ntok;
+  hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256), dim3(256), 0, s, h->sc16,
+                     h->temb + (size_t)step * D, h->ccond, M, D);
+  GemmArgs g = base_args(h->sc16, h->adaln_all, M);
+  g.out_f32 = modbuf;
+  g.ldo = h->Ntot;
+  return run_gemm<T, EPI_F32>(g, s);
+}
+
+// Block chain of an evaluation on the rows staged in the workspace, using the modulations in modbuf.
+// euler: update xcur/xin16 with dt, else write vout.
+template <class T>
+int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, float a, float r, float e, hipStream_t s) {
   const float_fmt_cfg_t& c = h->cfg;
   const int D = h->D, ntok = h->ntok, M = bc * ntok;
   int rc;
-  // sc = silu(t_emb + c_cond), once per evaluation, shared by every adaLN projection
-  hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256), dim3(256), 0, s, h->sc16,
-                     h->temb + (size_t)step * D, h->ccond, M, D);
-  // every adaLN modulation of the evaluation in one weight-streaming GEMM: mod[M][depth*6D + 2D]
-  {
-    GemmArgs g = base_args(h->sc16, h->adaln_all, M);
-    g.out_f32 = h->mod;
-    g.ldo = h->Ntot;
-    if ((rc = run_gemm<T, EPI_F32>(g, s))) return rc;
-  }
   // x_embedder + pos_embed; the CFG rows share x, so 60 rows are computed and broadcast
   {
     GemmArgs g = base_args(h->xin16, h->x_embed, ntok);
@@ -260,7 +276,7 @@ int run_eval(float_fmt* h, int bc, int step, bool euler, float dt, float a, floa
     if ((rc = run_gemm<T, EPI_XEMBED>(g, s))) return rc;
   }
   for (int b = 0; b < c.depth; ++b) {
-    const float* mod = h->mod + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    const float* mod = modbuf + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
     if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
     {
@@ -296,7 +312,7 @@ int run_eval(float_fmt* h, int bc, int step, bool euler, float dt, float a, floa
     }
   }
   {
-    const float* mod = h->mod + (size_t)c.depth * 6 * D;  // shift, scale (FMT.py:196)
+    const float* mod = modbuf + (size_t)c.depth * 6 * D;  // shift, scale (FMT.py:196)
     if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
     GemmArgs g = base_args(h->h16, h->final_lin, M);
     g.bc = bc;
@@ -391,15 +407,54 @@ int check_common(float_fmt* h, const void* we, int we_len, const void* prev_we) 
   return FLOAT_OK;
 }
 
-// The Euler chain of one window, eager.
+// The Euler chain of one window, eager and single-stream (also the profiling path).
 template <class T>
 int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
                      hipStream_t s) {
   for (int i = 0; i < nfe - 1; ++i) {
     const float dt = ts[i + 1] - ts[i];
-    int rc = run_eval<T>(h, m.bc, i, true, dt, a, r, e, s);
+    int rc = run_mod<T>(h, m.bc, i, h->mod, s);
     if (rc) return rc;
+    if ((rc = run_blocks<T>(h, m.bc, h->mod, true, dt, a, r, e, s))) return rc;
   }
+  return FLOAT_OK;
+}
+
+// The same chain as it is captured into the hipGraph: the modulation GEMM of step i+1 (HBM-bound,
+// independent of x) runs on a side stream while the latency-bound block chain of step i runs on the
+// main stream; mod is double-buffered.  Every output element is still produced by the same kernel
+// with the same operands, so results are bitwise identical to the eager chain.
+template <class T>
+int capture_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
+                         hipStream_t s, hipStream_t side) {
+  const int S = nfe - 1;
+  if (S <= 0) return FLOAT_OK;
+  int rc;
+  float* modb[2] = {h->mod, h->mod2};
+  std::vector<hipEvent_t>& ev = h->events;
+  while ((int)ev.size() < 2 * S + 2) {
+    hipEvent_t e2;
+    FH_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+    ev.push_back(e2);
+  }
+  hipEvent_t* ev_mod = ev.data();         // ev_mod[i]: modulations of step i ready
+  hipEvent_t* ev_done = ev.data() + S + 1;  // ev_done[i]: block chain of step i finished
+  FH_CHECK_HIP(hipEventRecord(ev_done[S], s));  // fork point
+  FH_CHECK_HIP(hipStreamWaitEvent(side, ev_done[S], 0));
+  if ((rc = run_mod<T>(h, m.bc, 0, modb[0], side))) return rc;
+  FH_CHECK_HIP(hipEventRecord(ev_mod[0], side));
+  for (int i = 0; i < S; ++i) {
+    if (i + 1 < S) {
+      // buffer (i+1)%2 was last read by step i-1
+      if (i >= 1) FH_CHECK_HIP(hipStreamWaitEvent(side, ev_done[i - 1], 0));
+      if ((rc = run_mod<T>(h, m.bc, i + 1, modb[(i + 1) & 1], side))) return rc;
+      FH_CHECK_HIP(hipEventRecord(ev_mod[i + 1], side));
+    }
+    FH_CHECK_HIP(hipStreamWaitEvent(s, ev_mod[i], 0));
+    if ((rc = run_blocks<T>(h, m.bc, modb[i & 1], true, ts[i + 1] - ts[i], a, r, e, s))) return rc;
+    FH_CHECK_HIP(hipEventRecord(ev_done[i], s));
+  }
+  // join: the side stream's last work (ev_mod[S-1]) was already waited on by the main stream
   return FLOAT_OK;
 }
 
@@ -419,9 +474,11 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
   auto it = h->graphs.find(key);
   if (it == h->graphs.end()) {
     if (!h->cap_stream) FH_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    if (!h->side_stream) FH_CHECK_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
     FH_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    int rc = run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream);
+    int rc = h->cfg.use_graph == 2 ? run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream)
+                                   : capture_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream, h->side_stream);
     hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
     if (rc) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -457,52 +514,49 @@ int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const floa
   if (rc) return rc;
   const CfgMode m = cfg_mode(a, r, e, include_r);
   if ((rc = stage_window<T>(h, m, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s))) return rc;
-  if ((rc = run_eval<T>(h, m.bc, 0, false, 0.f, a, r, e, s))) return rc;
+  if ((rc = run_mod<T>(h, m.bc, 0, h->mod, s))) return rc;
+  if ((rc = run_blocks<T>(h, m.bc, h->mod, false, 0.f, a, r, e, s))) return rc;
   FH_CHECK_HIP(hipMemcpyAsync(out, h->vout, (size_t)h->ntok * h->cfg.dim_w * sizeof(float), hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
 }
 
+// One window of the auto-regressive loop (FLOAT.py:214-251; nodes_adv.py:605-688).
 template <class T>
-int sample_impl(float_fmt* h, const float* wr, const float* wa, int Tn, const float* we, int we_len, const float* noise,
-                int nfe, float a, float r, float e, int include_r, float* r_d, hipStream_t s) {
+int sample_window(float_fmt* h, int k, hipStream_t s) {
   const float_fmt_cfg_t& c = h->cfg;
-  const int L = c.n_cur, P = c.n_prev;
-  const bool dynamic = we_len > 1;
-  std::vector<float> ts;
-  linspace01(nfe, &ts);
-  int rc = prepare_time<T>(h, ts, s);
-  if (rc) return rc;
-  const int n_chunks = (Tn + L - 1) / L;
-  // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
-  FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)P * c.dim_w * sizeof(float), s));
-  FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)P * c.dim_a * sizeof(float), s));
-  FH_CHECK_HIP(hipMemsetAsync(h->prev_we, 0, (size_t)P * c.dim_e * sizeof(float), s));
-  for (int k = 0; k < n_chunks; ++k) {
-    if (k > 0) {
-      // AR hand-off: last P frames of the previous final sample / (padded) wa window / we window
-      FH_CHECK_HIP(hipMemcpyAsync(h->prev_x, h->xcur + (size_t)(L - P) * c.dim_w, (size_t)P * c.dim_w * sizeof(float),
-                                  hipMemcpyDeviceToDevice, s));
-      FH_CHECK_HIP(hipMemcpyAsync(h->prev_wa, h->wa_c + (size_t)(L - P) * c.dim_a, (size_t)P * c.dim_a * sizeof(float),
-                                  hipMemcpyDeviceToDevice, s));
-      if (dynamic)
-        FH_CHECK_HIP(hipMemcpyAsync(h->prev_we, h->we_c + (size_t)(L - P) * c.dim_e,
-                                    (size_t)P * c.dim_e * sizeof(float), hipMemcpyDeviceToDevice, s));
-    }
-    hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_a + 255) / 256), dim3(256), 0, s, h->wa_c, wa, k * L, Tn, L,
-                       c.dim_a);
+  auto& J = h->job;
+  const int L = c.n_cur, P = c.n_prev, Tn = J.T;
+  const bool dynamic = J.we_len > 1;
+  int rc;
+  if (k == 0) {
+    if ((rc = prepare_time<T>(h, J.ts, s))) return rc;
+    // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
+    FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)P * c.dim_w * sizeof(float), s));
+    FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)P * c.dim_a * sizeof(float), s));
+    FH_CHECK_HIP(hipMemsetAsync(h->prev_we, 0, (size_t)P * c.dim_e * sizeof(float), s));
+  } else {
+    // AR hand-off: last P frames of the previous final sample / (padded) wa window / we window
+    FH_CHECK_HIP(hipMemcpyAsync(h->prev_x, h->xcur + (size_t)(L - P) * c.dim_w, (size_t)P * c.dim_w * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+    FH_CHECK_HIP(hipMemcpyAsync(h->prev_wa, h->wa_c + (size_t)(L - P) * c.dim_a, (size_t)P * c.dim_a * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
     if (dynamic)
-      hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_e + 255) / 256), dim3(256), 0, s, h->we_c, we, k * L, Tn,
-                         L, c.dim_e);
-    // x0 is copied into the workspace so the window chain only ever sees handle-owned pointers
-    FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, noise + (size_t)k * L * c.dim_w, (size_t)L * c.dim_w * sizeof(float),
-                                hipMemcpyDeviceToDevice, s));
-    rc = window_impl<T>(h, h->x0_c, h->wa_c, wr, dynamic ? h->we_c : we, dynamic ? L : 1, h->prev_x, h->prev_wa,
-                        dynamic ? h->prev_we : nullptr, nfe, ts, a, r, e, include_r, s);
-    if (rc) return rc;
-    const int rows = (k == n_chunks - 1) ? (Tn - k * L) : L;  // trim to T (FLOAT.py:252)
-    FH_CHECK_HIP(hipMemcpyAsync(r_d + (size_t)k * L * c.dim_w, h->xcur, (size_t)rows * c.dim_w * sizeof(float),
-                                hipMemcpyDeviceToDevice, s));
+      FH_CHECK_HIP(hipMemcpyAsync(h->prev_we, h->we_c + (size_t)(L - P) * c.dim_e, (size_t)P * c.dim_e * sizeof(float),
+                                  hipMemcpyDeviceToDevice, s));
   }
+  hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_a + 255) / 256), dim3(256), 0, s, h->wa_c, J.wa, k * L, Tn, L, c.dim_a);
+  if (dynamic)
+    hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_e + 255) / 256), dim3(256), 0, s, h->we_c, J.we, k * L, Tn, L,
+                       c.dim_e);
+  // x0 is copied into the workspace so the window chain only ever sees handle-owned pointers
+  FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, J.noise + (size_t)k * L * c.dim_w, (size_t)L * c.dim_w * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
+  rc = window_impl<T>(h, h->x0_c, h->wa_c, J.wr, dynamic ? h->we_c : J.we, dynamic ? L : 1, h->prev_x, h->prev_wa,
+                      dynamic ? h->prev_we : nullptr, J.nfe, J.ts, J.a, J.r, J.e, J.include_r, s);
+  if (rc) return rc;
+  const int rows = (k == J.n_chunks - 1) ? (Tn - k * L) : L;  // trim to T (FLOAT.py:252)
+  FH_CHECK_HIP(hipMemcpyAsync(J.r_d + (size_t)k * L * c.dim_w, h->xcur, (size_t)rows * c.dim_w * sizeof(float),
+                              hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
 }
 
@@ -590,6 +644,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->th16, (size_t)kMaxSteps * D);
   A(&h->ccond, (size_t)Mp * D);
   A(&h->mod, (size_t)Mp * h->Ntot);
+  A(&h->mod2, (size_t)Mp * h->Ntot);
   A(&h->xres, (size_t)Mp * D);
   A(&h->xcur, (size_t)cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
@@ -635,6 +690,8 @@ void float_fmt_destroy(float_fmt_t* h) {
   if (!h) return;
   for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+  for (hipEvent_t e2 : h->events) (void)hipEventDestroy(e2);
   h->pool.release();
   delete h;
 }
@@ -685,9 +742,9 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
   return FLOAT_OK;
 }
 
-int float_fmt_sample(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we, int32_t we_len,
-                     const float* noise, int32_t nfe, float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg,
-                     float* r_d, void* stream) {
+int float_fmt_sample_begin(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we, int32_t we_len,
+                           const float* noise, int32_t nfe, float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg,
+                           float* r_d) {
   FH_REQUIRE(h != nullptr, "null FMT handle");
   FH_REQUIRE(wr && wa && we && noise && r_d, "null tensor argument to float_fmt_sample");
   FH_REQUIRE(T >= 1, "T must be >= 1 (got %d)", T);
@@ -695,10 +752,52 @@ int float_fmt_sample(float_fmt_t* h, const float* wr, const float* wa, int32_t T
              "Dynamic emotion latent `we` time dimension (%d) does not match audio latent `wa` time dimension (%d).",
              we_len, T);
   FH_REQUIRE(nfe >= 1 && nfe <= kMaxSteps, "nfe=%d out of range [1,%d]", nfe, kMaxSteps);
+  auto& J = h->job;
+  J.wr = wr;
+  J.wa = wa;
+  J.we = we;
+  J.noise = noise;
+  J.r_d = r_d;
+  J.T = T;
+  J.we_len = we_len;
+  J.nfe = nfe;
+  J.include_r = include_r_cfg;
+  J.a = a_cfg;
+  J.r = r_cfg;
+  J.e = e_cfg;
+  J.next = 0;
+  J.n_chunks = (T + h->cfg.n_cur - 1) / h->cfg.n_cur;
+  linspace01(nfe, &J.ts);
+  J.active = true;
+  return FLOAT_OK;
+}
+
+int float_fmt_sample_next(float_fmt_t* h, void* stream, int32_t* window_done, int32_t* windows_left) {
+  FH_REQUIRE(h != nullptr && h->job.active, "float_fmt_sample_next without float_fmt_sample_begin");
+  auto& J = h->job;
   hipStream_t s = (hipStream_t)stream;
-  return h->cfg.dtype == FLOAT_DT_BF16
-             ? sample_impl<BF16>(h, wr, wa, T, we, we_len, noise, nfe, a_cfg, r_cfg, e_cfg, include_r_cfg, r_d, s)
-             : sample_impl<FP16>(h, wr, wa, T, we, we_len, noise, nfe, a_cfg, r_cfg, e_cfg, include_r_cfg, r_d, s);
+  const int k = J.next;
+  int rc = h->cfg.dtype == FLOAT_DT_BF16 ? sample_window<BF16>(h, k, s) : sample_window<FP16>(h, k, s);
+  if (rc) {
+    J.active = false;
+    return rc;
+  }
+  J.next = k + 1;
+  if (window_done) *window_done = k;
+  if (windows_left) *windows_left = J.n_chunks - J.next;
+  if (J.next >= J.n_chunks) J.active = false;
+  return FLOAT_OK;
+}
+
+int float_fmt_sample(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we, int32_t we_len,
+                     const float* noise, int32_t nfe, float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg,
+                     float* r_d, void* stream) {
+  int rc = float_fmt_sample_begin(h, wr, wa, T, we, we_len, noise, nfe, a_cfg, r_cfg, e_cfg, include_r_cfg, r_d);
+  if (rc) return rc;
+  int32_t left = 1;
+  while (left > 0)
+    if ((rc = float_fmt_sample_next(h, stream, nullptr, &left))) return rc;
+  return FLOAT_OK;
 }
 
 }  // extern "C"

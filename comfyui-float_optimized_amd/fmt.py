@@ -14,7 +14,7 @@ class FlowMatchingTransformerHIP:
     """Holds packed weights + workspace on one GPU.  Batch items are looped on the host, like the
     reference's FloatProcess (nodes.py:189-209)."""
 
-    def __init__(self, state_dict, cfg: FmtConfig = None, device="cuda:0", dtype="bf16", use_graph=True):
+    def __init__(self, state_dict, cfg: FmtConfig = None, device="cuda:0", dtype="bf16", use_graph=2):
         self.cfg = cfg or FmtConfig()
         self.device = torch.device(device)
         self.dtype = dtype
@@ -22,7 +22,7 @@ class FlowMatchingTransformerHIP:
         c = self.cfg
         ncfg = native.FmtCfg(c.dim_w, c.dim_a, c.dim_e, c.dim_h, c.fmt_depth, c.num_heads,
                              int(c.dim_h * c.mlp_ratio), c.num_prev_frames, c.num_frames_for_clip,
-                             c.attention_window, native.DTYPES[dtype], 1 if use_graph else 0)
+                             c.attention_window, native.DTYPES[dtype], int(use_graph))
         sd = {k[4:] if k.startswith("fmt.") else k: v for k, v in state_dict.items()
               if k not in ("alignment_mask", "fmt.alignment_mask")}
         arr, keep = native.tensor_table(sd)
@@ -132,6 +132,38 @@ class FlowMatchingTransformerHIP:
                     native.dev_ptr(nb), int(nfe), a_cfg_scale, r_cfg_scale, e_cfg_scale, 1 if include_r_cfg else 0,
                     native.dev_ptr(r_d[b]), s))
         return r_d
+
+
+class WindowSampler:
+    """Incremental form of FlowMatchingTransformerHIP.sample for ONE clip (B = 1): each next() enqueues
+    one 50-frame window on the current stream, so the caller can decode window k on another stream
+    while window k+1 is being sampled."""
+
+    def __init__(self, fmt, r_s, wa, we, noise, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg=False):
+        self.fmt = fmt
+        c = fmt.cfg
+        f = fmt._f
+        self.r_s, self.wa, self.we = f(r_s).reshape(-1), f(wa).reshape(-1, c.dim_a), f(we).reshape(-1, c.dim_e)
+        self.T = self.wa.shape[0]
+        self.n_chunks = int(math.ceil(self.T / c.num_frames_for_clip))
+        self.noise = f(noise).reshape(self.n_chunks, c.num_frames_for_clip, c.dim_w)
+        self.r_d = torch.empty(1, self.T, c.dim_w, device=fmt.device, dtype=torch.float32)
+        self.left = self.n_chunks
+        with torch.cuda.device(fmt.device):
+            native.check(native.lib().float_fmt_sample_begin(
+                fmt._h, native.dev_ptr(self.r_s), native.dev_ptr(self.wa), self.T, native.dev_ptr(self.we),
+                self.we.shape[0], native.dev_ptr(self.noise), int(nfe), a_cfg_scale, r_cfg_scale, e_cfg_scale,
+                1 if include_r_cfg else 0, native.dev_ptr(self.r_d)))
+
+    def next(self):
+        """Enqueue the next window on the current stream; returns (window index, frame range)."""
+        k, left = C.c_int32(0), C.c_int32(0)
+        with torch.cuda.device(self.fmt.device):
+            native.check(native.lib().float_fmt_sample_next(self.fmt._h, native.stream_ptr(self.fmt.device),
+                                                            C.byref(k), C.byref(left)))
+        self.left = left.value
+        L = self.fmt.cfg.num_frames_for_clip
+        return k.value, (k.value * L, min(self.T, (k.value + 1) * L))
 
 
 def draw_noise(n_chunks, batch, cfg, seed, device="cpu"):

@@ -44,6 +44,9 @@ _SIGNATURES = {
                                [C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "float_fmt_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "float_fmt_sample_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                         C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p]),
+    "float_fmt_sample_next": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "float_dec_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_dec_destroy": (None, [C.c_void_p]),
     "float_dec_set_feats": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),

@@ -62,7 +62,8 @@ typedef struct {
   int32_t n_prev, n_cur;   /* num_prev_frames, int(wav2vec_sec*fps) */
   int32_t attn_window;     /* |i-j| <= window is visible (FMT.py:15-19) */
   int32_t dtype;           /* FLOAT_DT_* */
-  int32_t use_graph;       /* 1: replay the per-chunk kernel chain from a cached hipGraph */
+  int32_t use_graph;       /* 0: eager launches; 1: replay each window's chain from a cached hipGraph with
+                              the adaLN GEMM of step i+1 on a parallel branch; 2: graph, single branch */
 } float_fmt_cfg_t;
 
 typedef struct float_fmt float_fmt_t;
@@ -96,6 +97,15 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
 int float_fmt_sample(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we,
                      int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg,
                      float e_cfg, int32_t include_r_cfg, float* r_d, void* stream);
+
+/* The same loop one window at a time, so the caller can overlap the decode of window k (on another
+ * stream) with the sampling of window k+1: _begin only records the job (pointers must stay valid
+ * until the last _next), each _next enqueues ONE window on `stream` and reports its index and how
+ * many remain.  r_d rows [k*n_cur, min(T,(k+1)*n_cur)) are complete once that stream work is done. */
+int float_fmt_sample_begin(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we,
+                           int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg,
+                           float e_cfg, int32_t include_r_cfg, float* r_d);
+int float_fmt_sample_next(float_fmt_t* h, void* stream, int32_t* window_done, int32_t* windows_left);
 
 /* ---------------------------------------------------------------- decoder --------- */
 typedef struct {

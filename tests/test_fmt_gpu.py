@@ -16,7 +16,7 @@ TOL = {"bf16": 2e-2, "fp16": 4e-3}
 
 def _fmt(cfg, seed, dtype, use_graph=True):
     sd = W.synth_fmt_state(cfg, seed)
-    return sd, pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", dtype=dtype, use_graph=use_graph)
+    return sd, pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", dtype=dtype, use_graph=2 if use_graph is True else int(use_graph))
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])

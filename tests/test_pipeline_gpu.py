@@ -1,0 +1,51 @@
+"""GPU checks of the whole hot path object: stage overlap on two streams and frame sharding give
+exactly the frames of the sequential single-stream order (size-independent properties), and the
+end-to-end result stays within the stated tolerance of the CPU oracle on a short clip."""
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import load_pkg
+
+pkg = load_pkg()
+pytestmark = pytest.mark.gpu
+
+
+def _hot_path(size=64, max_frames=8, graph=True):
+    cfg = pkg.config.FmtConfig()
+    fmt_sd = pkg.weights.synth_fmt_state(cfg, seed=21)
+    dec_sd = pkg.weights.synth_decoder_state(size, seed=21)
+    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, "cuda:0", size, "bf16", "fp16", max_frames, use_graph=graph)
+    feats = pkg.weights.synth_feats(size, seed=21)
+    return cfg, fmt_sd, dec_sd, hp, feats
+
+
+def test_overlap_and_shard_are_bitwise_sequential():
+    cfg, _, _, hp, feats = _hot_path()
+    T = 130  # 3 windows, the last one replicate-padded
+    cond = pkg.pipeline.synth_conditions(cfg, T, seed=3)
+    noise = pkg.fmt.draw_noise(hp.n_chunks(T), 1, cfg, seed=15)
+    args = (cond["r_s"], cond["wa"], cond["we"], cond["s_r"], feats, 6)
+    seq, rd_seq = hp.generate(*args, noise=noise, overlap=False, return_rd=True)
+    ovl, rd_ovl = hp.generate(*args, noise=noise, overlap=True, return_rd=True)
+    torch.cuda.synchronize()
+    assert torch.equal(rd_seq, rd_ovl)
+    assert torch.equal(seq, ovl)
+    shard = hp.generate(*args, noise=noise, overlap=True, frame_range=(40, 110))
+    torch.cuda.synchronize()
+    assert torch.equal(shard, seq[40:110])
+
+
+def test_end_to_end_vs_oracle_short_clip():
+    cfg, fmt_sd, dec_sd, hp, feats = _hot_path()
+    T = 30
+    cond = pkg.pipeline.synth_conditions(cfg, T, seed=5)
+    noise = pkg.fmt.draw_noise(1, 1, cfg, seed=15)
+    frames, r_d = hp.generate(cond["r_s"], cond["wa"], cond["we"], cond["s_r"], feats, 11, noise=noise, return_rd=True)
+    ref_rd = O.sample_rd(fmt_sd, cfg, cond["r_s"], cond["wa"], cond["we"], noise, 11, 2.0, 1.0, 1.0)
+    ref = O.decode_frames(dec_sd, cond["s_r"], ref_rd, feats)
+    e_rd = float((r_d.cpu() - ref_rd).norm() / ref_rd.norm())
+    mse = float(((frames.cpu() - ref) ** 2).mean())
+    print("e2e: r_d rel-L2 %.3e, frames mean|d| %.3e, PSNR %.1f dB" % (
+        e_rd, float((frames.cpu() - ref).abs().mean()), -10 * torch.log10(torch.tensor(mse))))
+    assert e_rd < 2e-2 and mse < 1e-4  # PSNR >= 40 dB
