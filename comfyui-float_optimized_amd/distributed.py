@@ -1,0 +1,126 @@
+"""Multi-GPU use of the hot path: one process per GPU, torch.distributed (backend "nccl" = RCCL over
+xGMI on MI355X; "gloo" in the CPU tests).  Nothing here is in the reference (it has no distributed
+code); SURVEY.md section 8e defines the three modes.
+
+  replicas         independent clips, one per rank - no communication (BASELINE configs[3]).
+  frame shard      ONE long clip, exact: the latent chain is sequential (window k needs the last 10
+                   sampled frames of window k-1, FLOAT.py:217-222), so every rank runs the identical,
+                   bitwise-deterministic chain (or rank 0 runs it and broadcasts r_d: T*512*4 bytes,
+                   3 MB for 60 s) and decodes only its contiguous frame range.  Frames never cross
+                   xGMI - each rank copies its own shard to the host.
+  window parallel  ONE long clip, approximate (the north-star wording): rank w owns a contiguous
+                   range of 50-frame windows and first samples them from zero history, like window 0;
+                   one all_gather of the boundary latents (last 10 frames of x, wa, we: ~41 KB per
+                   rank, latency-bound on xGMI) gives every rank its predecessor's tail, and the rank
+                   re-solves its windows from that history.  `iters` such rounds make ranks 0..iters
+                   exact (world-1 rounds reproduce the sequential chain bit for bit); the residual
+                   seam error is reported, never hidden.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def frame_shard(T, world, rank):
+    """Contiguous balanced frame range of `rank`."""
+    base, rem = divmod(T, world)
+    t0 = rank * base + min(rank, rem)
+    return t0, t0 + base + (1 if rank < rem else 0)
+
+
+def window_shard(n_windows, world, rank):
+    return frame_shard(n_windows, world, rank)
+
+
+def _pad_rep(a, n):
+    if a.shape[1] >= n:
+        return a
+    return torch.cat([a, a[:, -1:].expand(-1, n - a.shape[1], -1)], dim=1)
+
+
+def sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, hist=None):
+    """The AR window loop (FLOAT.py:209-253) over windows [w0, w1) starting from `hist`
+    (prev_x, prev_wa, prev_we) - zeros when None, as for window 0.  `fmt` needs
+    sample_chunk(x0, wa, wr, we, prev_x, prev_wa, prev_we, nfe=, a_cfg_scale=, r_cfg_scale=, e_cfg_scale=).
+    Returns (samples (B,(w1-w0)*L,dim_w), tail = (prev_x, prev_wa, prev_we) after the last window)."""
+    L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
+    B = wa.shape[0]
+    dev, dt = wa.device, wa.dtype
+    dynamic = we.shape[1] > 1
+    if hist is None:
+        hist = (torch.zeros(B, P, cfg.dim_w, device=dev, dtype=dt), torch.zeros(B, P, cfg.dim_a, device=dev, dtype=dt),
+                torch.zeros(B, P, cfg.dim_e, device=dev, dtype=dt))
+    prev_x, prev_wa, prev_we = hist
+    out = []
+    for k in range(w0, w1):
+        wa_c = _pad_rep(wa[:, k * L:(k + 1) * L], L)
+        we_c = _pad_rep(we[:, k * L:(k + 1) * L], L) if dynamic else we
+        xs = fmt.sample_chunk(noise[k], wa_c, r_s, we_c, prev_x, prev_wa, prev_we if dynamic else None, nfe=nfe,
+                              a_cfg_scale=a_cfg, r_cfg_scale=r_cfg, e_cfg_scale=e_cfg)
+        xs = xs.to(dev, dt)
+        out.append(xs)
+        prev_x, prev_wa = xs[:, -P:], wa_c[:, -P:]
+        if dynamic:
+            prev_we = we_c[:, -P:]
+    return torch.cat(out, dim=1), (prev_x, prev_wa, prev_we)
+
+
+def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1.0, e_cfg=1.0, iters=1, group=None):
+    """Window-parallel sampling of one clip.  Every rank passes the FULL wa/we/noise (they are tiny);
+    returns (r_d_local, (t0, t1), report) where r_d_local are the rank's frames of r_d and report has
+    the seam error of the last round: rel-L2 change of the rank's latents caused by that exchange
+    (0 once the rank's history has converged to the sequential chain's)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
+    T = wa.shape[1]
+    n_win = int(math.ceil(T / L))
+    w0, w1 = window_shard(n_win, world, rank)
+    xs, tail = sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, None)
+    seam = 0.0
+    for _ in range(iters if world > 1 else 0):
+        # boundary latents of every rank: [x tail | wa tail | we tail] flattened, one all_gather
+        mine = torch.cat([t.reshape(t.shape[0], -1) for t in tail], dim=1).contiguous()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+        if rank > 0 and w1 > w0:
+            g = gathered[rank - 1]
+            B = g.shape[0]
+            nx, na = P * cfg.dim_w, P * cfg.dim_a
+            hist = (g[:, :nx].reshape(B, P, cfg.dim_w), g[:, nx:nx + na].reshape(B, P, cfg.dim_a),
+                    g[:, nx + na:].reshape(B, P, cfg.dim_e))
+            new_xs, new_tail = sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, hist)
+            seam = float((new_xs - xs).norm() / (new_xs.norm() + 1e-30))
+            xs, tail = new_xs, new_tail
+    t0, t1 = w0 * L, min(T, w1 * L)
+    return xs[:, :t1 - t0], (t0, t1), {"seam_rel_change": seam, "windows": (w0, w1), "rounds": iters}
+
+
+def broadcast_latents(r_d, src=0, group=None):
+    """Exact mode, variant 2: rank `src` sampled the chain, everybody else receives r_d (B,T,512)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(r_d, src=src, group=group)
+    return r_d
+
+
+def generate_frame_sharded(hot_path, r_s, wa, we, s_r, feats, nfe, a_cfg=2.0, r_cfg=1.0, e_cfg=1.0, noise=None, seed=15,
+                           chain="replicate", group=None):
+    """Exact multi-GPU rendering of one clip: returns (frames of this rank's range, (t0, t1)).
+    chain="replicate": every rank runs the deterministic latent chain itself (zero communication);
+    chain="broadcast": rank 0 runs it, one broadcast of r_d."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    T = wa.shape[1]
+    t0, t1 = frame_shard(T, world, rank)
+    if chain == "replicate" or world == 1:
+        frames = hot_path.generate(r_s, wa, we, s_r, feats, nfe, a_cfg, r_cfg, e_cfg, seed=seed, noise=noise, frame_range=(t0, t1))
+        return frames, (t0, t1)
+    if chain != "broadcast":
+        raise ValueError("chain must be 'replicate' or 'broadcast'")
+    if rank == 0:
+        r_d = hot_path.sample(r_s, wa, we, nfe, a_cfg, r_cfg, e_cfg, seed=seed, noise=noise)
+    else:
+        r_d = torch.empty(wa.shape[0], T, hot_path.cfg.dim_w, device=hot_path.device, dtype=torch.float32)
+    broadcast_latents(r_d, 0, group)
+    return hot_path.decode(s_r, feats, r_d, (t0, t1)), (t0, t1)

@@ -1,0 +1,116 @@
+"""InferenceAgent of the MI355X build (reference generate.py:84-173): owns the weights, the host-side
+conditioning encoders and the HIP hot path, and exposes run_inference with the reference signature."""
+import math
+import os
+
+import torch
+
+from ... import host_models, weights
+from ...config import FmtConfig
+from ...fmt import draw_noise
+from ...pipeline import FloatHotPath
+from . import SYNTHETIC_MODEL, main_logger
+
+# key prefixes of the unified checkpoint (utils/downloader.py:35-42)
+PREFIXES = {
+    "enc": "motion_autoencoder.enc.",
+    "dec": "motion_autoencoder.dec.",
+    "proj": "audio_encoder.audio_projection.",
+    "fmt": "fmt.",
+    "wav2vec": "audio_encoder.wav2vec2.",
+    "ser": "emotion_encoder.wav2vec2_for_emotion.",
+}
+
+
+def split_unified(state):
+    """FLOAT.state_dict() -> per-part dicts with the prefixes stripped."""
+    parts = {k: {} for k in PREFIXES}
+    for key, v in state.items():
+        for part, pre in PREFIXES.items():
+            if key.startswith(pre):
+                parts[part][key[len(pre):]] = v
+                break
+    return parts
+
+
+class InferenceAgent:
+    def __init__(self, opt, parts=None, device=None):
+        self.opt = opt
+        self.rank = torch.device(device if device is not None else getattr(opt, "rank", "cuda:0"))
+        self.cfg = FmtConfig.from_options(opt)
+        if parts is None:
+            parts = self._load_parts(opt)
+        self.enc_sd, self.dec_sd = parts["enc"], parts["dec"]
+        self.G = FloatHotPath(parts["fmt"], parts["dec"], self.cfg, self.rank, opt.input_size)
+        self.direction_q = host_models.direction_basis(parts["dec"], self.rank)
+        self.audio_encoder = parts["audio_encoder"].to(self.rank)
+        self.emotion_predictor = parts.get("emotion_predictor")  # callable(a) -> (1,7) scores, optional
+
+    # ------------------------------------------------------------------ weights
+    @staticmethod
+    def _load_parts(opt):
+        path = getattr(opt, "ckpt_path", None)
+        if path is None or os.path.basename(path) == SYNTHETIC_MODEL or os.environ.get("FLOAT_AMD_SYNTHETIC") == "1":
+            return InferenceAgent.synthetic_parts(opt)
+        if not os.path.exists(path):
+            raise FileNotFoundError("Checkpoint file not found: %s" % path)
+        from safetensors.torch import load_file
+        parts = split_unified(load_file(path, device="cpu"))
+        enc = host_models.AudioEncoderHost(dim_w=opt.dim_w, only_last_features=opt.only_last_features)
+        missing = enc.wav2vec2.load_state_dict(parts["wav2vec"], strict=False)
+        if missing.missing_keys:
+            main_logger.warning("wav2vec2 keys missing from checkpoint: %s", missing.missing_keys[:5])
+        enc.audio_projection.load_state_dict(parts["proj"], strict=True)
+        parts["audio_encoder"] = enc
+        return parts
+
+    @staticmethod
+    def synthetic_parts(opt, seed=0):
+        """Seeded random weights in the checkpoint layout (no network / no checkpoint available)."""
+        from transformers import Wav2Vec2Config
+        cfg = FmtConfig.from_options(opt)
+        torch.manual_seed(seed)
+        small = Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
+                               conv_dim=(32, 32, 32, 32, 32, 32, 32), num_conv_pos_embeddings=16,
+                               num_conv_pos_embedding_groups=4)
+        return dict(enc=weights.synth_encoder_state(opt.input_size, seed=seed), dec=weights.synth_decoder_state(opt.input_size, seed=seed),
+                    fmt=weights.synth_fmt_state(cfg, seed=seed),
+                    audio_encoder=host_models.AudioEncoderHost(small, dim_w=opt.dim_w))
+
+    # ------------------------------------------------------------------ inference
+    @torch.no_grad()
+    def conditions(self, ref_img, ref_audio, emo=None):
+        """Host-side stage: image -> (s_r, feats, r_s); audio -> (wa, T); emotion -> we."""
+        o = self.opt
+        s = host_models.preprocess_image(ref_img[0] if ref_img.dim() == 4 else ref_img, o.input_size).to(self.rank)
+        a = host_models.preprocess_audio(ref_audio["waveform"][0], ref_audio["sample_rate"], o.sampling_rate).to(self.rank)
+        s_r, feats, lam = host_models.encode_appearance(self.enc_sd, s)
+        r_s = host_models.direction(self.direction_q, lam)
+        T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
+        wa = self.audio_encoder.inference(a, seq_len=T, sampling_rate=o.sampling_rate, fps=o.fps)
+        if emo is None or str(emo).lower() == "none":
+            if self.emotion_predictor is None:
+                raise NotImplementedError(
+                    "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198); that encoder is "
+                    "outside this build (SURVEY.md 8f) - pick an emotion or attach agent.emotion_predictor")
+            we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
+        else:
+            we = host_models.emotion_one_hot(emo, self.rank)
+        return dict(s_r=s_r, feats=feats, r_s=r_s, wa=wa, we=we, T=T)
+
+    @torch.no_grad()
+    def run_inference(self, res_video_path, ref_img, ref_audio, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0,
+                      emo="S2E", nfe=10, no_crop=False, seed=25):
+        """Reference signature (generate.py:154-173).  Returns (T,H,W,3) fp32 in [0,1] on the CPU.
+        Like the reference, the grid size comes from opt.nfe, not from the `nfe` argument (FLOAT.py:188)."""
+        if not no_crop:
+            raise NotImplementedError("face_align=True needs the face_alignment detector, which is not part of this "
+                                      "build; pass a cropped square portrait and face_align=False")
+        c = self.conditions(ref_img, ref_audio, emo)
+        n_chunks = int(math.ceil(c["T"] / self.cfg.num_frames_for_clip))
+        noise = draw_noise(n_chunks, 1, self.cfg, seed if seed is not None else self.opt.seed)
+        frames = self.G.generate(c["r_s"], c["wa"], c["we"], c["s_r"], c["feats"], self.opt.nfe, a_cfg_scale, r_cfg_scale,
+                                 e_cfg_scale, noise=noise)
+        host = torch.empty(frames.shape, dtype=torch.float32, pin_memory=frames.is_cuda)
+        host.copy_(frames)  # one D2H for the clip instead of one per frame (FLOAT.py:153,166)
+        return host

@@ -145,3 +145,41 @@ def synth_feats(size=512, seed=0, smooth=8, hi=0.02):
         feats.append(f.contiguous())
         r *= 2
     return feats
+
+
+ENC_CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
+
+
+def synth_encoder_state(size=512, dim=512, dim_motion=20, seed=0):
+    """Appearance/motion encoder weights in the reference layout (`motion_autoencoder.enc.` prefix
+    stripped; encoder.py:203-247).  Equalised-lr layers: N(0,1) weights."""
+    sd = {}
+    blur = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k2 = blur[None, :] * blur[:, None]
+    k2 = k2 / k2.sum()
+    p = "net_app.convs."
+    c = ENC_CHANNELS[size]
+    sd[p + "0.0.weight"] = _randn(seed, p + "0.0.weight", (c, 3, 1, 1))
+    sd[p + "0.1.bias"] = _randn(seed, p + "0.1.bias", (1, c, 1, 1), 0.1)
+    i = 1
+    r = size
+    while r > 4:
+        co = ENC_CHANNELS[r // 2]
+        q = p + "%d." % i
+        sd[q + "conv1.0.weight"] = _randn(seed, q + "conv1.0.weight", (c, c, 3, 3))
+        sd[q + "conv1.1.bias"] = _randn(seed, q + "conv1.1.bias", (1, c, 1, 1), 0.1)
+        sd[q + "conv2.0.kernel"] = k2.clone()
+        sd[q + "conv2.1.weight"] = _randn(seed, q + "conv2.1.weight", (co, c, 3, 3))
+        sd[q + "conv2.2.bias"] = _randn(seed, q + "conv2.2.bias", (1, co, 1, 1), 0.1)
+        sd[q + "skip.0.kernel"] = k2.clone()
+        sd[q + "skip.1.weight"] = _randn(seed, q + "skip.1.weight", (co, c, 1, 1))
+        c = co
+        r //= 2
+        i += 1
+    sd[p + "%d.weight" % i] = _randn(seed, p + "%d.weight" % i, (dim, c, 4, 4))
+    for j in range(4):
+        sd["fc.%d.weight" % j] = _randn(seed, "fc.%d.weight" % j, (dim, dim))
+        sd["fc.%d.bias" % j] = _randn(seed, "fc.%d.bias" % j, (dim,), 0.1)
+    sd["fc.4.weight"] = _randn(seed, "fc.4.weight", (dim_motion, dim))
+    sd["fc.4.bias"] = _randn(seed, "fc.4.bias", (dim_motion,), 0.1)
+    return sd

@@ -255,8 +255,67 @@ def gen_dec(ns, size, seed, n_frames, sparse):
     save("dec_%d" % size, **arrs)
 
 
+def gen_node_surface(ns):
+    """Widget/return contracts of the three north-star nodes and the batch/seed schedule of
+    FloatProcess.floatprocess (nodes.py:189-222), captured from the reference classes themselves."""
+    import contextlib
+    import json
+    print("[node surface]")
+    import sys as _sys
+    st = _sys.modules["seconohe.torch"]
+    st.model_to_target = lambda logger, model: contextlib.nullcontext()
+    import importlib
+    nodes = importlib.import_module("floatref.src.nodes.nodes")
+    adv = ns.nodes_adv
+
+    def contract(cls):
+        it = cls.INPUT_TYPES()
+        return dict(INPUT_TYPES=it, RETURN_TYPES=list(cls.RETURN_TYPES), RETURN_NAMES=list(cls.RETURN_NAMES),
+                    FUNCTION=cls.FUNCTION, CATEGORY=cls.CATEGORY, UNIQUE_NAME=cls.UNIQUE_NAME, DISPLAY_NAME=cls.DISPLAY_NAME)
+
+    calls = []
+
+    class FakePipe:
+        rank = "cpu"
+
+        class opt:
+            cudnn_benchmark_enabled = False
+            r_cfg_scale = 1.0
+            fps = 25.0
+
+        class G:
+            pass
+
+        def run_inference(self, path, img, audio, **kw):
+            calls.append(dict(image_mark=float(img[0, 0, 0, 0]), audio_mark=float(audio["waveform"][0, 0, 0]),
+                              seed=kw["seed"], emo=kw["emo"], no_crop=kw["no_crop"], a=kw["a_cfg_scale"], e=kw["e_cfg_scale"],
+                              r=kw["r_cfg_scale"]))
+            return torch.full((2, 4, 4, 3), float(len(calls)))
+
+    img = torch.zeros(2, 4, 4, 3)
+    img[0] += 10
+    img[1] += 11
+    wav = torch.zeros(3, 1, 8)
+    wav[0] += 20
+    wav[1] += 21
+    wav[2] += 22
+    out = nodes.FloatProcess().floatprocess(img, {"waveform": wav, "sample_rate": 16000}, FakePipe(), 2.0, 1.0, 30.0, "happy",
+                                            False, 1000)
+    sched = dict(calls=calls, images_shape=list(out[0].shape), images_first=[float(out[0][i, 0, 0, 0]) for i in range(out[0].shape[0])],
+                 audio_shape=list(out[1]["waveform"].shape), audio_values=out[1]["waveform"][0, 0].tolist(), fps=out[2])
+    fixture = dict(LoadFloatModelsOpt=contract(nodes.LoadFloatModels), FloatProcessOpt=contract(nodes.FloatProcess),
+                   FloatAdvancedParameters=contract(adv.FloatAdvancedParameters), schedule=sched,
+                   base_options={k: v for k, v in vars(ns.base_options.BaseOptions()).items()})
+    with open(os.path.join(GOLD, "node_surface.json"), "w") as f:
+        json.dump(fixture, f, indent=1, default=str)
+    print("  wrote node_surface.json")
+
+
 def main():
     ns = ref_import.load()
+    gen_node_surface(ns)
+    if os.environ.get("GOLDENS_ONLY") == "nodes":
+        return
     small = config.small_fmt_config()
     full = config.FmtConfig()
     gen_fmt_eval(ns, small, "small", seed=100)
