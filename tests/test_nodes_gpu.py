@@ -1,0 +1,58 @@
+"""The three north-star nodes end to end on the GPU with seeded synthetic weights (no checkpoint is
+reachable offline): shapes/ranges of the IMAGE output, seed semantics, error behaviour."""
+import pytest
+import torch
+
+from tests.util import load_pkg
+
+pkg = load_pkg()
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipe():
+    import importlib
+    nodes = pkg.NODE_CLASS_MAPPINGS
+    adv = nodes["FloatAdvancedParameters"]().get_options(1.0, 2, 0.1, 0.1, 0.1, 1e-5, 1e-5, 5, "euler", 1.6,
+                                                         "blend_with_color", "#000000")[0]
+    synth = importlib.import_module(pkg.__name__ + ".src.nodes").SYNTHETIC_MODEL
+    return nodes["LoadFloatModelsOpt"]().loadmodel(synth, "cuda:0", False, adv)[0]
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(1, 512, 512, 3, generator=g)
+    n = 16000
+    t = torch.arange(n) / 16000.0
+    wav = (0.1 * torch.randn(n, generator=g) + 0.3 * torch.sin(2 * torch.pi * 220 * t))[None, None]
+    return img, {"waveform": wav, "sample_rate": 16000}
+
+
+def test_float_process_end_to_end(pipe):
+    img, audio = _inputs()
+    node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    images, out_audio, fps = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    assert images.shape == (25, 512, 512, 3) and images.dtype == torch.float32 and images.device.type == "cpu"
+    assert float(images.min()) >= 0.0 and float(images.max()) <= 1.0 and torch.isfinite(images).all()
+    assert out_audio is audio and fps == 25.0
+    again, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    # same seed -> same frames up to the host-side PyTorch encoders' run-to-run noise (MIOpen/rocBLAS are not
+    # bitwise reproducible; the HIP operators are - tests/test_fmt_gpu.py, test_pipeline_gpu.py)
+    same = float((images - again).abs().mean())
+    other, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 8)
+    diff = float((images - other).abs().mean())
+    print("same-seed mean|d| %.2e, other-seed mean|d| %.2e" % (same, diff))
+    assert same < 1e-3 and diff > 20 * max(same, 1e-5)     # the seed feeds the noise stream (FLOAT.py:203-215)
+    assert float(images.std()) > 0.01
+
+
+def test_float_process_errors(pipe):
+    img, audio = _inputs()
+    node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    with pytest.raises(NotImplementedError):
+        node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "none", False, 7)   # needs the SER encoder
+    with pytest.raises(NotImplementedError):
+        node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", True, 7)   # needs the face detector
+    with pytest.raises(ValueError):
+        pkg.NODE_CLASS_MAPPINGS["LoadFloatModelsOpt"]().loadmodel("x.safetensors", "cuda:0", False,
+                                                                  {"torchdiffeq_ode_method": "rk4"})
