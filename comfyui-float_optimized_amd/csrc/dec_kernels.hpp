@@ -146,6 +146,8 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
 
   // global element offsets of this thread's halo chunks (constant over the channel loop)
   int aoff[MAXA];
+  const int fpix = g.hh * g.hw;
+  const float inv_fpix = 1.0f / (float)fpix, inv_hw = 1.0f / (float)g.hw;
   const int iy0 = ty * th + g.dymin, ix0 = tx * tw + g.dxmin;
 #pragma unroll
   for (int i = 0; i < MAXA; ++i) {
@@ -153,9 +155,10 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
     const int p = e >> 2, ch = e & 3;
     aoff[i] = -1;
     if (p < npix) {
-      const int fl = p / (g.hh * g.hw);
-      const int rem = p - fl * g.hh * g.hw;
-      const int hy = rem / g.hw, hx = rem - hy * g.hw;
+      // small-integer division by multiplication with the fp32 reciprocal (exact for p < 2^12)
+      const int fl = (int)(((float)p + 0.5f) * inv_fpix);
+      const int rem = p - fl * fpix;
+      const int hy = (int)(((float)rem + 0.5f) * inv_hw), hx = rem - hy * g.hw;
       const int f = fb * nf + fl, iy = iy0 + hy, ix = ix0 + hx;
       if (f < g.F && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi) aoff[i] = ((f * g.Hi + iy) * g.Wi + ix) * g.Cin + ch * 8;
       else aoff[i] = -2;  // in-tile, zero padding
@@ -202,31 +205,54 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + (size_t)((t * BN + j * 16 + r16) * 64 + q * 16));
 #pragma unroll
+      // operands swapped on purpose: D = W_tile (16 channels x K) * X_tile^T (K x 16 pixels), so a lane
+      // ends up with 4 CONSECUTIVE CHANNELS of one pixel (row = q*4 + reg -> channel, col = r16 -> pixel)
+      // and the epilogue stores 8 contiguous bytes per tile instead of four scattered 2-byte values
       for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(a[mt], b[j], acc[mt][j]);
+        for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[j], a[mt], acc[mt][j]);
     }
   }
 
-  // epilogue: C/D map row = q*4 + r (pixel), col = r16 (channel)
+  // epilogue: lane -> pixel m = tile row r16, channels n0 + j*16 + q*4 .. +3
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
+    const int m = (w * 4 + mt) * 16 + r16;
+    const int x = m & (tw - 1), y = (m >> g.ltw) & (th - 1), fl = m >> (g.ltw + g.lth);
+    const int f = fb * nf + fl, oy = ty * th + y, ox = tx * tw + x;
+    if (f >= g.F || oy >= g.Ho || ox >= g.Wo) continue;
+    u16* yp = g.Y + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int m = (w * 4 + mt) * 16 + q * 4 + r;
-      const int x = m & (tw - 1), y = (m >> g.ltw) & (th - 1), fl = m >> (g.ltw + g.lth);
-      const int f = fb * nf + fl, oy = ty * th + y, ox = tx * tw + x;
-      if (f >= g.F || oy >= g.Ho || ox >= g.Wo) continue;
-      u16* yp = g.Y + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int co = n0 + j * 16 + r16;
-        float v = acc[mt][j][r];
-        if (g.demod) v *= g.demod[(size_t)f * g.ldd + co];
-        if (g.act) v = fh_lrelu_s2(v + g.bias[co]);
-        if (g.snext) v *= g.snext[(size_t)f * g.lds + co];
-        yp[co] = T::from_float(v);
+    for (int j = 0; j < NT; ++j) {
+      const int co = n0 + j * 16 + q * 4;
+      float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
+      if (g.demod) {
+        const float4 d = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + co);
+        v[0] *= d.x;
+        v[1] *= d.y;
+        v[2] *= d.z;
+        v[3] *= d.w;
       }
+      if (g.act) {
+        const float4 bb = *reinterpret_cast<const float4*>(g.bias + co);
+        v[0] = fh_lrelu_s2(v[0] + bb.x);
+        v[1] = fh_lrelu_s2(v[1] + bb.y);
+        v[2] = fh_lrelu_s2(v[2] + bb.z);
+        v[3] = fh_lrelu_s2(v[3] + bb.w);
+      }
+      if (g.snext) {
+        const float4 sn = *reinterpret_cast<const float4*>(g.snext + (size_t)f * g.lds + co);
+        v[0] *= sn.x;
+        v[1] *= sn.y;
+        v[2] *= sn.z;
+        v[3] *= sn.w;
+      }
+      ushort4 o;
+      o.x = T::from_float(v[0]);
+      o.y = T::from_float(v[1]);
+      o.z = T::from_float(v[2]);
+      o.w = T::from_float(v[3]);
+      *reinterpret_cast<ushort4*>(yp + co) = o;
     }
   }
 }

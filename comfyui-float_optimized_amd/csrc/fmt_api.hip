@@ -125,8 +125,8 @@ int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
 // epilogue and 4/8/16 K-splitting waves; full-height tilings (4 waves, LDS bound) only the two
 // epilogues that need them: EPI_CFG (all CFG rows of a token in one workgroup) and EPI_F32.
 #define FMT_SPLIT_SHAPES(X, NW, EPI) \
-  X(3, 1, NW, EPI) X(3, 2, NW, EPI) X(5, 1, NW, EPI) X(5, 2, NW, EPI) X(4, 1, NW, EPI) X(4, 2, NW, EPI) X(6, 2, NW, EPI) \
-  X(2, 1, NW, EPI) X(1, 1, NW, EPI)
+  X(3, 1, NW, EPI) X(3, 2, NW, EPI) X(3, 4, NW, EPI) X(5, 1, NW, EPI) X(5, 2, NW, EPI) X(5, 4, NW, EPI) X(4, 1, NW, EPI) \
+  X(4, 2, NW, EPI) X(6, 2, NW, EPI) X(2, 1, NW, EPI) X(1, 1, NW, EPI)
 #define FMT_FOR_SPLIT(X, EPI) FMT_SPLIT_SHAPES(X, 4, EPI) FMT_SPLIT_SHAPES(X, 8, EPI) FMT_SPLIT_SHAPES(X, 16, EPI)
 #define FMT_FOR_FULL(X, EPI) X(12, 2, 4, EPI) X(15, 2, 4, EPI)
 
@@ -151,7 +151,7 @@ template <class T, int EPI>
 void prime_epi() {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
-  static const int shapes[][2] = {{3, 1}, {3, 2}, {5, 1}, {5, 2}, {4, 1}, {4, 2}, {6, 2}, {2, 1}, {1, 1}};
+  static const int shapes[][2] = {{3, 1}, {3, 2}, {3, 4}, {5, 1}, {5, 2}, {5, 4}, {4, 1}, {4, 2}, {6, 2}, {2, 1}, {1, 1}};
   for (auto& c : shapes)
     for (int nw : {4, 8, 16}) (void)launch_gemm<T, EPI>(g, c[0], c[1], nw, true, nullptr);
   if (EPI == EPI_F32 || EPI == EPI_CFG) {
@@ -202,7 +202,15 @@ Tiling pick_tiling(int M, int N, int K, bool need_full_rows) {
     }
   }
   if (wide) return {mt <= 4 ? 4 : 6, 2, std::min(8, pick_nw(K, 0))};
-  const int nt = ((N / 16) * blocks <= 512) ? 1 : 2;
+  // column tiles per workgroup: the widest (<= 4) that still gives >= ~200 workgroups, so that each CU
+  // runs ONE workgroup (two back-to-back workgroups per CU double the latency chain of the layer)
+  int nt = 1;
+  if (mt >= 5) {
+    if ((N / 64) * blocks >= 192 && N % 64 == 0) nt = 4;
+    else if ((N / 32) * blocks >= 192 && N % 32 == 0) nt = 2;
+  } else if ((N / 16) * blocks > 512) {
+    nt = 2;
+  }
   return {split, nt, pick_nw(K, 0)};
 }
 
