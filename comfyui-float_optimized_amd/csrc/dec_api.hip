@@ -97,7 +97,8 @@ struct ClassTaps {
 ClassTaps class_taps(int pu, int pv) {
   ClassTaps c;
   c.n = 0;
-  const int kys[2][2] = {{0, 2}, {1, -1}}, dys[2][2] = {{0, -1}, {0, 0}};
+  // taps listed with ascending input offset (dy = -1 first), the order dec_conv16_kernel enumerates
+  const int kys[2][2] = {{2, 0}, {1, -1}}, dys[2][2] = {{-1, 0}, {0, 0}};
   for (int a = 0; a < 2; ++a) {
     if (kys[pu][a] < 0) continue;
     for (int b = 0; b < 2; ++b) {
@@ -272,6 +273,12 @@ int create_impl(float_dec* h, const TensorTable& tt) {
     if ((rc = h->pool.alloc(&h->hiFlow[i], sk_hi, true))) return rc;
     if ((rc = h->pool.alloc(&h->hiRgb[i], sk_hi, true))) return rc;
   }
+#define CONV16_ATTR(NTv, TYv, TXv) \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, NTv, TYv, TXv>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3) CONV16_ATTR(4, 2, 2) CONV16_ATTR(2, 2, 2) CONV16_ATTR(4, 2, 1) CONV16_ATTR(2, 2, 1)
+  CONV16_ATTR(4, 1, 2) CONV16_ATTR(2, 1, 2) CONV16_ATTR(4, 1, 1) CONV16_ATTR(2, 1, 1)
+#undef CONV16_ATTR
+  (void)hipGetLastError();
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   return FLOAT_OK;
@@ -331,11 +338,26 @@ int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, in
   FH_REQUIRE(npix * 4 <= 9 * 256, "conv halo tile too large (%d pixels)", npix);
   const int bn = s.cout >= 64 ? 64 : 32;
   FH_REQUIRE(s.cout % bn == 0 && s.cin % 32 == 0, "conv channels (%d -> %d) not tileable", s.cin, s.cout);
-  const size_t smem = (size_t)npix * 64 + (size_t)ntaps * bn * 64;
-  dim3 grid(g.tiles_x * g.tiles_y * fblocks, s.cout / bn);
+  const int ty_taps = dymax - dymin + 1, tx_taps = dxmax - dxmin + 1;
   fh_prof_begin(1, st);
-  if (bn == 64) hipLaunchKernelGGL((dec_conv_kernel<T, 4>), grid, dim3(256), smem, st, g);
-  else hipLaunchKernelGGL((dec_conv_kernel<T, 2>), grid, dim3(256), smem, st, g);
+  if (tdim == 16 && ty_taps * tx_taps == ntaps) {
+    // dense TY x TX window on 16x16 tiles: compile-time geometry, swizzled LDS, register prefetch
+    const int total = g.tiles_x * g.tiles_y * F;
+    g.tpw = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
+    const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64;
+    dim3 grid((total + g.tpw - 1) / g.tpw, s.cout / bn);
+#define CONV16(NTv, TYv, TXv)                                                                                    \
+  if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv)                                                         \
+    hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);
+    CONV16(4, 3, 3) CONV16(2, 3, 3) CONV16(4, 2, 2) CONV16(2, 2, 2) CONV16(4, 2, 1) CONV16(2, 2, 1) CONV16(4, 1, 2)
+    CONV16(2, 1, 2) CONV16(4, 1, 1) CONV16(2, 1, 1)
+#undef CONV16
+  } else {
+    const size_t smem = (size_t)npix * 64 + (size_t)ntaps * bn * 64;
+    dim3 grid(g.tiles_x * g.tiles_y * fblocks, s.cout / bn);
+    if (bn == 64) hipLaunchKernelGGL((dec_conv_kernel<T, 4>), grid, dim3(256), smem, st, g);
+    else hipLaunchKernelGGL((dec_conv_kernel<T, 2>), grid, dim3(256), smem, st, g);
+  }
   fh_prof_end(1, st);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;

@@ -122,6 +122,7 @@ struct ConvArgs {
   int lth, ltw, lnf;                // log2 of tile height / width / frames per tile
   int tiles_x, tiles_y;
   int act;                          // 1: + bias, leaky_relu(0.2) * sqrt(2)
+  int tpw;                          // dec_conv16_kernel: consecutive tiles per workgroup
   signed char dy[9], dx[9];
 };
 
@@ -253,6 +254,176 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
       o.z = T::from_float(v[2]);
       o.w = T::from_float(v[3]);
       *reinterpret_cast<ushort4*>(yp + co) = o;
+    }
+  }
+}
+
+// Specialisation of the conv for 16x16-pixel tiles of one frame and a dense TY x TX tap window (3x3
+// plain convs; 2x2 / 2x1 / 1x2 / 1x1 parity classes of the transposed conv) - every layer from 16x16
+// upward.  What the counters asked for (r01 PMC: 12.6 VALU instructions per MFMA, 42 % of LDS cycles
+// bank conflicts, waves parked 69 % of their life):
+//   * geometry is compile-time: halo decode, tap shifts and unrolling cost no run-time index math, and
+//     every lane keeps its TY*TX swizzled LDS read offsets in registers;
+//   * LDS rows are 64 B (32 channels) and the 16-byte chunk index is XOR-ed with (row>>1)&3, which makes
+//     the ds_read_b128 fragment reads conflict-free for any tile alignment (brute-forced over the gfx950
+//     lane groups, tools/probes/lds_swizzle.py);
+//   * a workgroup walks `tpw` consecutive tiles and all K chunks as one item stream, and the global
+//     loads of item i+1 are issued into registers before the MFMAs of item i (single LDS buffer).
+template <class T, int NT, int TY, int TX>
+__global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
+  constexpr int BN = NT * 16, HH = 15 + TY, HW = 15 + TX, NPIX = HH * HW, NTAPS = TY * TX;
+  constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;              // [NPIX][64 B], chunk-swizzled
+  unsigned char* sB = smem + NPIX * 64;  // [NTAPS][BN][64 B], chunk-swizzled
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+
+  // per-lane swizzled LDS byte offsets of the A fragments, two 16-bit offsets per register
+  constexpr int NTP = (NTAPS + 1) / 2;
+  unsigned aaddr[4][NTP];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = (w * 4 + mt) * 16 + r16;
+    const int y = m >> 4, x = m & 15;
+#pragma unroll
+    for (int tp = 0; tp < NTP; ++tp) {
+      unsigned packed = 0;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int t = tp * 2 + h;
+        if (t < NTAPS) {
+          const int P = (y + t / TX) * HW + x + t % TX;
+          packed |= (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4)) << (16 * h);
+        }
+      }
+      aaddr[mt][tp] = packed;
+    }
+  }
+  const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);  // rows t*BN + j*16 + r16: same swizzle term
+
+  const int tiles_pf = g.tiles_x * g.tiles_y;
+  const int total = tiles_pf * g.F;
+  const int nchunks = g.Cin >> 5;
+  const int tile0 = blockIdx.x * g.tpw;
+  const int ntile = min(g.tpw, total - tile0);
+  const int nitems = ntile * nchunks;
+  const int n0 = blockIdx.y * BN;
+
+  u32x4 ra[NA], rb[NB];
+  auto issue = [&](int item) {
+    const int tile = tile0 + item / nchunks, c0 = (item % nchunks) << 5;
+    const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
+    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+    const int iy0 = ty * 16 + g.dymin, ix0 = tx * 16 + g.dxmin;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
+      ra[i] = u32x4{0u, 0u, 0u, 0u};
+      if (p < NPIX) {
+        const int hy = p / HW, hx = p - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
+          ra[i] = *reinterpret_cast<const u32x4*>(g.X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
+      }
+    }
+    if (nchunks > 1 || item == 0) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + i * 256;
+        if (e < NBC) {
+          const int row = e >> 2, ch = e & 3;
+          const int tap = row / BN, n = row - tap * BN;
+          rb[i] = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+        }
+      }
+    }
+  };
+
+  f32x4 acc[4][NT];
+  issue(0);
+  for (int item = 0; item < nitems; ++item) {
+    __syncthreads();  // every wave is done reading the previous item's tiles
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
+      if (p < NPIX) *reinterpret_cast<u32x4*>(sA + p * 64 + ((ch ^ ((p >> 1) & 3)) << 4)) = ra[i];
+    }
+    if (nchunks > 1 || item == 0) {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int e = tid + i * 256;
+        if (e < NBC) {
+          const int row = e >> 2, ch = e & 3;
+          *reinterpret_cast<u32x4*>(sB + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = rb[i];
+        }
+      }
+    }
+    __syncthreads();
+    if (item + 1 < nitems) issue(item + 1);  // in flight while this item computes
+    const int chunk = item % nchunks;
+    if (chunk == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+      u32x4 a[4], b[NT];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        a[mt] = *reinterpret_cast<const u32x4*>(sA + ((t & 1) ? (aaddr[mt][t >> 1] >> 16) : (aaddr[mt][t >> 1] & 0xffffu)));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + baddr + (t * BN + j * 16) * 64);
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[j], a[mt], acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+    }
+    if (chunk == nchunks - 1) {
+      const int tile = tile0 + item / nchunks;
+      const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
+      const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int m = (w * 4 + mt) * 16 + r16;
+        const int oy = ty * 16 + (m >> 4), ox = tx * 16 + (m & 15);
+        if (oy >= g.Ho || ox >= g.Wo) continue;
+        u16* yp = g.Y + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int co = n0 + j * 16 + q * 4;
+          float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
+          if (g.demod) {
+            const float4 d = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + co);
+            v[0] *= d.x;
+            v[1] *= d.y;
+            v[2] *= d.z;
+            v[3] *= d.w;
+          }
+          if (g.act) {
+            const float4 bb = *reinterpret_cast<const float4*>(g.bias + co);
+            v[0] = fh_lrelu_s2(v[0] + bb.x);
+            v[1] = fh_lrelu_s2(v[1] + bb.y);
+            v[2] = fh_lrelu_s2(v[2] + bb.z);
+            v[3] = fh_lrelu_s2(v[3] + bb.w);
+          }
+          if (g.snext) {
+            const float4 sn = *reinterpret_cast<const float4*>(g.snext + (size_t)f * g.lds + co);
+            v[0] *= sn.x;
+            v[1] *= sn.y;
+            v[2] *= sn.z;
+            v[3] *= sn.w;
+          }
+          ushort4 o;
+          o.x = T::from_float(v[0]);
+          o.y = T::from_float(v[1]);
+          o.z = T::from_float(v[2]);
+          o.w = T::from_float(v[3]);
+          *reinterpret_cast<ushort4*>(yp + co) = o;
+        }
+      }
     }
   }
 }
