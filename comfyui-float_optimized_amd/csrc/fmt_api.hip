@@ -97,6 +97,39 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
   return FLOAT_OK;
 }
 
+// Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
+template <class T, int MTW>
+int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
+  constexpr int smem = MTW * 8 * 1024;
+  auto kern = fmt_gemm_wide_kernel<T, MTW>;
+  if (prime) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      (void)hipGetLastError();
+    return FLOAT_OK;
+  }
+  const int mt_total = (g.M + 15) / 16;
+  g.mblk = (mt_total + MTW - 1) / MTW;
+  fh_prof_begin(0, s);
+  hipLaunchKernelGGL(kern, dim3((g.N / 128) * g.mblk), dim3(256), smem, s, g);
+  fh_prof_end(0, s);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+template <class T>
+int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
+  const int mt = (g.M + 15) / 16;
+  if (prime) {
+    (void)launch_wide_t<T, 4>(g, true, s);
+    (void)launch_wide_t<T, 5>(g, true, s);
+    (void)launch_wide_t<T, 6>(g, true, s);
+    return FLOAT_OK;
+  }
+  if (mt <= 4) return launch_wide_t<T, 4>(g, false, s);
+  if (mt <= 12) return launch_wide_t<T, 6>(g, false, s);
+  return launch_wide_t<T, 5>(g, false, s);
+}
+bool g_fmt_wide = true;  // FLOAT_FMT_WIDE=0 falls back to the generic tiling (A/B measurement)
+
 // ---- GEMM instantiation table: (row tiles, column tiles, waves splitting K) per workgroup ----
 template <class T, int MTW, int NT, int NW, int EPI>
 int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
@@ -168,6 +201,9 @@ void prime_kernels() {
   prime_epi<T, EPI_GATE_RES>();
   prime_epi<T, EPI_XEMBED>();
   prime_epi<T, EPI_CFG>();
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  (void)launch_wide<T>(g, true, nullptr);
 }
 
 // Tiling choice: split the rows over row blocks so that narrow layers still fill the 256 CUs, and
@@ -263,6 +299,7 @@ int run_mod(float_fmt* h, int bc, int step, float* modbuf, hipStream_t s) {
   GemmArgs g = base_args(h->sc16, h->adaln_all, M);
   g.out_f32 = modbuf;
   g.ldo = h->Ntot;
+  if (g_fmt_wide && g.N % 128 == 0 && g.K % 256 == 0) return launch_wide<T>(g, false, s);
   return run_gemm<T, EPI_F32>(g, s);
 }
 
@@ -629,6 +666,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   h->Mpad = 16 * ((4 * h->ntok + 15) / 16);
   h->Kc = round_up(cfg->dim_w + cfg->dim_a + cfg->dim_e, 128);
   h->Kx = round_up(cfg->dim_w, 128);
+  if (const char* wd = getenv("FLOAT_FMT_WIDE")) g_fmt_wide = atoi(wd) != 0;
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
     sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],
            &g_fmt_plan_override[3], &g_fmt_plan_override[4], &g_fmt_plan_override[5]);

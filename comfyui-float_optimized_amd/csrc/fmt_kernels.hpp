@@ -239,6 +239,92 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   }
 }
 
+// Wide-N variant for the fused adaLN projection (N = depth*6D + 2D = 51 200, K = D): here re-reading
+// the activations per 32-column slab dominates the L2->CU traffic (r01 PMC: 1.8 TB/s of HBM+write
+// traffic, waves 85 % stalled), so A goes through LDS ONCE per workgroup and serves 128 columns:
+//   * the fragment-major HBM image of A is exactly the LDS image a wave wants (1 KiB per fragment,
+//     lane-linear), so it is copied with global_load_lds (no VGPR staging, conflict-free ds_read_b128);
+//   * the 4 waves own 32 columns each for the whole K (no K split, no LDS reduction); weights stream
+//     straight to registers, non-temporal;
+//   * operands are swapped (D = W_tile * A_tile^T) so a lane holds 4 consecutive columns of one row and
+//     the fp32 result is stored as float4.
+template <class T, int MTW>
+__global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
+  constexpr int KCH = 8;  // k-blocks (of 32) per LDS chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char sA[];  // [MTW][KCH][1 KiB]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int nbx = g.N >> 7;
+  int bx, by;
+  {
+    const int id = blockIdx.x;
+    if ((nbx & 7) == 0) {
+      const int slot = id >> 3;
+      by = slot % g.mblk;
+      bx = (slot / g.mblk) * 8 + (id & 7);
+    } else {
+      bx = id % nbx;
+      by = id / nbx;
+    }
+  }
+  const int mt0 = by * MTW;
+  const int nb0 = bx * 8 + w * 2;  // this wave's two 16-column tiles
+  const int KB = g.K >> 5;
+  const size_t tstride = (size_t)KB * 512;
+  const u16* Wp = g.W + (size_t)nb0 * tstride + lane * 8;
+  const u16* Ag = g.A + (size_t)mt0 * tstride + lane * 8;
+
+  f32x4 acc[MTW][2];
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < KB; kc += KCH) {
+    // this wave copies fragments f = w, w+4, ... of the MTW x KCH chunk (f = i*KCH + kk)
+#pragma unroll
+    for (int f = 0; f < MTW * KCH / 4; ++f) {
+      const int fi = f * 4 + w;
+      const int i = fi / KCH, kk = fi % KCH;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + i * tstride + (size_t)(kc + kk) * 512),
+                                       (__attribute__((address_space(3))) void*)(sA + fi * 1024), 16, 0, 0);
+    }
+    u32x4 b[KCH][2];
+#pragma unroll
+    for (int kk = 0; kk < KCH; ++kk) {
+      b[kk][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + (size_t)(kc + kk) * 512));
+      b[kk][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + tstride + (size_t)(kc + kk) * 512));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KCH; ++kk) {
+#pragma unroll
+      for (int i = 0; i < MTW; ++i) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(sA + (i * KCH + kk) * 1024 + lane * 16);
+        acc[i][0] = T::mfma(b[kk][0], a, acc[i][0]);
+        acc[i][1] = T::mfma(b[kk][1], a, acc[i][1]);
+      }
+    }
+    __syncthreads();
+  }
+  // D[n = q*4 + reg][m = r16]: lane -> row m0 + i*16 + r16, columns n0 + j*16 + q*4 .. +3
+#pragma unroll
+  for (int i = 0; i < MTW; ++i) {
+    const int row = (mt0 + i) * 16 + r16;
+    if (row >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = (nb0 + j) * 16 + q * 4;
+      const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+      float4 o;
+      o.x = acc[i][j][0] + bb.x;
+      o.y = acc[i][j][1] + bb.y;
+      o.z = acc[i][j][2] + bb.z;
+      o.w = acc[i][j][3] + bb.w;
+      *reinterpret_cast<float4*>(g.out_f32 + (size_t)row * g.ldo + n) = o;
+    }
+  }
+}
+
 // LayerNorm (no affine, biased variance, eps 1e-6) + framewise modulate, one wave per token row
 // (FMT.py:157,168-169,174-175,197).  out = T( (x-mu)*rstd * (1 + scale[row]) + shift[row] ), written in
 // the packed A-operand order of the consuming GEMM (K = D).
