@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-mode", type=int, default=2, help="2: single-branch hipGraph per window, 1: adaLN GEMM on a parallel branch")
     ap.add_argument("--fmt-priority", type=int, default=-1)
+    ap.add_argument("--cu-split", type=int, default=0, help="with --overlap: FMT chain on CUs [0,N), decoder on the rest")
     ap.add_argument("--overlap", action="store_true", help="pipeline FMT sampling of window k+1 with the decode of window k on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -106,6 +107,7 @@ def main():
     hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, dev, args.size, args.fmt_dtype, args.dec_dtype,
                                    args.max_frames, use_graph=0 if args.no_graph else args.graph_mode)
     hp.fmt_stream_priority = args.fmt_priority
+    hp.cu_split = args.cu_split
     feats = [f.to(dev) for f in pkg.weights.synth_feats(args.size, seed=1 + rank)]
     hp.dec.set_feats(feats)
 

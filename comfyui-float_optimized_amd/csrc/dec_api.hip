@@ -1,6 +1,7 @@
 // C-ABI entry points of the decoder operator (include/float_hip.h): weight packing and the
 // per-batch launch chain of Synthesis.forward (reference styledecoder.py:497-534).
 #include <math.h>
+#include <stdlib.h>
 
 #include "dec_kernels.hpp"
 
@@ -417,6 +418,7 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   g.rgb_out = rgb_cur;
   g.final_out = last ? final_out : nullptr;
   g.final_mode = last ? final_mode : 0;
+  g.write_pyr = (!last || getenv("FLOAT_DEC_WRITE_PYR")) ? 1 : 0;
   g.F = n;
   g.R = R;
   g.C = L.C;

@@ -521,6 +521,7 @@ struct FlowArgs {
   const float* lin;    // [R] identity grid: np.linspace(-1, 1, R) (float64) cast to float32
   float* final_out;    // last level: frames
   int final_mode;      // 0: none, 1: HWC clamp(-1,1)*0.5+0.5 (FLOAT.py:149-152), 2: raw CHW
+  int write_pyr;       // store flow_out / rgb_out (0 on the last level: nobody reads them)
   int F, R, C, ld_s;
 };
 
@@ -684,8 +685,10 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
         const float os = sub == 0 ? o[k][0] : (sub == 1 ? o[k][1] : o[k][2]);
         const float v = fh_lrelu_s2(rs + b1) + b2 + upr[k];
         const size_t po = po0 + k;
-        g.flow_out[po * 3 + sub] = os;
-        g.rgb_out[po * 3 + sub] = v;
+        if (g.write_pyr) {  // the pyramids are only read by the next level
+          g.flow_out[po * 3 + sub] = os;
+          g.rgb_out[po * 3 + sub] = v;
+        }
         if (g.final_mode == 1) g.final_out[po * 3 + sub] = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
         else if (g.final_mode == 2) g.final_out[((size_t)f * 3 + sub) * npix + p0 + k] = v;
       }

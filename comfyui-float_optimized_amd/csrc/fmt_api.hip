@@ -291,12 +291,19 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
 // inside a captured window it runs on a side branch one step ahead of the block chain.
 //   sc = silu(t_emb + c_cond)  ->  mod[M][depth*6D + 2D] = every adaLN projection in one
 //   weight-streaming GEMM (105 MB of the 313 MB an evaluation reads).
+constexpr int kScSteps = 64;  // SiLU(c) of up to this many Euler steps is produced once per window
+
 template <class T>
-int run_mod(float_fmt* h, int bc, int step, float* modbuf, hipStream_t s) {
+int run_mod(float_fmt* h, int bc, int step, float* modbuf, hipStream_t s, bool hoisted) {
   const int D = h->D, M = bc * h->ntok;
-  hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256), dim3(256), 0, s, h->sc16,
-                     h->temb + (size_t)step * D, h->ccond, M, D);
-  GemmArgs g = base_args(h->sc16, h->adaln_all, M);
+  const u16* A = h->sc16;
+  if (hoisted) {
+    A = h->sc16 + (size_t)step * h->Mpad * D;
+  } else {
+    hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256, 1), dim3(256), 0, s, h->sc16,
+                       h->temb + (size_t)step * D, h->ccond, M, D, (size_t)0);
+  }
+  GemmArgs g = base_args(A, h->adaln_all, M);
   g.out_f32 = modbuf;
   g.ldo = h->Ntot;
   if (g_fmt_wide && g.N % 128 == 0 && g.K % 256 == 0) return launch_wide<T>(g, false, s);
@@ -458,7 +465,7 @@ int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<
                      hipStream_t s) {
   for (int i = 0; i < nfe - 1; ++i) {
     const float dt = ts[i + 1] - ts[i];
-    int rc = run_mod<T>(h, m.bc, i, h->mod, s);
+    int rc = run_mod<T>(h, m.bc, i, h->mod, s, nfe - 1 <= kScSteps);
     if (rc) return rc;
     if ((rc = run_blocks<T>(h, m.bc, h->mod, true, dt, a, r, e, s))) return rc;
   }
@@ -486,13 +493,14 @@ int capture_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vec
   hipEvent_t* ev_done = ev.data() + S + 1;  // ev_done[i]: block chain of step i finished
   FH_CHECK_HIP(hipEventRecord(ev_done[S], s));  // fork point
   FH_CHECK_HIP(hipStreamWaitEvent(side, ev_done[S], 0));
-  if ((rc = run_mod<T>(h, m.bc, 0, modb[0], side))) return rc;
+  const bool hoisted = S <= kScSteps;
+  if ((rc = run_mod<T>(h, m.bc, 0, modb[0], side, hoisted))) return rc;
   FH_CHECK_HIP(hipEventRecord(ev_mod[0], side));
   for (int i = 0; i < S; ++i) {
     if (i + 1 < S) {
       // buffer (i+1)%2 was last read by step i-1
       if (i >= 1) FH_CHECK_HIP(hipStreamWaitEvent(side, ev_done[i - 1], 0));
-      if ((rc = run_mod<T>(h, m.bc, i + 1, modb[(i + 1) & 1], side))) return rc;
+      if ((rc = run_mod<T>(h, m.bc, i + 1, modb[(i + 1) & 1], side, hoisted))) return rc;
       FH_CHECK_HIP(hipEventRecord(ev_mod[i + 1], side));
     }
     FH_CHECK_HIP(hipStreamWaitEvent(s, ev_mod[i], 0));
@@ -546,6 +554,11 @@ int window_impl(float_fmt* h, const float* x0, const float* wa, const float* wr,
   const CfgMode m = cfg_mode(a, r, e, include_r);
   int rc = stage_window<T>(h, m, x0, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s);
   if (rc) return rc;
+  if (nfe - 1 >= 1 && nfe - 1 <= kScSteps) {
+    const int M = m.bc * h->ntok;
+    hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * h->D / 8 + 255) / 256, nfe - 1), dim3(256), 0, s, h->sc16, h->temb,
+                       h->ccond, M, h->D, (size_t)h->Mpad * h->D);
+  }
   if (h->cfg.use_graph && !g_fh_profiling) return run_window_steps_graph<T>(h, m, we_len, nfe, ts, a, r, e, s);
   return run_window_steps<T>(h, m, nfe, ts, a, r, e, s);
 }
@@ -559,7 +572,7 @@ int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const floa
   if (rc) return rc;
   const CfgMode m = cfg_mode(a, r, e, include_r);
   if ((rc = stage_window<T>(h, m, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s))) return rc;
-  if ((rc = run_mod<T>(h, m.bc, 0, h->mod, s))) return rc;
+  if ((rc = run_mod<T>(h, m.bc, 0, h->mod, s, false))) return rc;
   if ((rc = run_blocks<T>(h, m.bc, h->mod, false, 0.f, a, r, e, s))) return rc;
   FH_CHECK_HIP(hipMemcpyAsync(out, h->vout, (size_t)h->ntok * h->cfg.dim_w * sizeof(float), hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
@@ -680,7 +693,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->pos, (size_t)64 * D);
   A(&h->freqs, 128);
   A(&h->cond16, (size_t)Mp * h->Kc);
-  A(&h->sc16, (size_t)Mp * D);
+  A(&h->sc16, (size_t)kScSteps * Mp * D);
   A(&h->h16, (size_t)Mp * D);
   A(&h->qkv16, (size_t)Mp * 3 * D);
   A(&h->att16, (size_t)Mp * D);

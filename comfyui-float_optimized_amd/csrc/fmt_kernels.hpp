@@ -509,10 +509,13 @@ __global__ void fmt_tsin_kernel(u16* __restrict__ out, const float* __restrict__
 // written packed: the A operand of the fused adaLN projection.  8 columns per thread.
 template <class T>
 __global__ void fmt_silu_c_kernel(u16* __restrict__ out, const float* __restrict__ temb, const float* __restrict__ ccond,
-                                  int M, int D) {
+                                  int M, int D, size_t step_stride) {
+  // blockIdx.y = Euler step: all steps of a window are produced by one launch when they fit
   const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (idx >= M * D) return;
   const int row = idx / D, c = idx % D;
+  out += (size_t)blockIdx.y * step_stride;
+  temb += (size_t)blockIdx.y * D;
   uint4 u;
   u16* e = reinterpret_cast<u16*>(&u);
 #pragma unroll

@@ -71,6 +71,25 @@ int float_set_profiling(int32_t on) {
   return FLOAT_OK;
 }
 
+// A stream whose kernels may only run on CUs [cu_begin, cu_end) of the device (hipExtStreamCreateWithCUMask):
+// lets the caller give the latency-bound FMT chain and the throughput-bound decoder disjoint CU sets so
+// that the chain's tiny dependent kernels never queue behind decoder workgroups.
+int float_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream_out) {
+  FH_REQUIRE(stream_out && cu_begin >= 0 && cu_end > cu_begin && cu_end <= 1024, "bad CU range [%d,%d)", cu_begin, cu_end);
+  uint32_t mask[32];
+  memset(mask, 0, sizeof(mask));
+  for (int c = cu_begin; c < cu_end; ++c) mask[c >> 5] |= 1u << (c & 31);
+  hipStream_t s = nullptr;
+  FH_CHECK_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)((cu_end + 31) / 32), mask));
+  *stream_out = (void*)s;
+  return FLOAT_OK;
+}
+
+int float_stream_destroy(void* stream) {
+  if (stream) FH_CHECK_HIP(hipStreamDestroy((hipStream_t)stream));
+  return FLOAT_OK;
+}
+
 double float_profile_ms(int32_t which, int64_t* n_launches) {
   if (which < 0 || which >= kClasses) return -1.0;
   Slot& s = g_slots[which];

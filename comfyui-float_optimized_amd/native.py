@@ -36,6 +36,8 @@ _SIGNATURES = {
     "float_last_error": (C.c_char_p, []),
     "float_set_profiling": (C.c_int, [C.c_int32]),
     "float_profile_ms": (C.c_double, [C.c_int32, C.POINTER(C.c_int64)]),
+    "float_stream_create_cu_range": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
+    "float_stream_destroy": (C.c_int, [C.c_void_p]),
     "float_fmt_create": (C.c_int, [C.POINTER(FmtCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_fmt_destroy": (None, [C.c_void_p]),
     "float_fmt_eval": (C.c_int, [C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 +
@@ -122,6 +124,13 @@ def dev_ptr(t, name="tensor"):
 
 def stream_ptr(device=None):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def cu_range_stream(cu_begin, cu_end, device=None):
+    """torch stream object over a HIP stream whose kernels only run on CUs [cu_begin, cu_end)."""
+    p = C.c_void_p()
+    check(lib().float_stream_create_cu_range(int(cu_begin), int(cu_end), C.byref(p)))
+    return torch.cuda.ExternalStream(p.value, device=device)
 
 
 def set_profiling(on):

@@ -64,8 +64,15 @@ class FloatHotPath:
         t0, t1 = frame_range if frame_range is not None else (0, T)
         dev = self.device
         if not hasattr(self, "_s_fmt"):
-            self._s_fmt = torch.cuda.Stream(dev, priority=getattr(self, "fmt_stream_priority", -1))
-            self._s_dec = torch.cuda.Stream(dev, priority=0)
+            split = getattr(self, "cu_split", None)
+            if split:  # disjoint CU sets: chain on CUs [0, split), decoder on [split, n_cu)
+                n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                with torch.cuda.device(dev):
+                    self._s_fmt = native.cu_range_stream(0, split, dev)
+                    self._s_dec = native.cu_range_stream(split, n_cu, dev)
+            else:
+                self._s_fmt = torch.cuda.Stream(dev, priority=getattr(self, "fmt_stream_priority", -1))
+                self._s_dec = torch.cuda.Stream(dev, priority=0)
         cur = torch.cuda.current_stream(dev)
         self._s_fmt.wait_stream(cur)
         self._s_dec.wait_stream(cur)

@@ -84,10 +84,13 @@ class InferenceAgent:
         o = self.opt
         s = host_models.preprocess_image(ref_img[0] if ref_img.dim() == 4 else ref_img, o.input_size).to(self.rank)
         a = host_models.preprocess_audio(ref_audio["waveform"][0], ref_audio["sample_rate"], o.sampling_rate).to(self.rank)
-        s_r, feats, lam = host_models.encode_appearance(self.enc_sd, s)
-        r_s = host_models.direction(self.direction_q, lam)
-        T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
-        wa = self.audio_encoder.inference(a, seq_len=T, sampling_rate=o.sampling_rate, fps=o.fps)
+        # the once-per-clip PyTorch encoders run with deterministic MIOpen/rocBLAS algorithms so that a seed
+        # reproduces a clip bit for bit (the HIP operators are deterministic by construction)
+        with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):
+            s_r, feats, lam = host_models.encode_appearance(self.enc_sd, s)
+            r_s = host_models.direction(self.direction_q, lam)
+            T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
+            wa = self.audio_encoder.inference(a, seq_len=T, sampling_rate=o.sampling_rate, fps=o.fps)
         if emo is None or str(emo).lower() == "none":
             if self.emotion_predictor is None:
                 raise NotImplementedError(

@@ -142,6 +142,10 @@ const char* float_last_error(void);
 /* Average device time (ms) of the kernels launched by the last timed call, by class, measured
  * with hipEvents on the caller's stream when profiling is on.  which: 0 = FMT GEMMs,
  * 1 = decoder convs.  Returns <0 when profiling is off. */
+/* A HIP stream restricted to CUs [cu_begin, cu_end) (hipExtStreamCreateWithCUMask).  Used to run the FMT
+ * chain and the decoder concurrently on disjoint CU sets (pipeline.generate(overlap="cu")). */
+int float_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream_out);
+int float_stream_destroy(void* stream);
 int float_set_profiling(int32_t on);
 double float_profile_ms(int32_t which, int64_t* n_launches);
 
