@@ -90,13 +90,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("FLOAT_BENCH_BACKEND", "nccl")  # "gloo": ranks may share one GPU (smoke test of the N>1 path)
+    n_dev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     pkg = load_pkg()
     cfg = pkg.config.FmtConfig()
@@ -144,7 +148,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert frames.shape == (T, args.size, args.size, 3)
@@ -195,6 +199,14 @@ def main():
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": c_n, "avg_launch_us": round(c_ms * 1e3, 2),
                      "algorithmic_flop_per_launch": round(conv_flop / max(c_n, 1)), "traffic": None}
         conv_roof["frac"] = round(conv_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
+        # HBM traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+        # separate passes, tools/profile_hotpath.py); null when the summary is not there
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            gemm_roof["traffic"] = pmc["fmt_gemm"]["hbm_bytes_per_launch"]
+            conv_roof["traffic"] = pmc["dec_conv"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         roof = (conv_roof, gemm_roof) if conv_total_ms >= gemm_total_ms else (gemm_roof, conv_roof)
         extra["kernel_class_ms"] = {"fmt_gemm": round(gemm_total_ms, 2), "dec_conv": round(conv_total_ms, 2)}
 
@@ -207,7 +219,8 @@ def main():
             "metric": "512x512 frames/sec end-to-end audio->video @50 ODE steps (hot path: FMT sampling + decode)",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": "weak",
+            "vs_baseline": None,
             "dtype": "%s+%s" % (args.fmt_dtype, args.dec_dtype) if args.fmt_dtype != args.dec_dtype else args.fmt_dtype,
             "data": "synthetic",
             "config": {"workload": "configs[1]: %.0f s audio -> %d frames %dx%d, %d Euler evaluations/window, CFG a=%.1f e=%.1f%s"

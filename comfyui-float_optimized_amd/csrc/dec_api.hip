@@ -426,11 +426,13 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   // Grid: ~2048 workgroups in total (8 per CU) so that every lane group runs many pixel iterations and
   // the per-workgroup prologue (56 per-lane weight values) is amortised; one row of workgroups per frame.
   const int lpp = L.C / 8, gpb = 256 / lpp;
-  const int pix = lpp <= 8 ? 4 : 2;
+  static const int pix_env = getenv("FLOAT_DEC_FLOW_PIX") ? atoi(getenv("FLOAT_DEC_FLOW_PIX")) : 0;  // tuning aid
+  const int pix = pix_env ? pix_env : (lpp <= 8 ? 4 : 2);
   const int max_bx = (R * R / pix + gpb - 1) / gpb;
   const int bx = std::max(1, std::min(max_bx, (2048 + n - 1) / n));
   if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx, n), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx, n), dim3(256), 0, st, g);
+  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx, n), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx, n), dim3(256), 0, st, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }

@@ -553,26 +553,29 @@ __device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x});
 }
 
 // PIX consecutive pixels of a row per lane group and iteration: every x load of the iteration is
-// issued before the first flow is reduced, and every feature gather before the first blend, so a
-// wave keeps PIX (x) then 4*PIX (feat) 16-byte loads in flight instead of one dependent pair.
+// issued before the first flow is reduced, and every feature gather before the first blend.  The
+// per-frame folded weights (flow conv * style, rgb conv, next style: 7 x C floats) live in LDS, not in
+// registers, which keeps the kernel at <=128 VGPRs (4 waves per SIMD) - the first version held them in
+// 56 registers per lane and ran at ONE wave per SIMD (r01 PMC: waves parked 56 % of their life).
 template <class T, int PIX>
 __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
-  const int lpp = g.C >> 3;          // lanes per pixel (4..64)
+  __shared__ __attribute__((aligned(16))) float sw[7 * 512];  // [wf0 wf1 wf2 | wr0 wr1 wr2 | sn][C]
+  const int C = g.C;
+  const int lpp = C >> 3;            // lanes per pixel (4..64)
   const int gpb = 256 / lpp;         // lane groups per block
   const int f = blockIdx.y;
   const int sub = threadIdx.x % lpp, grp = threadIdx.x / lpp;
   const int c0 = sub * 8;
-  float wf[3][8], wr[3][8], sn[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float s = g.sflow[(size_t)f * g.ld_s + c0 + i];
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float s = g.sflow[(size_t)f * g.ld_s + c];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      wf[j][i] = g.wflow[j * g.C + c0 + i] * s;
-      wr[j][i] = g.wrgb[j * g.C + c0 + i];
+      sw[j * C + c] = g.wflow[j * C + c] * s;
+      sw[(3 + j) * C + c] = g.wrgb[j * C + c];
     }
-    sn[i] = g.snext ? g.snext[(size_t)f * g.ld_s + c0 + i] : 0.f;
+    sw[6 * C + c] = g.snext ? g.snext[(size_t)f * g.ld_s + c] : 0.f;
   }
+  __syncthreads();
   // lane `sub` < 3 owns output channel `sub` of the 3-channel maps (bias, pyramid taps, stores)
   const int jch = sub < 3 ? sub : 0;
   const float bfl = sub < 3 ? g.bflow[jch] : 0.f;
@@ -584,23 +587,30 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     const size_t po0 = (size_t)f * npix + p0;
     uint4 xu[PIX];
 #pragma unroll
-    for (int k = 0; k < PIX; ++k) xu[k] = *reinterpret_cast<const uint4*>(g.x + (po0 + k) * g.C + c0);
+    for (int k = 0; k < PIX; ++k) xu[k] = *reinterpret_cast<const uint4*>(g.x + (po0 + k) * C + c0);
     float upf[PIX];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) upf[k] = (g.pflow && sub < 3) ? up2_tap(g.pflow, f, Rp, Y, X0 + k, jch) : 0.f;
     const float gy = g.lin[Y];
-    float xf[PIX][8], o[PIX][3];
+    float o[PIX][3];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) o[k][0] = o[k][1] = o[k][2] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 w0 = *reinterpret_cast<const float4*>(sw + j * C + c0);
+      const float4 w1 = *reinterpret_cast<const float4*>(sw + j * C + c0 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int k = 0; k < PIX; ++k) {
+        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += wv[i] * T::to_float(xe[i]);
+        o[k][j] = a;
+      }
+    }
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
-      const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
-      o[k][0] = o[k][1] = o[k][2] = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        xf[k][i] = T::to_float(xe[i]);
-        o[k][0] += wf[0][i] * xf[k][i];
-        o[k][1] += wf[1][i] * xf[k][i];
-        o[k][2] += wf[2][i] * xf[k][i];
-      }
       // bias + up-sampled previous flow enter the sum once, in the lane that owns the channel
       const float add = upf[k] + bfl;
       o[k][0] += sub == 0 ? add : 0.f;
@@ -633,7 +643,7 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
         for (int b = 0; b < 2; ++b) {
           const int yy = y0 + a, xx = x0 + b;
           const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
-          fu[k][a * 2 + b] = in ? *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * g.C + c0) : uint4{0u, 0u, 0u, 0u};
+          fu[k][a * 2 + b] = in ? *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * C + c0) : uint4{0u, 0u, 0u, 0u};
         }
     }
     float upr[PIX];
@@ -649,25 +659,28 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]);
+          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]) * mask[k];
           const u16* fe = reinterpret_cast<const u16*>(&fu[k][a * 2 + b]);
 #pragma unroll
           for (int i = 0; i < 8; ++i) fw[i] += wgt * T::to_float(fe[i]);
         }
-      rgb[k][0] = rgb[k][1] = rgb[k][2] = 0.f;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        fw[i] *= mask[k];
-        rgb[k][0] += wr[0][i] * fw[i];
-        rgb[k][1] += wr[1][i] * fw[i];
-        rgb[k][2] += wr[2][i] * fw[i];
+      for (int j = 0; j < 3; ++j) {
+        const float4 w0 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0);
+        const float4 w1 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0 + 4);
+        rgb[k][j] = w0.x * fw[0] + w0.y * fw[1] + w0.z * fw[2] + w0.w * fw[3] + w1.x * fw[4] + w1.y * fw[5] + w1.z * fw[6] + w1.w * fw[7];
       }
       if (g.xnext) {
+        const float4 n0 = *reinterpret_cast<const float4*>(sw + 6 * C + c0);
+        const float4 n1 = *reinterpret_cast<const float4*>(sw + 6 * C + c0 + 4);
+        const float sn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
+        const float om = 1.f - mask[k];
         uint4 ou;
         u16* oe = reinterpret_cast<u16*>(&ou);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + xf[k][i] * (1.f - mask[k])) * sn[i]);
-        *reinterpret_cast<uint4*>(g.xnext + (po0 + k) * g.C + c0) = ou;
+        for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + T::to_float(xe[i]) * om) * sn[i]);
+        *reinterpret_cast<uint4*>(g.xnext + (po0 + k) * C + c0) = ou;
       }
     }
     for (int d = 1; d < lpp; d <<= 1) {
