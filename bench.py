@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--fmt-dtype", default="bf16")
     ap.add_argument("--dec-dtype", default="fp16")
-    ap.add_argument("--max-frames", type=int, default=16)
+    ap.add_argument("--max-frames", type=int, default=32)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
     ap.add_argument("--dynamic-we", action="store_true", help="BASELINE configs[4]: per-window emotion")
     ap.add_argument("--no-graph", action="store_true")

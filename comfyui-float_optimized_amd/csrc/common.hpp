@@ -1,6 +1,7 @@
 // Shared device/host helpers for libfloat_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -171,5 +172,6 @@ struct ProfileSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
 };
 extern int g_fh_profiling;
+bool fh_prof_pair(int which, hipEvent_t* start, hipEvent_t* stop);
 void fh_prof_begin(int which, hipStream_t s);
 void fh_prof_end(int which, hipStream_t s);

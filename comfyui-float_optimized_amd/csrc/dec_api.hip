@@ -340,7 +340,8 @@ int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, in
   const int bn = s.cout >= 64 ? 64 : 32;
   FH_REQUIRE(s.cout % bn == 0 && s.cin % 32 == 0, "conv channels (%d -> %d) not tileable", s.cin, s.cout);
   const int ty_taps = dymax - dymin + 1, tx_taps = dxmax - dxmin + 1;
-  fh_prof_begin(1, st);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  const bool prof = fh_prof_pair(1, &e0, &e1);
   if (tdim == 16 && ty_taps * tx_taps == ntaps) {
     // dense TY x TX window on 16x16 tiles: compile-time geometry, swizzled LDS, register prefetch
     const int total = g.tiles_x * g.tiles_y * F;
@@ -348,18 +349,24 @@ int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, in
     const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64;
     dim3 grid((total + g.tpw - 1) / g.tpw, s.cout / bn);
 #define CONV16(NTv, TYv, TXv)                                                                                    \
-  if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv)                                                         \
-    hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);
+  if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv) {                                                       \
+    if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
+    else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);                  \
+  }
     CONV16(4, 3, 3) CONV16(2, 3, 3) CONV16(4, 2, 2) CONV16(2, 2, 2) CONV16(4, 2, 1) CONV16(2, 2, 1) CONV16(4, 1, 2)
     CONV16(2, 1, 2) CONV16(4, 1, 1) CONV16(2, 1, 1)
 #undef CONV16
   } else {
     const size_t smem = (size_t)npix * 64 + (size_t)ntaps * bn * 64;
     dim3 grid(g.tiles_x * g.tiles_y * fblocks, s.cout / bn);
-    if (bn == 64) hipLaunchKernelGGL((dec_conv_kernel<T, 4>), grid, dim3(256), smem, st, g);
-    else hipLaunchKernelGGL((dec_conv_kernel<T, 2>), grid, dim3(256), smem, st, g);
+    if (prof) {
+      if (bn == 64) hipExtLaunchKernelGGL((dec_conv_kernel<T, 4>), grid, dim3(256), smem, st, e0, e1, 0, g);
+      else hipExtLaunchKernelGGL((dec_conv_kernel<T, 2>), grid, dim3(256), smem, st, e0, e1, 0, g);
+    } else {
+      if (bn == 64) hipLaunchKernelGGL((dec_conv_kernel<T, 4>), grid, dim3(256), smem, st, g);
+      else hipLaunchKernelGGL((dec_conv_kernel<T, 2>), grid, dim3(256), smem, st, g);
+    }
   }
-  fh_prof_end(1, st);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }

@@ -109,9 +109,9 @@ int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   }
   const int mt_total = (g.M + 15) / 16;
   g.mblk = (mt_total + MTW - 1) / MTW;
-  fh_prof_begin(0, s);
-  hipLaunchKernelGGL(kern, dim3((g.N / 128) * g.mblk), dim3(256), smem, s, g);
-  fh_prof_end(0, s);
+  hipEvent_t e0, e1;
+  if (fh_prof_pair(0, &e0, &e1)) hipExtLaunchKernelGGL(kern, dim3((g.N / 128) * g.mblk), dim3(256), smem, s, e0, e1, 0, g);
+  else hipLaunchKernelGGL(kern, dim3((g.N / 128) * g.mblk), dim3(256), smem, s, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -147,9 +147,9 @@ int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
   const int mt_total = (g.M + 15) / 16;
   g.mblk = (mt_total + MTW - 1) / MTW;
   dim3 grid((g.N / (NT * 16)) * g.mblk);
-  fh_prof_begin(0, s);
-  hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, g);
-  fh_prof_end(0, s);
+  hipEvent_t e0, e1;
+  if (fh_prof_pair(0, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, e0, e1, 0, g);
+  else hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }

@@ -34,6 +34,18 @@ hipEvent_t get_event(Slot& s) {
 }
 }  // namespace
 
+// Kernel-exact timing: the pair is handed to hipExtLaunchKernelGGL, which stamps the events with the
+// dispatch's own begin/end timestamps (what rocprofv3 --kernel-trace reports), not with the time the
+// stream reached a separately recorded event (that adds ~3 us of event handling per launch).
+bool fh_prof_pair(int which, hipEvent_t* start, hipEvent_t* stop) {
+  if (!g_fh_profiling || which < 0 || which >= kClasses) return false;
+  Slot& s = g_slots[which];
+  *start = get_event(s);
+  *stop = get_event(s);
+  s.live.emplace_back(*start, *stop);
+  return true;
+}
+
 void fh_prof_begin(int which, hipStream_t st) {
   if (!g_fh_profiling || which < 0 || which >= kClasses) return;
   Slot& s = g_slots[which];
