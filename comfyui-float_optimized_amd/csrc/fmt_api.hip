@@ -559,6 +559,7 @@ int window_impl(float_fmt* h, const float* x0, const float* wa, const float* wr,
     hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * h->D / 8 + 255) / 256, nfe - 1), dim3(256), 0, s, h->sc16, h->temb,
                        h->ccond, M, h->D, (size_t)h->Mpad * h->D);
   }
+  if (nfe <= 1) return FLOAT_OK;  // a one-point grid has no evaluation: the sample is x0 (FLOAT.py:188,247-248)
   if (h->cfg.use_graph && !g_fh_profiling) return run_window_steps_graph<T>(h, m, we_len, nfe, ts, a, r, e, s);
   return run_window_steps<T>(h, m, nfe, ts, a, r, e, s);
 }

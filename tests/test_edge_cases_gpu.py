@@ -1,0 +1,70 @@
+"""Edge cases of the hot path on the GPU, against the live oracle: ragged / minimal lengths, the
+degenerate Euler grids, 4-way CFG through the whole loop, dynamic emotion with a ragged tail, and the
+largest sizes of BASELINE.json (60 s clip) through size-independent properties."""
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import load_pkg, rel_l2
+
+pkg = load_pkg()
+pytestmark = pytest.mark.gpu
+CFG = pkg.config.FmtConfig()
+
+
+@pytest.fixture(scope="module")
+def fmt():
+    sd = pkg.weights.synth_fmt_state(CFG, seed=31)
+    return sd, pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", "bf16")
+
+
+@pytest.mark.parametrize("T,nfe,dynamic", [(1, 3, False), (49, 2, False), (50, 3, True), (51, 3, True), (100, 1, False)])
+def test_ragged_lengths_and_degenerate_grids(fmt, T, nfe, dynamic):
+    sd, m = fmt
+    c = pkg.pipeline.synth_conditions(CFG, T, seed=T, dynamic_we=dynamic)
+    noise = pkg.fmt.draw_noise((T + 49) // 50, 1, CFG, seed=15)
+    a, e = (1.0, 3.0) if dynamic else (2.0, 1.0)
+    got = m.sample(c["r_s"], c["wa"], c["we"], noise, nfe, a, 1.0, e).cpu()
+    ref = O.sample_rd(sd, CFG, c["r_s"], c["wa"], c["we"], noise, nfe, a, 1.0, e)
+    assert got.shape == (1, T, 512)
+    if nfe == 1:  # no evaluation: the sample is the noise itself, bit for bit
+        assert torch.equal(got, noise.reshape(1, -1, 512)[:, :T])
+    else:
+        assert rel_l2(got, ref) < 2e-2
+
+
+def test_four_way_cfg_through_the_loop(fmt):
+    sd, m = fmt
+    T = 70
+    c = pkg.pipeline.synth_conditions(CFG, T, seed=9)
+    noise = pkg.fmt.draw_noise(2, 1, CFG, seed=15)
+    got = m.sample(c["r_s"], c["wa"], c["we"], noise, 4, 2.0, 1.5, 1.2, include_r_cfg=True).cpu()
+    ref = O.sample_rd(sd, CFG, c["r_s"], c["wa"], c["we"], noise, 4, 2.0, 1.5, 1.2, include_r_cfg=True)
+    assert rel_l2(got, ref) < 2e-2
+
+
+def test_batch_items_are_independent(fmt):
+    """B > 1 at the host mirror = the reference's per-item loop (nodes.py:189-209)."""
+    sd, m = fmt
+    c0, c1 = pkg.pipeline.synth_conditions(CFG, 60, seed=1), pkg.pipeline.synth_conditions(CFG, 60, seed=2)
+    noise = pkg.fmt.draw_noise(2, 2, CFG, seed=15)
+    both = m.sample(torch.cat([c0["r_s"], c1["r_s"]]), torch.cat([c0["wa"], c1["wa"]]), torch.cat([c0["we"], c1["we"]]), noise, 3)
+    one = m.sample(c1["r_s"], c1["wa"], c1["we"], noise[:, 1:2], 3)
+    assert torch.equal(both[1:2], one)
+
+
+def test_sixty_second_clip_properties():
+    """BASELINE configs[2] size (1500 frames, 30 windows) with a short grid: prefix property of the AR chain
+    (the first 10 s of the 60 s clip equal the 10 s clip), finite output, frames in range."""
+    fmt_sd = pkg.weights.synth_fmt_state(CFG, seed=33)
+    dec_sd = pkg.weights.synth_decoder_state(64, seed=33)
+    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, CFG, "cuda:0", 64, max_frames=32)
+    c = pkg.pipeline.synth_conditions(CFG, 1500, seed=4)
+    noise = pkg.fmt.draw_noise(30, 1, CFG, seed=15)
+    feats = pkg.weights.synth_feats(64, seed=33)
+    frames, r_d = hp.generate(c["r_s"], c["wa"], c["we"], c["s_r"], feats, 3, noise=noise, return_rd=True)
+    short = hp.sample(c["r_s"], c["wa"][:, :250], c["we"], 3, noise=noise[:5])
+    torch.cuda.synchronize()
+    assert frames.shape == (1500, 64, 64, 3) and torch.isfinite(frames).all()
+    assert float(frames.min()) >= 0 and float(frames.max()) <= 1
+    assert torch.equal(r_d[:, :250], short)
