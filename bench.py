@@ -45,7 +45,11 @@ def parse():
     ap.add_argument("--fmt-dtype", default="bf16")
     ap.add_argument("--dec-dtype", default="fp16")
     ap.add_argument("--max-frames", type=int, default=32)
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "shard"])
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "shard", "window"],
+                    help="N>1: replicas = one clip per GPU (exact); shard = one N x clip, latent chain replicated, frames "
+                         "sharded (exact); window = one N x clip, windows sharded, RCCL all_gather of boundary latents + "
+                         "re-solve (approximate unless --window-iters = N-1)")
+    ap.add_argument("--window-iters", type=int, default=1)
     ap.add_argument("--dynamic-we", action="store_true", help="BASELINE configs[4]: per-window emotion")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-mode", type=int, default=2, help="2: single-branch hipGraph per window, 1: adaLN GEMM on a parallel branch")
@@ -115,7 +119,7 @@ def main():
     feats = [f.to(dev) for f in pkg.weights.synth_feats(args.size, seed=1 + rank)]
     hp.dec.set_feats(feats)
 
-    if args.mode == "shard" and world > 1:
+    if args.mode in ("shard", "window") and world > 1:
         # one long clip of world*T frames; every rank runs the identical (deterministic) latent chain,
         # then decodes its contiguous frame range - see comfyui-float_optimized_amd/distributed.py
         T_total = T * world
@@ -126,7 +130,14 @@ def main():
     noise = pkg.fmt.draw_noise(hp.n_chunks(T_total), 1, cfg, seed=15).to(dev)
     a_cfg, e_cfg = (1.0, 3.0) if args.dynamic_we else (2.0, 1.0)
 
+    seam = {}
+
     def step():
+        if args.mode == "window" and world > 1:
+            r_loc, (t0, t1), rep = pkg.distributed.sample_window_parallel(
+                hp.fmt, cfg, cond["r_s"], cond["wa"], cond["we"], noise, args.nfe, a_cfg, 1.0, e_cfg, iters=args.window_iters)
+            seam.update(rep)
+            return hp.decode(cond["s_r"], None, r_loc)
         fr = (rank * T, (rank + 1) * T) if (args.mode == "shard" and world > 1) else None
         return hp.generate(cond["r_s"], cond["wa"], cond["we"], cond["s_r"], None, args.nfe, a_cfg, 1.0, e_cfg, noise=noise,
                            overlap=args.overlap, frame_range=fr)
@@ -151,7 +162,7 @@ def main():
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert frames.shape == (T, args.size, args.size, 3)
+    assert frames.shape[1:] == (args.size, args.size, 3) and (args.mode == "window" or frames.shape[0] == T)
     total_frames = T * world * args.steps
     fps = total_frames / elapsed
 
@@ -254,7 +265,10 @@ def main():
                        "decode_batch": args.max_frames, "hip_graph": not args.no_graph,
                        "stage_overlap": args.overlap,
                        "parallelism": ("replicas x%d (one clip per GPU)" % world) if args.mode == "replicas" or world == 1
-                       else "shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world)},
+                       else ("shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world)
+                             if args.mode == "shard" else
+                             "window: one %d-frame clip, windows sharded x%d, boundary all_gather x%d round(s), rank-0 seam change %.3e"
+                             % (T_total, world, args.window_iters, seam.get("seam_rel_change", 0.0)))},
         }
         out.update(extra)
         if roof:

@@ -41,7 +41,12 @@ class InferenceAgent:
         if parts is None:
             parts = self._load_parts(opt)
         self.enc_sd, self.dec_sd = parts["enc"], parts["dec"]
-        self.G = FloatHotPath(parts["fmt"], parts["dec"], self.cfg, self.rank, opt.input_size)
+        # 16-bit MFMA operand types (fp32 accumulation): fp16 in both operators gives ~8x lower rounding error than
+        # bf16 at the same rate (end-to-end 48.7 vs 34.1 dB on BASELINE configs[0]); FLOAT_AMD_FMT_DTYPE=bf16
+        # selects the type BASELINE configs[1] names.
+        self.G = FloatHotPath(parts["fmt"], parts["dec"], self.cfg, self.rank, opt.input_size,
+                              fmt_dtype=os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
+                              dec_dtype=os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"))
         self.direction_q = host_models.direction_basis(parts["dec"], self.rank)
         self.audio_encoder = parts["audio_encoder"].to(self.rank)
         self.emotion_predictor = parts.get("emotion_predictor")  # callable(a) -> (1,7) scores, optional

@@ -95,3 +95,17 @@ def test_euler_grid_and_chunking():
     a = torch.arange(6.0).reshape(1, 3, 2)
     p = O.pad_replicate(a, 5)
     assert p.shape == (1, 5, 2) and torch.equal(p[0, 3], a[0, 2]) and torch.equal(p[0, 4], a[0, 2])
+
+
+def test_e2e_config1():
+    """BASELINE configs[0] (1 s audio, 25 frames, nfe = 10, fp32): the reference's sampler + decode loop chained."""
+    g = golden("e2e_config1")
+    cfg = C.FmtConfig()
+    fsd = W.synth_fmt_state(cfg, g["seed"])
+    dsd = W.synth_decoder_state(512, seed=g["seed"])
+    feats = W.synth_feats(512, seed=g["seed"])
+    r_d = O.sample_rd(fsd, cfg, g["r_s"], g["wa"], g["we"], g["noise"], 10, 2.0, 1.0, 1.0)
+    assert rel_l2(r_d, g["r_d"]) < TOL_REL
+    pick = [int(i) for i in g["pick"]]
+    frames = O.decode_frames(dsd, g["s_r"], r_d[:, pick[:1]], feats)
+    assert max_abs(frames[:, ::7, ::5], g["lattice"][:1]) < 2e-4

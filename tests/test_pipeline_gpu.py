@@ -49,3 +49,28 @@ def test_end_to_end_vs_oracle_short_clip():
     print("e2e: r_d rel-L2 %.3e, frames mean|d| %.3e, PSNR %.1f dB" % (
         e_rd, float((frames.cpu() - ref).abs().mean()), -10 * torch.log10(torch.tensor(mse))))
     assert e_rd < 2e-2 and mse < 1e-4  # PSNR >= 40 dB
+
+
+@pytest.mark.parametrize("fmt_dtype,min_psnr", [("bf16", 30.0), ("fp16", 45.0)])
+def test_config1_golden_end_to_end(fmt_dtype, min_psnr):
+    """BASELINE configs[0] through the HIP path against what the reference itself produced on CPU.
+    The decoder amplifies latent error (a 0.3 % perturbation of r_d moves the flow-warped sampling
+    positions: with these synthetic weights it costs ~25 dB), so the end-to-end frame tolerance is set by
+    the FMT operand type: bf16 operands >= 30 dB, fp16 operands >= 45 dB; r_d itself <= 2e-2 / 4e-3 rel."""
+    from tests.util import golden
+    g = golden("e2e_config1")
+    cfg = pkg.config.FmtConfig()
+    fmt_sd = pkg.weights.synth_fmt_state(cfg, g["seed"])
+    dec_sd = pkg.weights.synth_decoder_state(512, seed=g["seed"])
+    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, "cuda:0", 512, fmt_dtype=fmt_dtype, max_frames=8)
+    feats = pkg.weights.synth_feats(512, seed=g["seed"])
+    frames, r_d = hp.generate(g["r_s"], g["wa"], g["we"], g["s_r"], feats, 10, noise=g["noise"], return_rd=True)
+    e_rd = float((r_d.cpu() - g["r_d"]).norm() / g["r_d"].norm())
+    pick = [int(i) for i in g["pick"]]
+    fr = frames.cpu()[pick]
+    mse = float(((fr[:, ::7, ::5] - g["lattice"]) ** 2).mean())
+    psnr = float(-10 * torch.log10(torch.tensor(mse)))
+    mean_err = float((fr.mean(dim=(1, 2, 3)) - g["mean"]).abs().max())
+    print("config1 %s: r_d rel-L2 %.3e, lattice PSNR %.1f dB, frame-mean err %.2e" % (fmt_dtype, e_rd, psnr, mean_err))
+    assert frames.shape == (25, 512, 512, 3) and mean_err < 2e-3
+    assert e_rd < (2e-2 if fmt_dtype == "bf16" else 4e-3) and psnr >= min_psnr

@@ -255,6 +255,36 @@ def gen_dec(ns, size, seed, n_frames, sparse):
     save("dec_%d" % size, **arrs)
 
 
+def gen_e2e_config1(ns, seed=900):
+    """BASELINE.json configs[0]: 1 s audio -> 25 frames, 512x512, nfe=10 (9 Euler evaluations), fp32, the
+    reference's own sampler (nodes_adv.py:545-694) and decode loop (FLOAT.py:113-169) chained on CPU."""
+    print("[e2e config 1]")
+    cfg = config.FmtConfig()
+    m, fsd, _ = ref_fmt(ns, cfg, seed)
+    d, dsd = ref_dec(ns, 512, seed)
+    feats = weights.synth_feats(512, seed=seed)
+    T = 25
+    wa = torch.nn.functional.silu(rnd(seed + 1, 1, T, cfg.dim_a))
+    we = torch.softmax(rnd(seed + 2, 1, 1, cfg.dim_e), -1)
+    r_s = rnd(seed + 3, 1, cfg.dim_w, std=0.5)
+    s_r = rnd(seed + 4, 1, cfg.dim_w)
+    g = torch.Generator("cpu")
+    g.manual_seed(15)
+    noise = torch.stack([torch.randn(1, 50, cfg.dim_w, generator=g)])
+    g.manual_seed(15)
+    with torch.no_grad():
+        r_d = ns.nodes_adv._perform_ode_sampling_loop(m, r_s, wa, we, T, 10, 50, cfg.dim_w, 10, "euler", 1e-5, 1e-5,
+                                                      torch.device("cpu"), 2.0, 1.0, 1.0, False, g)
+        fake = types.SimpleNamespace(motion_autoencoder=types.SimpleNamespace(dec=d), pbar=types.SimpleNamespace(update=lambda n: None))
+        pick = [0, 12, 24]
+        frames = ns.FLOAT.FLOAT.decode_latent_into_processed_images(fake, s_r, feats, r_d[:, pick])
+    orc_rd = O.sample_rd(fsd, cfg, r_s, wa, we, noise, 10, 2.0, 1.0, 1.0)
+    orc = O.decode_frames(dsd, s_r, orc_rd[:, pick], feats)
+    print("  r_d oracle-ref rel %.3e ; frames oracle-ref max|d| %.3e" % (maxdiff(orc_rd, r_d)[1], maxdiff(orc, frames)[0]))
+    save("e2e_config1", seed=seed, wa=wa, we=we, r_s=r_s, s_r=s_r, noise=noise, r_d=r_d, pick=np.array(pick),
+         lattice=frames[:, ::7, ::5], band=frames[:, 250:258], mean=frames.mean(dim=(1, 2, 3)))
+
+
 def gen_node_surface(ns):
     """Widget/return contracts of the three north-star nodes and the batch/seed schedule of
     FloatProcess.floatprocess (nodes.py:189-222), captured from the reference classes themselves."""
@@ -315,6 +345,9 @@ def main():
     ns = ref_import.load()
     gen_node_surface(ns)
     if os.environ.get("GOLDENS_ONLY") == "nodes":
+        return
+    gen_e2e_config1(ns)
+    if os.environ.get("GOLDENS_ONLY") == "e2e":
         return
     small = config.small_fmt_config()
     full = config.FmtConfig()
