@@ -137,6 +137,11 @@ def main():
             r_loc, (t0, t1), rep = pkg.distributed.sample_window_parallel(
                 hp.fmt, cfg, cond["r_s"], cond["wa"], cond["we"], noise, args.nfe, a_cfg, 1.0, e_cfg, iters=args.window_iters)
             seam.update(rep)
+            if world > 1:  # report the largest seam change over the ranks
+                import torch.distributed as dist
+                t = torch.tensor([rep["seam_rel_change"]], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                seam["seam_rel_change"] = float(t.item())
             return hp.decode(cond["s_r"], None, r_loc)
         fr = (rank * T, (rank + 1) * T) if (args.mode == "shard" and world > 1) else None
         return hp.generate(cond["r_s"], cond["wa"], cond["we"], cond["s_r"], None, args.nfe, a_cfg, 1.0, e_cfg, noise=noise,
@@ -267,7 +272,7 @@ def main():
                        "parallelism": ("replicas x%d (one clip per GPU)" % world) if args.mode == "replicas" or world == 1
                        else ("shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world)
                              if args.mode == "shard" else
-                             "window: one %d-frame clip, windows sharded x%d, boundary all_gather x%d round(s), rank-0 seam change %.3e"
+                             "window: one %d-frame clip, windows sharded x%d, boundary all_gather x%d round(s), max seam change %.3e"
                              % (T_total, world, args.window_iters, seam.get("seam_rel_change", 0.0)))},
         }
         out.update(extra)

@@ -27,3 +27,26 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp")):
                 src = open(os.path.join(base, f)).read()
                 assert "float_oracle" not in src and "from oracle" not in src and "import oracle" not in src, f
+
+
+def test_argument_validation_needs_no_gpu():
+    """Error paths of the C ABI that return before any HIP call: status code + message, no exception across
+    the boundary (the host mirror turns FLOAT_E_INVALID into ValueError)."""
+    import ctypes as C
+    N = pkg.native
+    L = N.lib()
+    h = C.c_void_p()
+    assert L.float_fmt_create(None, None, 0, C.byref(h)) == 1
+    assert b"null argument" in L.float_last_error()
+    cfg = N.FmtCfg(512, 512, 7, 1000, 8, 8, 4000, 10, 50, 2, 0, 0)  # dim_h not a multiple of 256
+    arr = (N.FloatTensor * 1)()
+    assert L.float_fmt_create(C.byref(cfg), arr, 0, C.byref(h)) == 1 and b"dim_h" in L.float_last_error()
+    dcfg = N.DecCfg(100, 512, 0, 8)  # size not a power of two
+    assert L.float_dec_create(C.byref(dcfg), arr, 0, C.byref(h)) == 1 and b"power of two" in L.float_last_error()
+    assert L.float_fmt_sample_next(None, None, None, None) == 1
+    try:
+        N.check(1)
+    except ValueError as e:
+        assert "float_fmt_sample_begin" in str(e)
+    else:
+        raise AssertionError("check(1) must raise ValueError")
