@@ -100,7 +100,7 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
 template <class T, int MTW>
 int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
-  constexpr int smem = MTW * 8 * 1024;
+  constexpr int smem = 2 * MTW * 4 * 1024;
   auto kern = fmt_gemm_wide_kernel<T, MTW>;
   if (prime) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -161,7 +161,7 @@ int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
   X(3, 1, NW, EPI) X(3, 2, NW, EPI) X(3, 4, NW, EPI) X(5, 1, NW, EPI) X(5, 2, NW, EPI) X(5, 4, NW, EPI) X(4, 1, NW, EPI) \
   X(4, 2, NW, EPI) X(6, 2, NW, EPI) X(2, 1, NW, EPI) X(1, 1, NW, EPI)
 #define FMT_FOR_SPLIT(X, EPI) FMT_SPLIT_SHAPES(X, 4, EPI) FMT_SPLIT_SHAPES(X, 8, EPI) FMT_SPLIT_SHAPES(X, 16, EPI)
-#define FMT_FOR_FULL(X, EPI) X(12, 2, 4, EPI) X(15, 2, 4, EPI)
+#define FMT_FOR_FULL(X, EPI) X(12, 2, 4, EPI) X(15, 2, 4, EPI) X(12, 1, 4, EPI) X(15, 1, 4, EPI)
 
 template <class T, int EPI>
 int launch_gemm(const GemmArgs& g, int mtw, int nt, int nw, bool prime, hipStream_t s) {
@@ -188,8 +188,10 @@ void prime_epi() {
   for (auto& c : shapes)
     for (int nw : {4, 8, 16}) (void)launch_gemm<T, EPI>(g, c[0], c[1], nw, true, nullptr);
   if (EPI == EPI_F32 || EPI == EPI_CFG) {
-    (void)launch_gemm<T, EPI>(g, 12, 2, 4, true, nullptr);
-    (void)launch_gemm<T, EPI>(g, 15, 2, 4, true, nullptr);
+    for (int nt : {1, 2}) {
+      (void)launch_gemm<T, EPI>(g, 12, nt, 4, true, nullptr);
+      (void)launch_gemm<T, EPI>(g, 15, nt, 4, true, nullptr);
+    }
   }
 }
 template <class T>
@@ -222,8 +224,8 @@ int pick_nw(int K, int forced) {
 Tiling pick_tiling(int M, int N, int K, bool need_full_rows) {
   const int mt = (M + 15) / 16;
   if (need_full_rows) {
-    if (mt <= 4) return {4, 2, pick_nw(K, 0)};
-    return {mt <= 12 ? 12 : 15, 2, 4};
+    if (mt <= 4) return {4, 1, pick_nw(K, 0)};
+    return {mt <= 12 ? 12 : 15, 1, 4};  // 16 columns per workgroup: twice the workgroups of the 32-column tile
   }
   int split = mt <= 4 ? 4 : (mt <= 12 ? 3 : 5);
   if (mt <= 2) split = mt;
@@ -306,7 +308,7 @@ int run_mod(float_fmt* h, int bc, int step, float* modbuf, hipStream_t s, bool h
   GemmArgs g = base_args(A, h->adaln_all, M);
   g.out_f32 = modbuf;
   g.ldo = h->Ntot;
-  if (g_fmt_wide && g.N % 128 == 0 && g.K % 256 == 0) return launch_wide<T>(g, false, s);
+  if (g_fmt_wide && g.N % 128 == 0 && g.K % 128 == 0) return launch_wide<T>(g, false, s);
   return run_gemm<T, EPI_F32>(g, s);
 }
 

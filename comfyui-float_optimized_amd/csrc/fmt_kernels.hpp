@@ -243,15 +243,18 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
 // the activations per 32-column slab dominates the L2->CU traffic (r01 PMC: 1.8 TB/s of HBM+write
 // traffic, waves 85 % stalled), so A goes through LDS ONCE per workgroup and serves 128 columns:
 //   * the fragment-major HBM image of A is exactly the LDS image a wave wants (1 KiB per fragment,
-//     lane-linear), so it is copied with global_load_lds (no VGPR staging, conflict-free ds_read_b128);
+//     lane-linear: conflict-free ds_read_b128); chunks of 4 k-blocks are double-buffered through
+//     registers so the loads of chunk c+1 fly while chunk c is multiplied;
 //   * the 4 waves own 32 columns each for the whole K (no K split, no LDS reduction); weights stream
 //     straight to registers, non-temporal;
 //   * operands are swapped (D = W_tile * A_tile^T) so a lane holds 4 consecutive columns of one row and
 //     the fp32 result is stored as float4.
 template <class T, int MTW>
 __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
-  constexpr int KCH = 8;  // k-blocks (of 32) per LDS chunk
-  extern __shared__ __attribute__((aligned(16))) unsigned char sA[];  // [MTW][KCH][1 KiB]
+  constexpr int KCH = 4;                   // k-blocks (of 32) per LDS chunk
+  constexpr int NF = MTW * KCH;            // 1-KiB A fragments per chunk
+  constexpr int NFW = (NF + 3) / 4;        // fragments staged by one wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char sA[];  // [2][MTW][KCH][1 KiB]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int nbx = g.N >> 7;
@@ -270,6 +273,7 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
   const int mt0 = by * MTW;
   const int nb0 = bx * 8 + w * 2;  // this wave's two 16-column tiles
   const int KB = g.K >> 5;
+  const int nchunk = KB / KCH;
   const size_t tstride = (size_t)KB * 512;
   const u16* Wp = g.W + (size_t)nb0 * tstride + lane * 8;
   const u16* Ag = g.A + (size_t)mt0 * tstride + lane * 8;
@@ -278,33 +282,57 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < MTW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int kc = 0; kc < KB; kc += KCH) {
-    // this wave copies fragments f = w, w+4, ... of the MTW x KCH chunk (f = i*KCH + kk)
+  // Register-staged software pipeline (all ordinary loads, so hipcc's counted vmcnt waits keep the next
+  // chunk in flight): while chunk c is multiplied out of LDS buffer c&1 and the b registers, the A
+  // fragments and the weights of chunk c+1 are already on their way.
+  u32x4 an[NFW], bn[KCH][2], bc[KCH][2];
+  auto issue = [&](int c) {
+    const int kc = c * KCH;
 #pragma unroll
-    for (int f = 0; f < MTW * KCH / 4; ++f) {
+    for (int f = 0; f < NFW; ++f) {
       const int fi = f * 4 + w;
-      const int i = fi / KCH, kk = fi % KCH;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ag + i * tstride + (size_t)(kc + kk) * 512),
-                                       (__attribute__((address_space(3))) void*)(sA + fi * 1024), 16, 0, 0);
+      if (fi < NF) {
+        const int i = fi / KCH, kk = fi % KCH;
+        an[f] = *reinterpret_cast<const u32x4*>(Ag + i * tstride + (size_t)(kc + kk) * 512);
+      }
     }
-    u32x4 b[KCH][2];
 #pragma unroll
     for (int kk = 0; kk < KCH; ++kk) {
-      b[kk][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + (size_t)(kc + kk) * 512));
-      b[kk][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + tstride + (size_t)(kc + kk) * 512));
+      bn[kk][0] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + (size_t)(kc + kk) * 512));
+      bn[kk][1] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + tstride + (size_t)(kc + kk) * 512));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  };
+  auto commit = [&](int buf) {  // registers -> LDS buffer `buf`, weights -> current set
+#pragma unroll
+    for (int f = 0; f < NFW; ++f) {
+      const int fi = f * 4 + w;
+      if (fi < NF) *reinterpret_cast<u32x4*>(sA + (buf * NF + fi) * 1024 + lane * 16) = an[f];
+    }
+#pragma unroll
+    for (int kk = 0; kk < KCH; ++kk) {
+      bc[kk][0] = bn[kk][0];
+      bc[kk][1] = bn[kk][1];
+    }
+  };
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int c = 0; c < nchunk; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nchunk) issue(c + 1);
 #pragma unroll
     for (int kk = 0; kk < KCH; ++kk) {
 #pragma unroll
       for (int i = 0; i < MTW; ++i) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(sA + (i * KCH + kk) * 1024 + lane * 16);
-        acc[i][0] = T::mfma(b[kk][0], a, acc[i][0]);
-        acc[i][1] = T::mfma(b[kk][1], a, acc[i][1]);
+        const u32x4 a = *reinterpret_cast<const u32x4*>(sA + (buf * NF + i * KCH + kk) * 1024 + lane * 16);
+        acc[i][0] = T::mfma(bc[kk][0], a, acc[i][0]);
+        acc[i][1] = T::mfma(bc[kk][1], a, acc[i][1]);
       }
     }
-    __syncthreads();
+    if (c + 1 < nchunk) {
+      commit(buf ^ 1);  // the other buffer was last read in iteration c-1, and a barrier has passed since
+      __syncthreads();
+    }
   }
   // D[n = q*4 + reg][m = r16]: lane -> row m0 + i*16 + r16, columns n0 + j*16 + q*4 .. +3
 #pragma unroll
