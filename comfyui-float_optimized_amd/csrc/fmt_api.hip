@@ -33,8 +33,10 @@ struct float_fmt {
   float *ccond, *mod, *xres, *xcur, *temb, *ts_dev, *vout;
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
   // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, scales)
+  int method = 0;          // FLOAT_ODE_*
+  float* kbuf = nullptr;   // [4][64][dim_w] stage velocities of the Runge-Kutta solvers
   struct GraphKey {
-    int nfe, bc, we_len;
+    int nfe, bc, we_len, method;
     float a, r, e;
     bool operator<(const GraphKey& o) const {
       return memcmp(this, &o, sizeof(GraphKey)) < 0;
@@ -315,7 +317,8 @@ int run_mod(float_fmt* h, int bc, int step, float* modbuf, hipStream_t s, bool h
 // Block chain of an evaluation on the rows staged in the workspace, using the modulations in modbuf.
 // euler: update xcur/xin16 with dt, else write vout.
 template <class T>
-int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, float a, float r, float e, hipStream_t s) {
+int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, float a, float r, float e, hipStream_t s,
+               float* vout_to = nullptr) {
   const float_fmt_cfg_t& c = h->cfg;
   const int D = h->D, ntok = h->ntok, M = bc * ntok;
   int rc;
@@ -381,7 +384,7 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
       g.xin16 = h->xin16;
       g.ldx = h->Kx / 32;
     } else {
-      g.vout = h->vout;
+      g.vout = vout_to ? vout_to : h->vout;
     }
     if ((rc = run_gemm<T, EPI_CFG>(g, s, true))) return rc;
   }
@@ -461,10 +464,73 @@ int check_common(float_fmt* h, const void* we, int we_len, const void* prev_we) 
   return FLOAT_OK;
 }
 
+// Fixed-grid explicit Runge-Kutta schemes of torchdiffeq's solver list (reference src/nodes/__init__.py:15-23):
+// stage times t0 + c_j dt, stage inputs y0 + dt sum_m a[j][m] k_m, update dt sum_j b_j k_j.  torchdiffeq is not
+// installed where this is built, so these are its published rules (midpoint; "rk4" = the 3/8-rule
+// rk4_alt_step_func; heun2 / heun3 Butcher tableaux) - parity with the package itself is unpinned.
+struct Tableau {
+  int s;
+  float c[4], a[4][3], b[4];
+};
+const Tableau& tableau(int method) {
+  static const Tableau T[5] = {
+      {1, {0.f}, {{0.f}}, {1.f}},                                                                        // euler
+      {2, {0.f, 0.5f}, {{0.f}, {0.5f}}, {0.f, 1.f}},                                                     // midpoint
+      {4, {0.f, 1.f / 3, 2.f / 3, 1.f}, {{0.f}, {1.f / 3}, {-1.f / 3, 1.f}, {1.f, -1.f, 1.f}}, {0.125f, 0.375f, 0.375f, 0.125f}},  // rk4 (3/8)
+      {2, {0.f, 1.f}, {{0.f}, {1.f}}, {0.5f, 0.5f}},                                                     // heun2
+      {3, {0.f, 1.f / 3, 2.f / 3}, {{0.f}, {1.f / 3}, {0.f, 2.f / 3}}, {0.25f, 0.f, 0.75f}},             // heun3
+  };
+  return T[method];
+}
+
+// evaluation times of a window: Euler -> the grid itself; RK -> t_i + c_j (t_{i+1} - t_i), step-major
+void eval_times(int method, const std::vector<float>& grid, std::vector<float>* out) {
+  if (method == FLOAT_ODE_EULER) {
+    *out = grid;
+    return;
+  }
+  const Tableau& tb = tableau(method);
+  out->clear();
+  for (size_t i = 0; i + 1 < grid.size(); ++i) {
+    const float dt = grid[i + 1] - grid[i];
+    for (int j = 0; j < tb.s; ++j) out->push_back(grid[i] + dt * tb.c[j]);
+  }
+  if (out->empty()) out->push_back(0.f);
+}
+int n_evals(int method, int nfe) { return (nfe - 1) * tableau(method).s; }
+
+template <class T>
+int run_window_steps_rk(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
+                        hipStream_t s) {
+  const Tableau& tb = tableau(h->method);
+  const float_fmt_cfg_t& c = h->cfg;
+  const int kstride = 64 * c.dim_w, n = c.n_cur * c.dim_w;
+  const bool hoisted = n_evals(h->method, nfe) <= kScSteps;
+  int rc;
+  for (int i = 0; i < nfe - 1; ++i) {
+    const float dt = ts[i + 1] - ts[i];
+    for (int j = 0; j < tb.s; ++j) {
+      if (j > 0) {
+        hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, j,
+                           dt * tb.a[j][0], dt * tb.a[j][1], dt * tb.a[j][2], 0.f, 0, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
+                           c.dim_w);
+      }
+      if ((rc = run_mod<T>(h, m.bc, i * tb.s + j, h->mod, s, hoisted))) return rc;
+      if ((rc = run_blocks<T>(h, m.bc, h->mod, false, 0.f, a, r, e, s, h->kbuf + (size_t)j * kstride))) return rc;
+    }
+    hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, tb.s,
+                       dt * tb.b[0], dt * tb.b[1], dt * tb.b[2], dt * tb.b[3], 1, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
+                       c.dim_w);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
 // The Euler chain of one window, eager and single-stream (also the profiling path).
 template <class T>
 int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
                      hipStream_t s) {
+  if (h->method != FLOAT_ODE_EULER) return run_window_steps_rk<T>(h, m, nfe, ts, a, r, e, s);
   for (int i = 0; i < nfe - 1; ++i) {
     const float dt = ts[i + 1] - ts[i];
     int rc = run_mod<T>(h, m.bc, i, h->mod, s, nfe - 1 <= kScSteps);
@@ -521,6 +587,7 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
   float_fmt::GraphKey key;
   memset(&key, 0, sizeof(key));
   key.nfe = nfe;
+  key.method = h->method;
   key.bc = m.bc;
   key.we_len = we_len;
   key.a = a;
@@ -532,7 +599,7 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
     if (!h->side_stream) FH_CHECK_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
     FH_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    int rc = h->cfg.use_graph == 2 ? run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream)
+    int rc = (h->cfg.use_graph == 2 || h->method != FLOAT_ODE_EULER) ? run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream)
                                    : capture_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream, h->side_stream);
     hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
     if (rc) {
@@ -556,9 +623,10 @@ int window_impl(float_fmt* h, const float* x0, const float* wa, const float* wr,
   const CfgMode m = cfg_mode(a, r, e, include_r);
   int rc = stage_window<T>(h, m, x0, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s);
   if (rc) return rc;
-  if (nfe - 1 >= 1 && nfe - 1 <= kScSteps) {
+  const int nev = n_evals(h->method, nfe);
+  if (nev >= 1 && nev <= kScSteps) {
     const int M = m.bc * h->ntok;
-    hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * h->D / 8 + 255) / 256, nfe - 1), dim3(256), 0, s, h->sc16, h->temb,
+    hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * h->D / 8 + 255) / 256, nev), dim3(256), 0, s, h->sc16, h->temb,
                        h->ccond, M, h->D, (size_t)h->Mpad * h->D);
   }
   if (nfe <= 1) return FLOAT_OK;  // a one-point grid has no evaluation: the sample is x0 (FLOAT.py:188,247-248)
@@ -590,7 +658,9 @@ int sample_window(float_fmt* h, int k, hipStream_t s) {
   const bool dynamic = J.we_len > 1;
   int rc;
   if (k == 0) {
-    if ((rc = prepare_time<T>(h, J.ts, s))) return rc;
+    std::vector<float> ets;
+    eval_times(h->method, J.ts, &ets);
+    if ((rc = prepare_time<T>(h, ets, s))) return rc;
     // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
     FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)P * c.dim_w * sizeof(float), s));
     FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)P * c.dim_a * sizeof(float), s));
@@ -707,6 +777,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->ccond, (size_t)Mp * D);
   A(&h->mod, (size_t)Mp * h->Ntot);
   A(&h->mod2, (size_t)Mp * h->Ntot);
+  A(&h->kbuf, (size_t)4 * 64 * cfg->dim_w);
   A(&h->xres, (size_t)Mp * D);
   A(&h->xcur, (size_t)cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
@@ -776,7 +847,7 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
   int rc = check_common(h, we, we_len, prev_we);
   if (rc) return rc;
   FH_REQUIRE(x0 && wa && wr && we && prev_x && prev_wa && out, "null tensor argument to float_fmt_sample_chunk");
-  FH_REQUIRE(nfe >= 1 && nfe <= kMaxSteps, "nfe=%d out of range [1,%d]", nfe, kMaxSteps);
+  FH_REQUIRE(nfe >= 1 && n_evals(h->method, nfe) < kMaxSteps, "nfe=%d: too many evaluations (max %d)", nfe, kMaxSteps);
   hipStream_t s = (hipStream_t)stream;
   std::vector<float> ts;
   linspace01(nfe, &ts);
@@ -792,15 +863,24 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
   }
   const float* we_p = we_len > 1 ? h->we_c : we;
   const float* pwe_p = we_len > 1 ? h->prev_we : nullptr;
+  std::vector<float> ets;
+  eval_times(h->method, ts, &ets);
   if (c.dtype == FLOAT_DT_BF16) {
-    if ((rc = prepare_time<BF16>(h, ts, s))) return rc;
+    if ((rc = prepare_time<BF16>(h, ets, s))) return rc;
     rc = window_impl<BF16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
   } else {
-    if ((rc = prepare_time<FP16>(h, ts, s))) return rc;
+    if ((rc = prepare_time<FP16>(h, ets, s))) return rc;
     rc = window_impl<FP16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
   }
   if (rc) return rc;
   FH_CHECK_HIP(hipMemcpyAsync(out, h->xcur, (size_t)c.n_cur * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
+  return FLOAT_OK;
+}
+
+int float_fmt_set_method(float_fmt_t* h, int32_t method) {
+  FH_REQUIRE(h != nullptr, "null FMT handle");
+  FH_REQUIRE(method >= FLOAT_ODE_EULER && method <= FLOAT_ODE_HEUN3, "unknown ODE method %d", method);
+  h->method = method;
   return FLOAT_OK;
 }
 
@@ -813,7 +893,7 @@ int float_fmt_sample_begin(float_fmt_t* h, const float* wr, const float* wa, int
   FH_REQUIRE(we_len == 1 || we_len == T,
              "Dynamic emotion latent `we` time dimension (%d) does not match audio latent `wa` time dimension (%d).",
              we_len, T);
-  FH_REQUIRE(nfe >= 1 && nfe <= kMaxSteps, "nfe=%d out of range [1,%d]", nfe, kMaxSteps);
+  FH_REQUIRE(nfe >= 1 && n_evals(h->method, nfe) < kMaxSteps, "nfe=%d: too many evaluations (max %d)", nfe, kMaxSteps);
   auto& J = h->job;
   J.wr = wr;
   J.wa = wa;

@@ -576,6 +576,23 @@ __global__ void fmt_init_x_kernel(float* __restrict__ xcur, u16* __restrict__ xi
   xin16[fmt_pack_off(i, c, ldx)] = T::from_float(v);
 }
 
+// Explicit Runge-Kutta glue for the non-Euler fixed-grid solvers: y = xcur + sum_m coef[m] * k_m over the
+// current-window rows (coef already includes dt).  final = 0: y is the next stage's input (packed 16-bit
+// rows of the x_embedder operand); final = 1: y becomes the new state and the next step's stage-0 input.
+template <class T>
+__global__ void fmt_rk_combine_kernel(float* __restrict__ xcur, const float* __restrict__ kbuf, int kstride, int nk, float c0,
+                                      float c1, float c2, float c3, int final, u16* __restrict__ xin16, int ldx, int n_prev,
+                                      int n_cur, int W) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_cur * W) return;
+  const int i = idx / W, c = idx % W;
+  const float cf[4] = {c0, c1, c2, c3};
+  float y = xcur[idx];
+  for (int m = 0; m < nk; ++m) y += cf[m] * kbuf[(size_t)m * kstride + (size_t)(n_prev + i) * W + c];
+  if (final) xcur[idx] = y;
+  xin16[fmt_pack_off(n_prev + i, c, ldx)] = T::from_float(y);
+}
+
 // Window slice with replicate padding along time (FLOAT.py:224-227): dst[i] = src[min(t0+i, T-1)].
 __global__ void fmt_slice_pad_kernel(float* __restrict__ dst, const float* __restrict__ src, int t0, int T, int n, int dim) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;

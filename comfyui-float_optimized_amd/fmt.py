@@ -32,6 +32,13 @@ class FlowMatchingTransformerHIP:
         self._h = h
         del keep
 
+    def set_method(self, name):
+        """torchdiffeq fixed-grid method name: euler | midpoint | rk4 | heun2 | heun3 (base_options.py:50)."""
+        if name not in native.ODE_METHODS:
+            raise ValueError("unknown fixed-step ODE method %r (known: %s)" % (name, ", ".join(native.ODE_METHODS)))
+        native.check(native.lib().float_fmt_set_method(self._h, native.ODE_METHODS[name]))
+        self.method = name
+
     def close(self):
         if getattr(self, "_h", None):
             native.lib().float_fmt_destroy(self._h)

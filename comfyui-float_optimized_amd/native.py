@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfloat_hip.so")
 
 FLOAT_DT_BF16, FLOAT_DT_FP16 = 0, 1
+ODE_METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "heun2": 3, "heun3": 4}
 DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16}
 
 
@@ -40,6 +41,7 @@ _SIGNATURES = {
     "float_stream_destroy": (C.c_int, [C.c_void_p]),
     "float_fmt_create": (C.c_int, [C.POINTER(FmtCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_fmt_destroy": (None, [C.c_void_p]),
+    "float_fmt_set_method": (C.c_int, [C.c_void_p, C.c_int32]),
     "float_fmt_eval": (C.c_int, [C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 +
                        [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "float_fmt_sample_chunk": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 +

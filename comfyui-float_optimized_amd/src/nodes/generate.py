@@ -47,6 +47,7 @@ class InferenceAgent:
         self.G = FloatHotPath(parts["fmt"], parts["dec"], self.cfg, self.rank, opt.input_size,
                               fmt_dtype=os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
                               dec_dtype=os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"))
+        self.G.fmt.set_method(getattr(opt, "torchdiffeq_ode_method", "euler"))
         self.direction_q = host_models.direction_basis(parts["dec"], self.rank)
         self.audio_encoder = parts["audio_encoder"].to(self.rank)
         self.emotion_predictor = parts.get("emotion_predictor")  # callable(a) -> (1,7) scores, optional

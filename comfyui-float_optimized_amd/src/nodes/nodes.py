@@ -59,9 +59,9 @@ class LoadFloatModels:
                     setattr(opt, key, value)
                 else:
                     main_logger.warning("opt_instance has no attribute '%s' from advanced_float_options.", key)
-        if opt.torchdiffeq_ode_method != "euler":
-            raise ValueError("the MI355X hot path implements the fixed-grid 'euler' solver only (got %r)"
-                             % opt.torchdiffeq_ode_method)
+        from . import TORCHDIFFEQ_FIXED_STEP_SOLVERS
+        if opt.torchdiffeq_ode_method not in TORCHDIFFEQ_FIXED_STEP_SOLVERS:
+            raise ValueError("unknown fixed-step ODE method %r" % (opt.torchdiffeq_ode_method,))
         opt.rank = torch.device(target_device)
         opt.cudnn_benchmark = cudnn_benchmark  # accepted for graph compatibility; MIOpen is not on this path
         opt.ckpt_path = os.path.join(_MODELS_DIR, "float", model)

@@ -72,6 +72,12 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
                      float_fmt_t** out);
 void float_fmt_destroy(float_fmt_t* h);
 
+/* Fixed-grid solver of the sampling calls, the reference's TORCHDIFFEQ_FIXED_STEP_SOLVERS list
+ * (src/nodes/__init__.py:15-23; options/base_options.py:50).  Default FLOAT_ODE_EULER (fused update in the last
+ * GEMM's epilogue); the Runge-Kutta schemes evaluate the field s times per step (2/4/2/3). */
+enum { FLOAT_ODE_EULER = 0, FLOAT_ODE_MIDPOINT = 1, FLOAT_ODE_RK4 = 2, FLOAT_ODE_HEUN2 = 3, FLOAT_ODE_HEUN3 = 4 };
+int float_fmt_set_method(float_fmt_t* h, int32_t method);
+
 /* forward_with_cfv (FMT.py:342-401), B = 1.
  *   x, wa: (n_cur, dim)   wr: (dim_w)   we: (we_len, dim_e) with we_len 1 (static) or n_cur
  *   prev_x, prev_wa: (n_prev, dim)   prev_we: (n_prev, dim_e) - required iff we_len > 1

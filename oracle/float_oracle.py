@@ -158,15 +158,44 @@ def euler_grid(nfe, dtype=torch.float32):
 
 
 def sample_chunk(sd, cfg, x0, wa_c, wr, we_c, prev_x, prev_wa, prev_we, nfe,
-                 a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg=False, dtype=torch.float32):
-    """Fixed-grid Euler over one 50-frame window (FLOAT.py:229-248, nodes_adv.py:629-659)."""
+                 a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg=False, dtype=torch.float32, method="euler"):
+    """Fixed-grid solve over one 50-frame window (FLOAT.py:229-248, nodes_adv.py:629-659).
+    `method`: torchdiffeq's fixed-step list (src/nodes/__init__.py:15-23).  torchdiffeq is absent here, so its
+    published step rules are restated (parity with the package unpinned): euler; midpoint; rk4 = the 3/8-rule
+    `rk4_alt_step_func`; heun2 / heun3 = their Butcher tableaux."""
     ts = euler_grid(nfe, dtype)
     x = x0.to(dtype)
     P = cfg.num_prev_frames
+
+    def f(t, y):
+        return fmt_forward_cfv(sd, cfg, t.reshape(1), y, wa_c, wr, we_c, prev_x, prev_wa, prev_we,
+                               a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg, dtype)[:, P:]
+
     for i in range(nfe - 1):
-        v = fmt_forward_cfv(sd, cfg, ts[i].reshape(1), x, wa_c, wr, we_c, prev_x, prev_wa, prev_we,
-                            a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg, dtype)[:, P:]
-        x = x + (ts[i + 1] - ts[i]) * v
+        t0, t1 = ts[i], ts[i + 1]
+        dt = t1 - t0
+        if method == "euler":
+            x = x + dt * f(t0, x)
+        elif method == "midpoint":
+            k1 = f(t0, x)
+            x = x + dt * f(t0 + 0.5 * dt, x + k1 * (0.5 * dt))
+        elif method == "rk4":
+            k1 = f(t0, x)
+            k2 = f(t0 + dt / 3, x + dt * k1 / 3)
+            k3 = f(t0 + dt * 2 / 3, x + dt * (k2 - k1 / 3))
+            k4 = f(t1, x + dt * (k1 - k2 + k3))
+            x = x + (k1 + 3 * (k2 + k3) + k4) * dt * 0.125
+        elif method == "heun2":
+            k1 = f(t0, x)
+            k2 = f(t0 + dt, x + dt * k1)
+            x = x + dt * (0.5 * k1 + 0.5 * k2)
+        elif method == "heun3":
+            k1 = f(t0, x)
+            k2 = f(t0 + dt / 3, x + dt * k1 / 3)
+            k3 = f(t0 + dt * 2 / 3, x + dt * (k2 * 2 / 3))
+            x = x + dt * (0.25 * k1 + 0.75 * k3)
+        else:
+            raise ValueError("unknown fixed-step method %r" % (method,))
     return x
 
 
@@ -178,7 +207,7 @@ def pad_replicate(a, length):
 
 
 def sample_rd(sd, cfg, r_s, wa, we, noise, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0,
-              include_r_cfg=False, dtype=torch.float32):
+              include_r_cfg=False, dtype=torch.float32, method="euler"):
     """The auto-regressive chunk loop (FLOAT.py:209-253; nodes_adv.py:578-694).
     r_s (B,512); wa (B,T,512); we (B,1,7) static or (B,T,7) dynamic; noise (n_chunks,B,50,512)
     is the explicit stand-in for the sequential torch.randn draws (FLOAT.py:215).
@@ -196,7 +225,7 @@ def sample_rd(sd, cfg, r_s, wa, we, noise, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0
         we_c = pad_replicate(we[:, k * L:(k + 1) * L].to(dtype), L) if dynamic else we.to(dtype)
         xs = sample_chunk(sd, cfg, noise[k], wa_c, r_s.to(dtype), we_c, prev_x, prev_wa,
                           prev_we if dynamic else None, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale,
-                          include_r_cfg, dtype)
+                          include_r_cfg, dtype, method)
         out.append(xs)
         prev_x, prev_wa = xs[:, -P:], wa_c[:, -P:]
         if dynamic:

@@ -68,3 +68,27 @@ def test_sixty_second_clip_properties():
     assert frames.shape == (1500, 64, 64, 3) and torch.isfinite(frames).all()
     assert float(frames.min()) >= 0 and float(frames.max()) <= 1
     assert torch.equal(r_d[:, :250], short)
+
+
+@pytest.mark.parametrize("method", ["midpoint", "rk4", "heun2", "heun3"])
+def test_other_fixed_step_solvers(method):
+    """The other entries of the reference's solver dropdown (src/nodes/__init__.py:15-23) against the oracle's
+    restatement of the same published step rules; two windows so the AR hand-off is covered."""
+    cfg = pkg.config.small_fmt_config()
+    sd = pkg.weights.synth_fmt_state(cfg, seed=41)
+    m = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", "fp16")
+    m.set_method(method)
+    T = 80
+    c = pkg.pipeline.synth_conditions(cfg, T, seed=6)
+    noise = pkg.fmt.draw_noise(2, 1, cfg, seed=15)
+    got = m.sample(c["r_s"], c["wa"], c["we"], noise, 4, 2.0, 1.0, 1.0).cpu()
+    ref = O.sample_rd(sd, cfg, c["r_s"], c["wa"], c["we"], noise, 4, 2.0, 1.0, 1.0, method=method)
+    eul = O.sample_rd(sd, cfg, c["r_s"], c["wa"], c["we"], noise, 4, 2.0, 1.0, 1.0)
+    err = rel_l2(got, ref)
+    print(method, "rel-L2 %.3e (vs euler %.3e)" % (err, rel_l2(got, eul)))
+    assert err < 4e-3 and rel_l2(got, eul) > 5 * err   # matches its own scheme, and is not Euler
+    m.set_method("euler")
+    back = m.sample(c["r_s"], c["wa"], c["we"], noise, 4, 2.0, 1.0, 1.0).cpu()
+    assert rel_l2(back, eul) < 4e-3
+    with pytest.raises(ValueError):
+        m.set_method("dopri5")

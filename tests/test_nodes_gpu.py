@@ -55,4 +55,4 @@ def test_float_process_errors(pipe):
         node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", True, 7)   # needs the face detector
     with pytest.raises(ValueError):
         pkg.NODE_CLASS_MAPPINGS["LoadFloatModelsOpt"]().loadmodel("x.safetensors", "cuda:0", False,
-                                                                  {"torchdiffeq_ode_method": "rk4"})
+                                                                  {"torchdiffeq_ode_method": "dopri5"})
