@@ -50,7 +50,10 @@ class InferenceAgent:
         self.G.fmt.set_method(getattr(opt, "torchdiffeq_ode_method", "euler"))
         self.direction_q = host_models.direction_basis(parts["dec"], self.rank)
         self.audio_encoder = parts["audio_encoder"].to(self.rank)
-        self.emotion_predictor = parts.get("emotion_predictor")  # callable(a) -> (1,7) scores, optional
+        ser = parts.get("emotion_encoder")
+        self.emotion_encoder = ser.to(self.rank) if ser is not None else None
+        # callable(a) -> (1,7) softmax scores; None disables emotion="none" (speech-to-emotion)
+        self.emotion_predictor = self.emotion_encoder.predict_emotion if ser is not None else parts.get("emotion_predictor")
 
     # ------------------------------------------------------------------ weights
     @staticmethod
@@ -68,6 +71,12 @@ class InferenceAgent:
             main_logger.warning("wav2vec2 keys missing from checkpoint: %s", missing.missing_keys[:5])
         enc.audio_projection.load_state_dict(parts["proj"], strict=True)
         parts["audio_encoder"] = enc
+        if parts["ser"]:
+            ser = host_models.EmotionHost()
+            miss = ser.load_state_dict(parts["ser"], strict=False)
+            if miss.missing_keys:
+                main_logger.warning("emotion encoder keys missing from checkpoint: %s", miss.missing_keys[:5])
+            parts["emotion_encoder"] = ser
         return parts
 
     @staticmethod
@@ -81,7 +90,8 @@ class InferenceAgent:
                                num_conv_pos_embedding_groups=4)
         return dict(enc=weights.synth_encoder_state(opt.input_size, seed=seed), dec=weights.synth_decoder_state(opt.input_size, seed=seed),
                     fmt=weights.synth_fmt_state(cfg, seed=seed),
-                    audio_encoder=host_models.AudioEncoderHost(small, dim_w=opt.dim_w))
+                    audio_encoder=host_models.AudioEncoderHost(small, dim_w=opt.dim_w),
+                    emotion_encoder=host_models.EmotionHost(small))
 
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
@@ -100,8 +110,8 @@ class InferenceAgent:
         if emo is None or str(emo).lower() == "none":
             if self.emotion_predictor is None:
                 raise NotImplementedError(
-                    "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198); that encoder is "
-                    "outside this build (SURVEY.md 8f) - pick an emotion or attach agent.emotion_predictor")
+                    "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198) but the checkpoint has "
+                    "no `emotion_encoder.wav2vec2_for_emotion.` weights - pick an emotion or attach agent.emotion_predictor")
             we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
         else:
             we = host_models.emotion_one_hot(emo, self.rank)

@@ -49,8 +49,13 @@ def test_float_process_end_to_end(pipe):
 def test_float_process_errors(pipe):
     img, audio = _inputs()
     node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    # emotion="none" = speech-to-emotion through the host-side SER encoder (FLOAT.py:196-198)
+    s2e, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "none", False, 7)
+    assert s2e.shape == (25, 512, 512, 3) and torch.isfinite(s2e).all()
+    saved, pipe.emotion_predictor = pipe.emotion_predictor, None
     with pytest.raises(NotImplementedError):
-        node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "none", False, 7)   # needs the SER encoder
+        node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "none", False, 7)   # no SER weights in the checkpoint
+    pipe.emotion_predictor = saved
     with pytest.raises(NotImplementedError):
         node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", True, 7)   # needs the face detector
     with pytest.raises(ValueError):
