@@ -384,16 +384,40 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   const Styled& c2 = h->convs[2 + 2 * li];
   const int R = L.R, Ri = R / 2;
   int rc;
-  // transposed conv (stride 2) as four parity-class convolutions into z (R+1 x R+1), demodulated
-  size_t t0 = 0;
-  for (int pu = 0; pu < 2; ++pu)
-    for (int pv = 0; pv < 2; ++pv) {
-      const ClassTaps c = class_taps(pu, pv);
-      if ((rc = launch_conv<T>(x_in, Ri, Ri, up, up.W + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Zb, Ri + 1 - pu, Ri + 1 - pv,
-                               R + 1, R + 1, 2, 2, pu, pv, n, demod + up.demod_off, h->Dtot, nullptr, 0, nullptr, 0, st)))
-        return rc;
-      t0 += c.n;
-    }
+  // transposed conv (stride 2) into z (R+1 x R+1), demodulated: all four parity classes in one launch when
+  // the (m, n) grid is at least one 16x16 block, else class by class through the generic kernel
+  static const bool fuse_z = !getenv("FLOAT_DEC_NO_ZFUSE");
+  if (Ri + 1 > 8 && up.cout % 32 == 0 && fuse_z) {
+    ConvArgs z;
+    memset(&z, 0, sizeof(z));
+    z.X = x_in;
+    z.Wt = up.W;
+    z.Y = Zb;
+    z.demod = demod + up.demod_off;
+    z.F = n;
+    z.Hi = z.Wi = Ri;
+    z.Cin = up.cin;
+    z.Cout = up.cout;
+    z.OH = z.OW = R + 1;
+    z.ldd = h->Dtot;
+    z.tiles_x = z.tiles_y = (Ri + 1 + 15) / 16;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = fh_prof_pair(1, &e0, &e1);
+    dim3 grid(z.tiles_x * z.tiles_y * n, up.cout / 32);
+    const size_t smem = 17 * 17 * 64 + 9 * 32 * 64;
+    if (prof) hipExtLaunchKernelGGL((dec_zconv4_kernel<T>), grid, dim3(256), smem, st, e0, e1, 0, z);
+    else hipLaunchKernelGGL((dec_zconv4_kernel<T>), grid, dim3(256), smem, st, z);
+  } else {
+    size_t t0 = 0;
+    for (int pu = 0; pu < 2; ++pu)
+      for (int pv = 0; pv < 2; ++pv) {
+        const ClassTaps c = class_taps(pu, pv);
+        if ((rc = launch_conv<T>(x_in, Ri, Ri, up, up.W + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Zb, Ri + 1 - pu, Ri + 1 - pv,
+                                 R + 1, R + 1, 2, 2, pu, pv, n, demod + up.demod_off, h->Dtot, nullptr, 0, nullptr, 0, st)))
+          return rc;
+        t0 += c.n;
+      }
+  }
   // FIR blur + bias + lrelu, scaled by conv2's style
   {
     const size_t tot = (size_t)n * R * (R / 4) * (up.cout / 8);

@@ -428,6 +428,144 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
   }
 }
 
+// All four parity classes of the stride-2 transposed conv in ONE launch (styledecoder.py:250-257): output
+// row u = 2m + pu takes kernel rows (ky=2, y=m-1),(ky=0, y=m) for pu = 0 and (ky=1, y=m) for pu = 1 (same in
+// x), so the classes read the SAME 17x17 input halo of a 16x16 block of (m, n) positions.  One staging of
+// the halo and of the 9 tap matrices feeds 4 + 2 + 2 + 1 tap products; the separate-launch version staged
+// the halo four times for a quarter of the MFMA work each (r01: 165 TFLOP/s vs 530-810 for the 3x3 convs).
+// Weights: [9][Cout][Cin] in class order (0,0),(0,1),(1,0),(1,1), taps by ascending (dy, dx).
+template <class T>
+__global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
+  constexpr int NT = 2, BN = 32, HW = 17, NPIX = HW * HW, NTAPS = 9;
+  constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;              // [17*17][64 B], chunk-swizzled
+  unsigned char* sB = smem + NPIX * 64;  // [9][BN][64 B], chunk-swizzled
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  // swizzled LDS offsets of the four distinct input shifts (dy, dx) in {-1,0}^2, two per register
+  unsigned aaddr[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int mrow = (w * 4 + mt), x = r16;  // position (m = tile_y*16 + mrow, n = tile_x*16 + x)
+#pragma unroll
+    for (int sh = 0; sh < 4; ++sh) {
+      const int P = (mrow + (sh >> 1)) * HW + x + (sh & 1);  // halo origin is (m-1, n-1)
+      const unsigned off = (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4));
+      if (sh & 1) aaddr[mt][sh >> 1] |= off << 16;
+      else aaddr[mt][sh >> 1] = off;
+    }
+  }
+  const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);
+  const int tiles_pf = g.tiles_x * g.tiles_y;
+  const int tile = blockIdx.x;
+  const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
+  const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+  const int n0 = blockIdx.y * BN;
+  const int nchunks = g.Cin >> 5;
+  const int iy0 = ty * 16 - 1, ix0 = tx * 16 - 1;
+
+  f32x4 acc[4][4][NT];  // [class][m-tile][n-tile]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[NA], rb[NB];
+  auto issue = [&](int chunk) {
+    const int c0 = chunk << 5;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
+      ra[i] = u32x4{0u, 0u, 0u, 0u};
+      if (p < NPIX) {
+        const int hy = p / HW, hx = p - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
+          ra[i] = *reinterpret_cast<const u32x4*>(g.X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + i * 256;
+      if (e < NBC) {
+        const int row = e >> 2, ch = e & 3;
+        const int tap = row / BN, n = row - tap * BN;
+        rb[i] = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+      }
+    }
+  };
+  issue(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
+      if (p < NPIX) *reinterpret_cast<u32x4*>(sA + p * 64 + ((ch ^ ((p >> 1) & 3)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + i * 256;
+      if (e < NBC) {
+        const int row = e >> 2, ch = e & 3;
+        *reinterpret_cast<u32x4*>(sB + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = rb[i];
+      }
+    }
+    __syncthreads();
+    if (chunk + 1 < nchunks) issue(chunk + 1);
+    // input shift sh = 2*(dy+1) + (dx+1): 0 (-1,-1)  1 (-1,0)  2 (0,-1)  3 (0,0); the A fragments of one shift
+    // serve every (class, tap) that reads it: class 0 taps 0..3 = sh 0..3; class 1 (pv=1) taps 4,5 = sh 1,3;
+    // class 2 (pu=1) taps 6,7 = sh 2,3; class 3 tap 8 = sh 3
+    constexpr int kNum[4] = {1, 2, 2, 4};
+    constexpr int kTap[4][4] = {{0, 0, 0, 0}, {1, 4, 0, 0}, {2, 6, 0, 0}, {3, 5, 7, 8}};
+    constexpr int kCls[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 1, 2, 3}};
+#pragma unroll
+    for (int sh = 0; sh < 4; ++sh) {
+      u32x4 a[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        a[mt] = *reinterpret_cast<const u32x4*>(sA + ((sh & 1) ? (aaddr[mt][sh >> 1] >> 16) : (aaddr[mt][sh >> 1] & 0xffffu)));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < kNum[sh]) {
+          const int t = kTap[sh][u], c = kCls[sh][u];
+          u32x4 b[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + baddr + (t * BN + j * 16) * 64);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[c][mt][j] = T::mfma(b[j], a[mt], acc[c][mt][j]);
+        }
+      }
+    }
+  }
+  // epilogue: z[f][2m+pu][2n+pv][co] = acc * demod, for the positions that exist (u, v <= R = OH-1)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int mpos = ty * 16 + w * 4 + mt, npos = tx * 16 + r16;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int u = 2 * mpos + (c >> 1), v = 2 * npos + (c & 1);
+      if (u >= g.OH || v >= g.OW) continue;
+      u16* yp = g.Y + ((size_t)(f * g.OH + u) * g.OW + v) * g.Cout;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + q * 4;
+        const float4 d = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + co);
+        ushort4 o;
+        o.x = T::from_float(acc[c][mt][j][0] * d.x);
+        o.y = T::from_float(acc[c][mt][j][1] * d.y);
+        o.z = T::from_float(acc[c][mt][j][2] * d.z);
+        o.w = T::from_float(acc[c][mt][j][3] * d.w);
+        *reinterpret_cast<ushort4*>(yp + co) = o;
+      }
+    }
+  }
+}
+
 // Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4) over the
 // transposed-conv output z (R+1 x R+1), then + bias, leaky-relu*sqrt2, and the style of the next
 // conv (styledecoder.py:209-213,255-258 then 320-325).  A thread makes 4 consecutive pixels x 8
