@@ -420,7 +420,7 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   }
   // FIR blur + bias + lrelu, scaled by conv2's style
   {
-    const size_t tot = (size_t)n * R * (R / 4) * (up.cout / 8);
+    const size_t tot = (size_t)n * (R / 2) * (R / 4) * (up.cout / 8);
     hipLaunchKernelGGL((dec_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Zb, U, n, R, up.cout, up.abias,
                        styles + c2.style_off, h->Stot);
   }

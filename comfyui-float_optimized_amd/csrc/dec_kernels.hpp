@@ -568,31 +568,33 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
 
 // Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4) over the
 // transposed-conv output z (R+1 x R+1), then + bias, leaky-relu*sqrt2, and the style of the next
-// conv (styledecoder.py:209-213,255-258 then 320-325).  A thread makes 4 consecutive pixels x 8
-// channels: 4 rows x 7 columns of z are read once (7 loads per output instead of 16) and filtered
-// separably (horizontal per row, then vertical).
+// conv (styledecoder.py:209-213,255-258 then 320-325).  A thread makes a 2 (rows) x 4 (pixels) x 8
+// (channels) block: 5 rows x 7 columns of z are read once (4.4 loads per output instead of 16), each
+// row is filtered horizontally once and feeds both output rows (18 VALU per output element, was 31).
 template <class T>
 __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z, u16* __restrict__ out, int F, int R, int C,
                                                        const float* __restrict__ bias, const float* __restrict__ snext, int lds) {
-  const int c8 = C >> 3, xq = R >> 2;
+  const int c8 = C >> 3, xq = R >> 2, yh = R >> 1;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (size_t)F * R * xq * c8) return;
+  if (idx >= (size_t)F * yh * xq * c8) return;
   const int cg = (int)(idx % c8);
   size_t p = idx / c8;
   const int X0 = (int)(p % xq) * 4;
   p /= xq;
-  const int Y = (int)(p % R);
-  const int f = (int)(p / R);
+  const int Y0 = (int)(p % yh) * 2;
+  const int f = (int)(p / yh);
   const int Z = R + 1;
   const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-  float acc[4][8];
+  float acc[2][4][8];
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int y = 0; y < 2; ++y)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = 0.f;
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int zy = Y + a - 1;
+      for (int i = 0; i < 8; ++i) acc[y][j][i] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 5; ++a) {  // z rows Y0-1 .. Y0+3
+    const int zy = Y0 + a - 1;
     if (zy < 0 || zy > R) continue;
     uint4 u[7];
 #pragma unroll
@@ -601,19 +603,35 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
       u[b] = (zx >= 0 && zx <= R) ? *reinterpret_cast<const uint4*>(z + ((size_t)(f * Z + zy) * Z + zx) * C + cg * 8)
                                   : uint4{0u, 0u, 0u, 0u};
     }
+    float h[4][8];  // horizontal FIR of this row for the 4 output columns
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h[j][i] = 0.f;
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
       const u16* e = reinterpret_cast<const u16*>(&u[b]);
       float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = T::to_float(e[i]) * k1[a];
+      for (int i = 0; i < 8; ++i) v[i] = T::to_float(e[i]);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int t = b - j;  // horizontal tap index for output j
+        const int t = b - j;
         if (t >= 0 && t < 4) {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) acc[j][i] += k1[t] * v[i];
+          for (int i = 0; i < 8; ++i) h[j][i] += k1[t] * v[i];
         }
+      }
+    }
+    // row a contributes to output row y with vertical tap a - y
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      const int t = a - y;
+      if (t >= 0 && t < 4) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[y][j][i] += k1[t] * h[j][i];
       }
     }
   }
@@ -624,13 +642,15 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
     sn[i] = snext[(size_t)f * lds + cg * 8 + i];
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint4 o;
-    u16* oe = reinterpret_cast<u16*>(&o);
+  for (int y = 0; y < 2; ++y)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) oe[i] = T::from_float(fh_lrelu_s2(acc[j][i] + bs[i]) * sn[i]);
-    *reinterpret_cast<uint4*>(out + ((size_t)(f * R + Y) * R + X0 + j) * C + cg * 8) = o;
-  }
+    for (int j = 0; j < 4; ++j) {
+      uint4 o;
+      u16* oe = reinterpret_cast<u16*>(&o);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) oe[i] = T::from_float(fh_lrelu_s2(acc[y][j][i] + bs[i]) * sn[i]);
+      *reinterpret_cast<uint4*>(out + ((size_t)(f * R + Y0 + y) * R + X0 + j) * C + cg * 8) = o;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
