@@ -104,9 +104,11 @@ struct FP16 {
 __device__ __forceinline__ float fh_silu(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float fh_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }
 __device__ __forceinline__ float fh_gelu_tanh(float x) {
+  // 0.5 x (1 + tanh(u)) == x * sigmoid(2u): one v_exp + one v_rcp instead of libm tanhf (which cost the
+  // fc1 epilogue 1.4 us per launch); exp overflow -> rcp(inf) = 0 -> 0, underflow -> x, both the right limits
   const float k0 = 0.7978845608028654f;  // sqrt(2/pi)
-  float u = k0 * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.f + tanhf(u));
+  const float u = k0 * (x + 0.044715f * x * x * x);
+  return x * __frcp_rn(1.f + __expf(-2.f * u));
 }
 __device__ __forceinline__ float fh_lrelu_s2(float x) {  // leaky_relu(x, 0.2) * sqrt(2)
   return (x > 0.f ? x : 0.2f * x) * 1.4142135623730951f;

@@ -31,6 +31,7 @@ struct float_fmt {
   // workspace
   u16 *cond16, *sc16, *h16, *qkv16, *att16, *hid16, *xin16, *tsin16, *th16;
   float *ccond, *mod, *xres, *xcur, *temb, *ts_dev, *vout;
+  float* slab = nullptr;  // [4][Mpad][D] split-K partial sums (EPI_PARTIAL)
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
   // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, scales)
   int method = 0;          // FLOAT_ODE_*
@@ -148,7 +149,8 @@ int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
   }
   const int mt_total = (g.M + 15) / 16;
   g.mblk = (mt_total + MTW - 1) / MTW;
-  dim3 grid((g.N / (NT * 16)) * g.mblk);
+  if (EPI != EPI_PARTIAL || g.ksplit < 1) g.ksplit = 1;
+  dim3 grid((g.N / (NT * 16)) * g.mblk * g.ksplit);
   hipEvent_t e0, e1;
   if (fh_prof_pair(0, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, e0, e1, 0, g);
   else hipLaunchKernelGGL(kern, grid, dim3(NW * 64), smem, s, g);
@@ -167,7 +169,7 @@ int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
 
 template <class T, int EPI>
 int launch_gemm(const GemmArgs& g, int mtw, int nt, int nw, bool prime, hipStream_t s) {
-  if (!prime && (g.N % (nt * 16) || g.K % (32 * nw))) {
+  if (!prime && (g.N % (nt * 16) || g.K % (32 * nw * ((EPI == EPI_PARTIAL && g.ksplit > 1) ? g.ksplit : 1)))) {
     fh_set_error("gemm shape N=%d K=%d not tileable by %d columns / %d waves", g.N, g.K, nt * 16, nw);
     return FLOAT_E_INVALID;
   }
@@ -205,6 +207,7 @@ void prime_kernels() {
   prime_epi<T, EPI_GATE_RES>();
   prime_epi<T, EPI_XEMBED>();
   prime_epi<T, EPI_CFG>();
+  prime_epi<T, EPI_PARTIAL>();
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   (void)launch_wide<T>(g, true, nullptr);
@@ -272,13 +275,42 @@ int run_gemm(const GemmArgs& g, hipStream_t s, bool need_full_rows = false) {
   return launch_gemm<T, EPI>(g, t.mtw, t.nt, t.nw, false, s);
 }
 
+// Split-K GEMM whose gated residual add happens in the next LayerNorm launch (EPI_PARTIAL + LnRed).
+// The tiling is the one a GEMM with ksplit * N columns and K / ksplit would get: same workgroup
+// count, a fraction of the activation bytes per workgroup.
+int g_fmt_fc2_split = 4;   // FLOAT_FMT_FC2_SPLIT: K slices of mlp.fc2 (0 = in-GEMM gate*residual epilogue)
+int g_fmt_proj_split = 0;  // FLOAT_FMT_PROJ_SPLIT: same for attn.proj
+struct PendingRed {
+  int ks = 0;
+  LnRed red{};
+};
+
 template <class T>
-int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s) {
+int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
+  g.ksplit = ksplit;
+  g.out_f32 = h->slab;
+  g.ldo = g.N;
+  g.slab_stride = (size_t)h->Mpad * g.N;
+  Tiling t = pick_tiling(g.M, g.N * ksplit, g.K / ksplit, false);
+  while (t.nt > 1 && g.N % (t.nt * 16)) t.nt >>= 1;
+  return launch_gemm<T, EPI_PARTIAL>(g, t.mtw, t.nt, t.nw, false, s);
+}
+
+template <class T>
+int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s, PendingRed* pend = nullptr) {
   const int nv = h->D / 256;
   dim3 grid((M + 3) / 4);
-#define LN_CASE(NV)                                                                                              \
-  case NV:                                                                                                       \
-    hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV>), grid, dim3(256), 0, s, h->xres, M, shift, scale, h->Ntot, h->h16); \
+  const int ks = pend ? pend->ks : 0;
+  LnRed red{};
+  if (ks) red = pend->red;
+#define LN_LAUNCH(NV, KS) \
+  hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS>), grid, dim3(256), 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red)
+#define LN_CASE(NV)                     \
+  case NV:                              \
+    if (ks == 0) LN_LAUNCH(NV, 0);      \
+    else if (ks == 1) LN_LAUNCH(NV, 1); \
+    else if (ks == 2) LN_LAUNCH(NV, 2); \
+    else LN_LAUNCH(NV, 4);              \
     break;
   switch (nv) {
     LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8)
@@ -287,6 +319,8 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
       return FLOAT_E_INVALID;
   }
 #undef LN_CASE
+#undef LN_LAUNCH
+  if (pend) pend->ks = 0;
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -332,10 +366,12 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
     g.ntok = ntok;
     if ((rc = run_gemm<T, EPI_XEMBED>(g, s))) return rc;
   }
+  PendingRed pend;  // residual update left to the next LayerNorm launch
+  auto split_ok = [&](int ks, const Lin& L) { return (ks == 1 || ks == 2 || ks == 4) && L.K % (128 * ks) == 0; };
   for (int b = 0; b < c.depth; ++b) {
     const float* mod = modbuf + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.qkv, M);
       g.out16 = h->qkv16;
@@ -344,7 +380,11 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
     }
     hipLaunchKernelGGL((fmt_attn_kernel<T>), dim3(bc * c.heads), dim3(512), 0, s, h->qkv16, 3 * D, h->att16, ntok,
                        c.heads, D, c.attn_window);
-    {
+    if (split_ok(g_fmt_proj_split, B.proj)) {
+      if ((rc = run_gemm_partial<T>(h, base_args(h->att16, B.proj, M), g_fmt_proj_split, s))) return rc;
+      pend.ks = g_fmt_proj_split;
+      pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
+    } else {
       GemmArgs g = base_args(h->att16, B.proj, M);
       g.out_f32 = h->xres;
       g.ldo = D;
@@ -352,14 +392,18 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
       g.ldg = h->Ntot;
       if ((rc = run_gemm<T, EPI_GATE_RES>(g, s))) return rc;
     }
-    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.fc1, M);
       g.out16 = h->hid16;
       g.ldo16 = B.fc2.K / 32;  // packed for fc2
       if ((rc = run_gemm<T, EPI_GELU_P16>(g, s))) return rc;
     }
-    {
+    if (split_ok(g_fmt_fc2_split, B.fc2)) {
+      if ((rc = run_gemm_partial<T>(h, base_args(h->hid16, B.fc2, M), g_fmt_fc2_split, s))) return rc;
+      pend.ks = g_fmt_fc2_split;
+      pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.fc2.b, mod + 5 * D};
+    } else {
       GemmArgs g = base_args(h->hid16, B.fc2, M);
       g.out_f32 = h->xres;
       g.ldo = D;
@@ -370,7 +414,7 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
   }
   {
     const float* mod = modbuf + (size_t)c.depth * 6 * D;  // shift, scale (FMT.py:196)
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend))) return rc;
     GemmArgs g = base_args(h->h16, h->final_lin, M);
     g.bc = bc;
     g.ntok = ntok;
@@ -753,6 +797,8 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   h->Kc = round_up(cfg->dim_w + cfg->dim_a + cfg->dim_e, 128);
   h->Kx = round_up(cfg->dim_w, 128);
   if (const char* wd = getenv("FLOAT_FMT_WIDE")) g_fmt_wide = atoi(wd) != 0;
+  if (const char* v = getenv("FLOAT_FMT_FC2_SPLIT")) g_fmt_fc2_split = atoi(v);
+  if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
     sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],
            &g_fmt_plan_override[3], &g_fmt_plan_override[4], &g_fmt_plan_override[5]);
@@ -779,6 +825,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->mod2, (size_t)Mp * h->Ntot);
   A(&h->kbuf, (size_t)4 * 64 * cfg->dim_w);
   A(&h->xres, (size_t)Mp * D);
+  A(&h->slab, (size_t)4 * Mp * D);
   A(&h->xcur, (size_t)cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
   A(&h->ts_dev, (size_t)kMaxSteps);

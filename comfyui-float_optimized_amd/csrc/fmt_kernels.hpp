@@ -21,7 +21,9 @@ enum {
   EPI_GELU_P16 = 3,  // out16   = T(gelu_tanh(acc + bias))                     (packed, feeds a GEMM)
   EPI_GATE_RES = 4,  // out_f32 += gate * (acc + bias)                         (FMT.py:174-175)
   EPI_XEMBED = 5,    // out_f32[b*ntok + r] = acc + bias + pos[r], b < bc       (FMT.py:319-320)
-  EPI_CFG = 6        // CFG combine (+ Euler update) on the final linear        (FMT.py:375-399)
+  EPI_CFG = 6,       // CFG combine (+ Euler update) on the final linear        (FMT.py:375-399)
+  EPI_PARTIAL = 7    // slab[ks][row][n] = acc  (split-K slice ks, no bias): summed, gated and added to the
+                     // residual stream by the LayerNorm kernel that follows (fmt_lnmod_kernel<.., KS>)
 };
 
 // element offset of (row, k) in a packed operand with KB = K/32 k-blocks
@@ -49,6 +51,9 @@ struct GemmArgs {
   float* xcur;   // (ntok - n_prev, N) Euler state or nullptr
   u16* xin16;    // next evaluation's x_embedder input, packed with KB = ldx
   int ldx;
+  // EPI_PARTIAL: K is cut into ksplit slices, one per workgroup; slice ks writes out_f32 + ks * slab_stride
+  int ksplit;
+  size_t slab_stride;
 };
 
 template <class T, int MTW, int NT, int NW, int EPI>
@@ -63,9 +68,10 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   const int r16 = lane & 15, q = lane >> 4;
   // 1-D grid of (column blocks) x (row blocks).  Row blocks of one column block read the same
   // weights: give them consecutive slots on ONE XCD (ids congruent mod 8 share an XCD's L2).
-  int bx, by;
+  int bx, by, ks = 0;
   {
-    const int nbx = g.N / BN, id = blockIdx.x;
+    const int nbn = g.N / BN, id = blockIdx.x;
+    const int nbx = (EPI == EPI_PARTIAL) ? nbn * g.ksplit : nbn;  // (column block, K slice) pairs
     if ((nbx & 7) == 0) {
       const int slot = id >> 3;
       by = slot % g.mblk;
@@ -73,6 +79,10 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
     } else {
       bx = id % nbx;
       by = id / nbx;
+    }
+    if constexpr (EPI == EPI_PARTIAL) {
+      ks = bx / nbn;
+      bx = bx % nbn;
     }
   }
   const int nb0 = bx * NT;
@@ -86,10 +96,26 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
     for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int KB = g.K >> 5;
-  const int KBw = KB / NW;  // k-blocks per wave
-  const u16* Ap = g.A + ((size_t)mt0 * KB + w * KBw) * 512 + lane * 8;
-  const u16* Wp = g.W + ((size_t)nb0 * KB + w * KBw) * 512 + lane * 8;
+  const int KBs = (EPI == EPI_PARTIAL) ? KB / g.ksplit : KB;  // k-blocks of this workgroup's K slice
+  const int KBw = KBs / NW;                                   // k-blocks per wave
+  const u16* Ap = g.A + ((size_t)mt0 * KB + ks * KBs + w * KBw) * 512 + lane * 8;
+  const u16* Wp = g.W + ((size_t)nb0 * KB + ks * KBs + w * KBw) * 512 + lane * 8;
   const size_t tstride = (size_t)KB * 512;
+  // EPI_GATE_RES with one epilogue item per thread: fetch residual and gate now, not after the K loop
+  constexpr bool kEarlyRes = (EPI == EPI_GATE_RES) && (MTW * 16 * (NT * 2) <= NW * 64);
+  float4 res_pf[2], gate_pf[2];
+  if constexpr (kEarlyRes) {
+    const int r = threadIdx.x / (NT * 2), cg = threadIdx.x % (NT * 2);
+    const int row = m0 + r, nb = n0 + cg * 8;
+    if (r < ROWS && row < g.M) {
+      const float* o = g.out_f32 + (size_t)row * g.ldo + nb;
+      const float* gt = g.gate + (size_t)row * g.ldg + nb;
+      res_pf[0] = *reinterpret_cast<const float4*>(o);
+      res_pf[1] = *reinterpret_cast<const float4*>(o + 4);
+      gate_pf[0] = *reinterpret_cast<const float4*>(gt);
+      gate_pf[1] = *reinterpret_cast<const float4*>(gt + 4);
+    }
+  }
 
   u32x4 a[PF][MTW], b[PF][NT];
 #pragma unroll
@@ -189,15 +215,16 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
             a4.z += t4.z;
             a4.w += t4.w;
           }
-          const float4 bb = *reinterpret_cast<const float4*>(g.bias + nb + e);
+          float4 bb = float4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (EPI != EPI_PARTIAL) bb = *reinterpret_cast<const float4*>(g.bias + nb + e);
           v[e + 0] = a4.x + bb.x;
           v[e + 1] = a4.y + bb.y;
           v[e + 2] = a4.z + bb.z;
           v[e + 3] = a4.w + bb.w;
         }
       }
-      if constexpr (EPI == EPI_F32) {
-        float* o = g.out_f32 + (size_t)row * g.ldo + nb;
+      if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) {
+        float* o = g.out_f32 + (size_t)ks * g.slab_stride + (size_t)row * g.ldo + nb;
         *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
       } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16) {
@@ -217,8 +244,14 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         const float* gt = g.gate + (size_t)row * g.ldg + nb;
 #pragma unroll
         for (int e = 0; e < 8; e += 4) {
-          float4 x = *reinterpret_cast<const float4*>(o + e);
-          const float4 gg = *reinterpret_cast<const float4*>(gt + e);
+          float4 x, gg;
+          if constexpr (kEarlyRes) {
+            x = res_pf[e / 4];
+            gg = gate_pf[e / 4];
+          } else {
+            x = *reinterpret_cast<const float4*>(o + e);
+            gg = *reinterpret_cast<const float4*>(gt + e);
+          }
           x.x += gg.x * v[e + 0];
           x.y += gg.y * v[e + 1];
           x.z += gg.z * v[e + 2];
@@ -356,14 +389,26 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
 // LayerNorm (no affine, biased variance, eps 1e-6) + framewise modulate, one wave per token row
 // (FMT.py:157,168-169,174-175,197).  out = T( (x-mu)*rstd * (1 + scale[row]) + shift[row] ), written in
 // the packed A-operand order of the consuming GEMM (K = D).
-template <class T, int NV>
-__global__ __launch_bounds__(256) void fmt_lnmod_kernel(const float* __restrict__ x, int M, const float* __restrict__ shift,
-                                                        const float* __restrict__ scale, int ldm, u16* __restrict__ out) {
+// KS > 0: the residual update of the preceding split-K GEMM (EPI_PARTIAL) is folded in first,
+//   x[row] += gate[row] * (bias + slab[0][row] + ... + slab[KS-1][row])      (fixed order: bitwise reproducible)
+// and the new residual row is written back, so the gated add costs no launch and no extra round trip:
+// every operand of the row is requested before the first one is used.
+struct LnRed {
+  const float* slab;   // [KS][rows][D] partial sums of the GEMM
+  size_t slab_stride;
+  const float* bias;   // [D]
+  const float* gate;   // row stride ldm (a column block of the modulation matrix)
+};
+
+template <class T, int NV, int KS>
+__global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, int M, const float* __restrict__ shift,
+                                                        const float* __restrict__ scale, int ldm, u16* __restrict__ out,
+                                                        LnRed red) {
   constexpr int D = NV * 256;
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const float* xr = x + (size_t)row * D;
+  float* xr = x + (size_t)row * D;
   const float* sh = shift + (size_t)row * ldm;
   const float* sc = scale + (size_t)row * ldm;
   float4 v[NV], a[NV], b[NV];
@@ -374,6 +419,33 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(const float* __restrict_
     v[i] = *reinterpret_cast<const float4*>(xr + c);
     a[i] = *reinterpret_cast<const float4*>(sh + c);
     b[i] = *reinterpret_cast<const float4*>(sc + c);
+  }
+  if constexpr (KS > 0) {
+    float4 p[KS][NV], gt[NV], bi[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = i * 256 + lane * 4;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) p[k][i] = *reinterpret_cast<const float4*>(red.slab + k * red.slab_stride + (size_t)row * D + c);
+      gt[i] = *reinterpret_cast<const float4*>(red.gate + (size_t)row * ldm + c);
+      bi[i] = *reinterpret_cast<const float4*>(red.bias + c);
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      float4 t = p[0][i];
+#pragma unroll
+      for (int k = 1; k < KS; ++k) {
+        t.x += p[k][i].x;
+        t.y += p[k][i].y;
+        t.z += p[k][i].z;
+        t.w += p[k][i].w;
+      }
+      v[i].x += gt[i].x * (t.x + bi[i].x);
+      v[i].y += gt[i].y * (t.y + bi[i].y);
+      v[i].z += gt[i].z * (t.z + bi[i].z);
+      v[i].w += gt[i].w * (t.w + bi[i].w);
+      *reinterpret_cast<float4*>(xr + i * 256 + lane * 4) = v[i];
+    }
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);

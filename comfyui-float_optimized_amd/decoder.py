@@ -25,7 +25,7 @@ class SynthesisHIP:
         del keep
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and native is not None:
             native.lib().float_dec_destroy(self._h)
             self._h = None
 

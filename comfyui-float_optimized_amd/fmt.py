@@ -40,7 +40,7 @@ class FlowMatchingTransformerHIP:
         self.method = name
 
     def close(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and native is not None:  # `native` is None during interpreter shutdown
             native.lib().float_fmt_destroy(self._h)
             self._h = None
 
