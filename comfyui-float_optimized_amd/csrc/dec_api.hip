@@ -623,6 +623,20 @@ int float_dec_set_feats(float_dec_t* h, const float* const* feats, int32_t n_fea
   return rc;
 }
 
+int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_feats, int32_t dtype, void* stream) {
+  FH_REQUIRE(h && feats16, "null argument to float_dec_set_feats16");
+  FH_REQUIRE(n_feats == h->n_levels, "expected %d feature maps (8..%d), got %d", h->n_levels, h->cfg.size, n_feats);
+  FH_REQUIRE(dtype == h->cfg.dtype, "feature dtype %d differs from the decoder's (%d)", dtype, h->cfg.dtype);
+  for (int i = 0; i < n_feats; ++i) FH_REQUIRE(feats16[i] != nullptr, "feats16[%d] is null", i);
+  hipStream_t st = (hipStream_t)stream;
+  for (int li = 0; li < h->n_levels; ++li) {
+    const Level& L = h->levels[li];
+    FH_CHECK_HIP(hipMemcpyAsync(L.feat, feats16[li], (size_t)L.R * L.R * L.C * sizeof(u16), hipMemcpyDeviceToDevice, st));
+  }
+  h->feats_set = true;
+  return FLOAT_OK;
+}
+
 static int dec_run(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames, float* out, int mode, void* stream) {
   FH_REQUIRE(h && s_r && r_d && out, "null argument to float_dec_frames");
   FH_REQUIRE(h->feats_set, "float_dec_set_feats must be called before decoding");

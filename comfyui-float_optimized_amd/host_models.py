@@ -1,89 +1,20 @@
 """Host-side (PyTorch on ROCm or CPU) producers of the hot path's inputs.  These run ONCE per
-clip and are plumbing, not part of the HIP hot path ("OUT OF SCOPE for HIP"):
+clip and are plumbing, not part of the HIP hot path ("OUT OF SCOPE for HIP").
+The appearance encoder and Direction are NOT here any more: they are the HIP operator `float_enc_*`
+(encoder.py in this package).
 
-  * appearance encoder  image -> s_r (512), 7 skip maps, motion coefficients (encoder.py:183-281)
-  * Direction           lambda -> r_s via QR of a (512,20) weight (styledecoder.py:428-444), hoisted
   * audio encoder       wav2vec2-base hidden states, interpolated to T frames *before* the
                         transformer, 12x768 -> 512 projection + LayerNorm + SiLU (FLOAT.py:304-375,
                         wav2vec2.py:33-98,184-197)
   * image / audio pre-processing of the simple node (generate.py:29-39, 69-73)
 
-They are written functionally over the reference's checkpoint keys so the split checkpoint layout
-(motion_autoencoder/encoder.safetensors, audio_projections/projection.safetensors,
-audio/wav2vec2-base-960h) loads unchanged.
+Sub-module names are the reference's checkpoint keys so the split checkpoint layout
+(audio_projections/projection.safetensors, audio/wav2vec2-base-960h) loads unchanged.
 """
 import math
 
 import torch
 import torch.nn.functional as F
-
-_SQRT2 = math.sqrt(2.0)
-
-
-def _fir(dtype, device):
-    k = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=dtype, device=device)
-    k = k[:, None] * k[None, :]
-    return k / k.sum()
-
-
-def _blur(x, pad):
-    """Blur([1,3,3,1], pad=(p0,p1)) (encoder.py:59-75): depth-wise 4x4 FIR after zero padding."""
-    C = x.shape[1]
-    w = _fir(x.dtype, x.device)[None, None].expand(C, 1, 4, 4)
-    return F.conv2d(F.pad(x, [pad[0], pad[1], pad[0], pad[1]]), w, groups=C)
-
-
-def _eq_conv(x, w, stride=1, padding=0):
-    return F.conv2d(x, w * (1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])), stride=stride, padding=padding)
-
-
-def _flrelu(x, b):
-    return F.leaky_relu(x + b, 0.2) * _SQRT2
-
-
-def _eq_linear(x, w, b):
-    return F.linear(x, w * (1.0 / math.sqrt(w.shape[1])), b)
-
-
-def encode_appearance(sd, img):
-    """EncoderApp.forward + Encoder.fc (encoder.py:220-231, 242-247).
-    img (B,3,S,S) in [-1,1].  Returns s_r (B,512), feats [8..S] (reference order), lambda (B,20)."""
-    p = "net_app.convs."
-    n_res = 0
-    while (p + "%d.conv1.0.weight" % (n_res + 1)) in sd:
-        n_res += 1
-    dev, dt = img.device, img.dtype
-    g = lambda k: sd[k].to(dev, dt)  # noqa: E731
-    h = _flrelu(_eq_conv(img, g(p + "0.0.weight")), g(p + "0.1.bias"))
-    res = [h]
-    for i in range(1, n_res + 1):
-        q = p + "%d." % i
-        o = _flrelu(_eq_conv(h, g(q + "conv1.0.weight"), padding=1), g(q + "conv1.1.bias"))
-        o = _flrelu(_eq_conv(_blur(o, (2, 2)), g(q + "conv2.1.weight"), stride=2), g(q + "conv2.2.bias"))
-        s = _eq_conv(_blur(h, (1, 1)), g(q + "skip.1.weight"), stride=2)
-        h = (o + s) / _SQRT2  # ResBlock (encoder.py:183-199)
-        res.append(h)
-    h = _eq_conv(h, g(p + "%d.weight" % (n_res + 1)))
-    res.append(h)
-    s_r = h.squeeze(-1).squeeze(-1)
-    feats = res[::-1][2:]
-    lam = s_r
-    i = 0
-    while ("fc.%d.weight" % i) in sd:
-        lam = _eq_linear(lam, g("fc.%d.weight" % i), g("fc.%d.bias" % i))
-        i += 1
-    return s_r, feats, lam
-
-
-def direction_basis(dec_sd, device="cpu"):
-    """Q of QR(W + 1e-8) (styledecoder.py:435-436), computed once instead of on every call."""
-    q, _ = torch.linalg.qr(dec_sd["direction.weight"].to(device, torch.float32) + 1e-8)
-    return q
-
-
-def direction(q, lam):
-    """Direction.forward: sum(diag_embed(lam) @ Q^T, dim=1) == lam @ Q^T (styledecoder.py:441-444)."""
-    return lam @ q.T.to(lam.device, lam.dtype)
 
 
 def preprocess_image(image_hwc, size=512):

@@ -31,6 +31,10 @@ class DecCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("size", "style_dim", "dtype", "max_frames")]
 
 
+class EncCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("size", "dim", "dim_motion", "dtype")]
+
+
 _F = C.POINTER(C.c_float)
 _SIGNATURES = {
     "float_hip_abi_version": (C.c_int, []),
@@ -56,6 +60,11 @@ _SIGNATURES = {
     "float_dec_set_feats": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "float_dec_frames": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_dec_frames_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "float_dec_set_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
+    "float_enc_create": (C.c_int, [C.POINTER(EncCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
+    "float_enc_destroy": (None, [C.c_void_p]),
+    "float_enc_forward": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
+    "float_enc_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
 }
 EXPORTS = tuple(_SIGNATURES)
 

@@ -142,6 +142,43 @@ int float_dec_frames(float_dec_t* h, const float* s_r, const float* r_d, int32_t
 int float_dec_frames_raw(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames,
                          float* out_chw, void* stream);
 
+/* Same hand-over without the fp32 round trip: feats16[i] = (R_i, R_i, C_i) NHWC 16-bit device buffers
+ * of element type `dtype` (must equal the decoder's), e.g. the ones float_enc_feats16 returns. */
+int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_feats, int32_t dtype,
+                          void* stream);
+
+/* ---------------------------------------------------------------- encoder --------- */
+/* Appearance / motion encoder, once per clip: EncoderApp.forward
+ * (reference src/nodes/models/float/encoder.py:203-231), Encoder.fc (encoder.py:242-247) and
+ * Direction (styledecoder.py:428-444, QR hoisted to create time), as called by
+ * FLOAT.encode_image_into_latent / inference (FLOAT.py:283-291).
+ * Checkpoint keys: `net_app.convs.*`, `fc.*` (prefix `motion_autoencoder.enc.` stripped) and,
+ * optionally, `direction.weight` (from `motion_autoencoder.dec.`) to get r_s as well. */
+typedef struct {
+  int32_t size;        /* input resolution, power of two in [64, 1024] */
+  int32_t dim;         /* 512 */
+  int32_t dim_motion;  /* 20 */
+  int32_t dtype;       /* FLOAT_DT_* of activations / conv weights; accumulation, s_r, fc are fp32 */
+} float_enc_cfg_t;
+
+typedef struct float_enc float_enc_t;
+
+int float_enc_create(const float_enc_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors,
+                     float_enc_t** out);
+void float_enc_destroy(float_enc_t* h);
+
+/* img: (3, size, size) fp32 NCHW in [-1,1] (generate.py:34-39).  Outputs (device, fp32, each optional):
+ *   s_r (dim); lam = Encoder.fc(s_r) (dim_motion); r_s = Direction(lam) (dim; needs direction.weight);
+ *   feats[i] (C_i, R_i, R_i) NCHW with R_i = 8 << i, the reference's res[::-1][2:] order
+ *   (n_feats <= log2(size) - 2; NULL entries are skipped). */
+int float_enc_forward(float_enc_t* h, const float* img, float* s_r, float* lam, float* r_s,
+                      float* const* feats, int32_t n_feats, void* stream);
+
+/* The NHWC 16-bit feature maps left in the handle by the last float_enc_forward (valid until the
+ * next one), reference order; *n_out = how many were written (<= max_feats). */
+int float_enc_feats16(float_enc_t* h, const void** feats16, int32_t* channels, int32_t max_feats,
+                      int32_t* n_out);
+
 /* ---------------------------------------------------------------- misc ------------ */
 int float_hip_abi_version(void);
 const char* float_last_error(void);

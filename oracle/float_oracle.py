@@ -371,3 +371,71 @@ def direction(sd, lam, dtype=torch.float32):
     """Direction.forward (styledecoder.py:434-444): Q from QR(W + 1e-8); out = lam @ Q^T."""
     q, _ = torch.linalg.qr(sd["direction.weight"].to(dtype) + 1e-8)
     return lam.to(dtype) @ q.T
+
+
+# ------------------------------------------------------------------------- appearance encoder
+# SURVEY.md section 8f row 1: EncoderApp / Encoder (encoder.py:183-281), once per clip.
+
+
+def enc_blur(x, pad):
+    """Blur([1,3,3,1], pad) of a down-sampling ConvLayer (encoder.py:59-75,160-166): upfirdn with
+    up = down = 1, i.e. zero-pad by (pad0, pad1) and correlate with the (symmetric) 4x4 FIR / 64."""
+    return upfirdn(x, fir_kernel(1.0, x.dtype), up=1, pad=pad)
+
+
+def equal_conv2d(x, w, stride=1, padding=0):
+    """EqualConv2d without bias (encoder.py:88-106): conv2d(x, W / sqrt(Cin k^2))."""
+    w = w.to(x.dtype)
+    return F.conv2d(x, w * (1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])), stride=stride, padding=padding)
+
+
+def enc_conv_layer(x, sd, prefix, k, downsample=False, activate=True):
+    """ConvLayer (encoder.py:146-181).  Sequential indices: plain = [conv, act]; down-sampling =
+    [blur, conv, act] with pad0 = (p+1)//2, pad1 = p//2, p = (4 - 2) + (k - 1), stride 2, padding 0."""
+    if downsample:
+        p = (4 - 2) + (k - 1)
+        x = enc_blur(x, ((p + 1) // 2, p // 2))
+        y = equal_conv2d(x, sd[prefix + "1.weight"], stride=2, padding=0)
+        bias_key = prefix + "2.bias"
+    else:
+        y = equal_conv2d(x, sd[prefix + "0.weight"], stride=1, padding=k // 2)
+        bias_key = prefix + "1.bias"
+    if activate:  # FusedLeakyReLU: leaky_relu(x + b, 0.2) * sqrt(2)  (encoder.py:13-14,47-57)
+        y = F.leaky_relu(y + sd[bias_key].to(x.dtype), 0.2) * _SQRT2
+    return y
+
+
+def enc_res_block(x, sd, prefix):
+    """ResBlock (encoder.py:183-199): conv1 3x3, conv2 blur+3x3 stride 2, skip blur+1x1 stride 2 (no
+    bias, no activation); (out + skip) / sqrt(2)."""
+    o = enc_conv_layer(x, sd, prefix + "conv1.", 3)
+    o = enc_conv_layer(o, sd, prefix + "conv2.", 3, downsample=True)
+    s = enc_conv_layer(x, sd, prefix + "skip.", 1, downsample=True, activate=False)
+    return (o + s) / _SQRT2
+
+
+def encode_appearance(sd, img, dtype=torch.float32):
+    """EncoderApp.forward + Encoder.fc (encoder.py:203-231, 234-247, 266-281 with input_target=None plus
+    FLOAT.py's enc.fc call).  img (B,3,S,S) in [-1,1].
+    Returns s_r (B,512), feats = res[::-1][2:] (resolutions 8..S, reference order), lambda (B,20)."""
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    x = img.to(dtype)
+    p = "net_app.convs."
+    n_res = 0
+    while (p + "%d.conv1.0.weight" % (n_res + 1)) in sd:
+        n_res += 1
+    h = enc_conv_layer(x, sd, p + "0.", 1)
+    res = [h]
+    for i in range(1, n_res + 1):
+        h = enc_res_block(h, sd, p + "%d." % i)
+        res.append(h)
+    h = equal_conv2d(h, sd[p + "%d.weight" % (n_res + 1)])  # EqualConv2d(C, 512, 4, padding=0, bias=False)
+    res.append(h)
+    s_r = h.squeeze(-1).squeeze(-1)
+    feats = res[::-1][2:]
+    lam = s_r
+    i = 0
+    while ("fc.%d.weight" % i) in sd:  # 4 x EqualLinear(512,512) + EqualLinear(512,20), no activation
+        lam = equal_linear(lam, sd["fc.%d.weight" % i], sd["fc.%d.bias" % i])
+        i += 1
+    return s_r, feats, lam

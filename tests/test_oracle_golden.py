@@ -109,3 +109,25 @@ def test_e2e_config1():
     pick = [int(i) for i in g["pick"]]
     frames = O.decode_frames(dsd, g["s_r"], r_d[:, pick[:1]], feats)
     assert max_abs(frames[:, ::7, ::5], g["lattice"][:1]) < 2e-4
+
+
+def _enc_image(seed, size):
+    import numpy as np
+    return torch.from_numpy(np.random.RandomState(seed).rand(1, 3, size, size).astype(np.float32)) * 2 - 1
+
+
+@pytest.mark.parametrize("size", [64, 512])
+def test_encoder(size):
+    """Encoder.forward(img, None) + Encoder.fc + Direction (encoder.py:203-281)."""
+    g = golden("enc_%d" % size)
+    esd = W.synth_encoder_state(size, seed=g["seed"])
+    dsd = W.synth_decoder_state(size, seed=g["seed"])
+    s_r, feats, lam = O.encode_appearance(esd, _enc_image(g["seed"], size))
+    assert rel_l2(s_r, g["s_r"]) < TOL_REL and rel_l2(lam, g["lam"]) < TOL_REL
+    assert rel_l2(O.direction(dsd, lam), g["r_s"]) < TOL_REL
+    assert len(feats) == int(math.log2(size)) - 2
+    for i, f in enumerate(feats):
+        st = int(g["feat%d_stride" % i])
+        assert f.shape[-1] == 8 << i
+        assert rel_l2(f[:, :, ::st, ::st], g["feat%d" % i]) < TOL_REL
+        assert rel_l2(f.mean(dim=(2, 3)), g["feat%d_mean" % i]) < TOL_REL

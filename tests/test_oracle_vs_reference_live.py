@@ -58,7 +58,7 @@ def test_synthesis_live(ref):
     assert float((got - want).abs().max()) < 1e-4 and float((gflow - flow).abs().max()) < 1e-5
 
 
-def test_host_encoder_live(ref):
+def test_encoder_oracle_live(ref):
     sd = pkg.weights.synth_encoder_state(64, seed=79)
     e = ref.encoder.Encoder(64, 512, 20)
     e.load_state_dict(sd, strict=True)
@@ -67,6 +67,6 @@ def test_host_encoder_live(ref):
     with torch.no_grad():
         s_r, _, feats = e(img, None)
         lam = e.fc(s_r)
-    s2, f2, l2 = pkg.host_models.encode_appearance(sd, img)
+    s2, f2, l2 = O.encode_appearance(sd, img)
     assert float((s_r - s2).abs().max()) < 1e-5 and float((lam - l2).abs().max()) < 1e-5
     assert all(float((a - b).abs().max()) < 1e-5 for a, b in zip(feats, f2))

@@ -285,6 +285,36 @@ def gen_e2e_config1(ns, seed=900):
          lattice=frames[:, ::7, ::5], band=frames[:, 250:258], mean=frames.mean(dim=(1, 2, 3)))
 
 
+def gen_encoder(ns, size, seed, sparse):
+    """Encoder.forward(img, None) + Encoder.fc + Direction of the reference itself (encoder.py:266-281, 242-247;
+    styledecoder.py:428-444; FLOAT.py:283-291) on seeded synthetic weights."""
+    print("[encoder %d]" % size)
+    esd = weights.synth_encoder_state(size, seed=seed)
+    enc = ns.encoder.Encoder(size, 512, 20)
+    enc.load_state_dict(esd, strict=True)
+    enc.eval()
+    dsd = weights.synth_decoder_state(size, seed=seed)
+    dirn = ns.styledecoder.Direction(20)
+    dirn.load_state_dict({"weight": dsd["direction.weight"]})
+    img = torch.from_numpy(np.random.RandomState(seed).rand(1, 3, size, size).astype(np.float32)) * 2 - 1
+    with torch.no_grad():
+        s_r, _, feats = enc(img, None)
+        lam = enc.fc(s_r)
+        r_s = dirn(lam)
+    o_s, o_f, o_l = O.encode_appearance(esd, img)
+    o_r = O.direction(dsd, o_l)
+    print("  oracle-ref max|d|: s_r %.3e lam %.3e r_s %.3e feats %.3e" % (
+        maxdiff(o_s, s_r)[0], maxdiff(o_l, lam)[0], maxdiff(o_r, r_s)[0], max(maxdiff(a, b)[0] for a, b in zip(o_f, feats))))
+    # the image is RandomState(seed).rand(1,3,S,S)*2-1: tests regenerate it from the seed
+    arrs = dict(seed=seed, size=size, s_r=s_r, lam=lam, r_s=r_s)
+    for i, f in enumerate(feats):
+        st = max(1, f.shape[-1] // 16) if sparse else (2 if f.shape[-1] > 16 else 1)
+        arrs["feat%d_stride" % i] = st
+        arrs["feat%d" % i] = f[:, :, ::st, ::st]
+        arrs["feat%d_mean" % i] = f.mean(dim=(2, 3))
+    save("enc_%d" % size, **arrs)
+
+
 def gen_node_surface(ns):
     """Widget/return contracts of the three north-star nodes and the batch/seed schedule of
     FloatProcess.floatprocess (nodes.py:189-222), captured from the reference classes themselves."""
@@ -343,6 +373,10 @@ def gen_node_surface(ns):
 
 def main():
     ns = ref_import.load()
+    if os.environ.get("GOLDENS_ONLY") == "enc":
+        gen_encoder(ns, 64, seed=1000, sparse=False)
+        gen_encoder(ns, 512, seed=1100, sparse=True)
+        return
     gen_node_surface(ns)
     if os.environ.get("GOLDENS_ONLY") == "nodes":
         return
@@ -359,6 +393,8 @@ def main():
     gen_dec_units(ns, seed=600)
     gen_dec(ns, 64, seed=700, n_frames=3, sparse=False)
     gen_dec(ns, 512, seed=800, n_frames=2, sparse=True)
+    gen_encoder(ns, 64, seed=1000, sparse=False)
+    gen_encoder(ns, 512, seed=1100, sparse=True)
 
 
 if __name__ == "__main__":
