@@ -8,7 +8,7 @@ import importlib
 
 __version__ = "0.1.0"
 
-_SUBMODULES = ("config", "weights", "native", "fmt", "decoder", "encoder", "pipeline", "distributed", "host_models")
+_SUBMODULES = ("config", "weights", "native", "fmt", "decoder", "encoder", "audio", "pipeline", "distributed", "host_models")
 
 
 def __getattr__(name):

@@ -37,3 +37,45 @@ class FmtConfig:
 def small_fmt_config():
     return FmtConfig(dim_w=128, dim_a=128, dim_e=7, dim_h=256, fmt_depth=2, num_heads=2,
                      mlp_ratio=4.0, num_prev_frames=10, num_frames_for_clip=50, attention_window=2)
+
+
+@dataclass
+class AudioConfig:
+    """Shape of the audio conditioning encoder = the bundled wav2vec2_base config
+    (reference src/nodes/model_configs/wav2vec2_base/config.json) + opt.dim_w / opt.only_last_features."""
+    conv_dim: tuple = (512,) * 7
+    conv_kernel: tuple = (10, 3, 3, 3, 3, 2, 2)
+    conv_stride: tuple = (5, 2, 2, 2, 2, 2, 2)
+    hidden_size: int = 768
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    intermediate_size: int = 3072
+    num_conv_pos_embeddings: int = 128
+    num_conv_pos_embedding_groups: int = 16
+    layer_norm_eps: float = 1e-5
+    dim_w: int = 512
+    only_last_features: bool = False
+
+    def to_hf(self):
+        """The same shape as a transformers Wav2Vec2Config (eager attention, group-norm feature extractor)."""
+        from transformers import Wav2Vec2Config
+        return Wav2Vec2Config(conv_dim=tuple(self.conv_dim), conv_kernel=tuple(self.conv_kernel), conv_stride=tuple(self.conv_stride),
+                              num_feat_extract_layers=len(self.conv_dim), hidden_size=self.hidden_size,
+                              num_hidden_layers=self.num_hidden_layers, num_attention_heads=self.num_attention_heads,
+                              intermediate_size=self.intermediate_size, num_conv_pos_embeddings=self.num_conv_pos_embeddings,
+                              num_conv_pos_embedding_groups=self.num_conv_pos_embedding_groups, layer_norm_eps=self.layer_norm_eps,
+                              feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False, attn_implementation="eager")
+
+    @classmethod
+    def from_hf(cls, hf, dim_w=512, only_last_features=False):
+        if getattr(hf, "feat_extract_norm", "group") != "group" or getattr(hf, "do_stable_layer_norm", False) or getattr(hf, "conv_bias", False):
+            raise ValueError("only the wav2vec2-base family (feat_extract_norm='group', no conv bias, post-LayerNorm encoder) is supported")
+        return cls(tuple(hf.conv_dim), tuple(hf.conv_kernel), tuple(hf.conv_stride), hf.hidden_size, hf.num_hidden_layers,
+                   hf.num_attention_heads, hf.intermediate_size, hf.num_conv_pos_embeddings, hf.num_conv_pos_embedding_groups,
+                   hf.layer_norm_eps, dim_w, only_last_features)
+
+
+def small_audio_config():
+    """Reduced wav2vec2 shape for fast parity tests (same head dim 64, LayerNorm widths multiples of 256)."""
+    return AudioConfig(conv_dim=(256,) * 7, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                       num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=16, dim_w=256)

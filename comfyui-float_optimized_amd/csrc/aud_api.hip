@@ -1,0 +1,451 @@
+// C-ABI entry points of the audio conditioning encoder (include/float_hip.h, section "audio encoder"):
+// AudioEncoder.inference (reference FLOAT.py:370-375) = Wav2VecModel.forward(seq_len) with all hidden states
+// (src/nodes/models/wav2vec2.py:33-98) + audio_projection (FLOAT.py:338-342).
+#include <math.h>
+
+#include "aud_kernels.hpp"
+#include "fmt_gemm.hpp"
+
+namespace {
+
+struct ConvL {
+  u16* W = nullptr;  // [N][k*Cin], K ordered (tap, channel)
+  int cin = 0, cout = 0, k = 0, stride = 0;
+};
+
+struct LnP {
+  float *g = nullptr, *b = nullptr;
+};
+
+struct TLayer {
+  FmtLin qkv, out, ff1, ff2;
+  LnP ln1, ln2;
+};
+
+int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+}  // namespace
+
+struct float_aud {
+  float_aud_cfg_t cfg;
+  DevicePool pool;  // weights
+  DevicePool ws;    // workspace, regrown when a longer clip arrives
+  int C = 0, D = 0;
+  float* w0 = nullptr;  // [C][k0] fp32
+  LnP gn;               // GroupNorm affine of layer 0
+  std::vector<ConvL> convs;  // layers 1..n-1
+  LnP fp_ln;
+  FmtLin fp_proj;
+  u16* pos_w = nullptr;  // [pairs][taps][GP][GP]
+  float* pos_b = nullptr;
+  int pos_gp = 0, pos_pairs = 0;
+  LnP enc_ln;
+  std::vector<TLayer> layers;
+  FmtLin aproj;
+  LnP aproj_ln;
+  // workspace
+  size_t cap_samples = 0;
+  int cap_T = 0, Mp = 0;
+  u16 *fa = nullptr, *fb = nullptr;
+  float *part = nullptr, *scsh = nullptr;
+  u16 *x16 = nullptr, *hp16 = nullptr, *qkv16 = nullptr, *att16 = nullptr, *hid16 = nullptr, *stack16 = nullptr;
+  float *hproj = nullptr, *pos = nullptr, *h = nullptr, *h1 = nullptr, *y = nullptr, *yproj = nullptr;
+};
+
+namespace {
+
+const float_tensor_t* need(const TensorTable& tt, const std::string& name) {
+  const float_tensor_t* t = tt.find(name);
+  if (!t) fh_set_error("missing checkpoint tensor '%s'", name.c_str());
+  return t;
+}
+
+int upload(DevicePool* pool, const float* src, size_t n, float** out) {
+  int rc = pool->alloc(out, n, false);
+  if (rc) return rc;
+  FH_CHECK_HIP(hipMemcpy(*out, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return FLOAT_OK;
+}
+
+int load_ln(float_aud* h, const TensorTable& tt, const std::string& p, int n, LnP* out) {
+  const float_tensor_t* w = need(tt, p + ".weight");
+  const float_tensor_t* b = need(tt, p + ".bias");
+  if (!w || !b) return FLOAT_E_MISSING;
+  FH_REQUIRE(TensorTable::numel(w) == n && TensorTable::numel(b) == n, "'%s' must have %d elements", p.c_str(), n);
+  int rc;
+  if ((rc = upload(&h->pool, w->data, n, &out->g))) return rc;
+  return upload(&h->pool, b->data, n, &out->b);
+}
+
+template <class T>
+int create_impl(float_aud* h, const TensorTable& tt) {
+  const float_aud_cfg_t& c = h->cfg;
+  const std::string W2 = "wav2vec2.";
+  int rc;
+  h->C = c.conv_dim[0];
+  h->D = c.hidden;
+  // ---- feature extractor (Wav2Vec2FeatureEncoder, feat_extract_norm = "group", conv_bias = false)
+  {
+    const std::string p = W2 + "feature_extractor.conv_layers.0.";
+    const float_tensor_t* w = need(tt, p + "conv.weight");
+    if (!w) return FLOAT_E_MISSING;
+    FH_REQUIRE(w->ndim == 3 && w->shape[0] == h->C && w->shape[1] == 1 && w->shape[2] == c.conv_kernel[0],
+               "conv_layers.0.conv.weight must be (%d,1,%d)", h->C, c.conv_kernel[0]);
+    FH_REQUIRE(tt.find(p + "conv.bias") == nullptr, "conv_bias=true feature extractors are not supported");
+    if ((rc = upload(&h->pool, w->data, (size_t)h->C * c.conv_kernel[0], &h->w0))) return rc;
+    if ((rc = load_ln(h, tt, p + "layer_norm", h->C, &h->gn))) return rc;
+  }
+  for (int i = 1; i < c.n_conv; ++i) {
+    const std::string p = W2 + "feature_extractor.conv_layers." + std::to_string(i) + ".";
+    const float_tensor_t* w = need(tt, p + "conv.weight");
+    if (!w) return FLOAT_E_MISSING;
+    ConvL L;
+    L.cin = c.conv_dim[i - 1];
+    L.cout = c.conv_dim[i];
+    L.k = c.conv_kernel[i];
+    L.stride = c.conv_stride[i];
+    FH_REQUIRE(w->ndim == 3 && w->shape[0] == L.cout && w->shape[1] == L.cin && w->shape[2] == L.k, "conv_layers.%d.conv.weight must be (%d,%d,%d)",
+               i, L.cout, L.cin, L.k);
+    FH_REQUIRE(tt.find(p + "conv.bias") == nullptr && tt.find(p + "layer_norm.weight") == nullptr,
+               "only feat_extract_norm='group' without conv bias is supported (conv layer %d)", i);
+    std::vector<u16> hw((size_t)L.cout * L.k * L.cin);
+    for (int n = 0; n < L.cout; ++n)
+      for (int ci = 0; ci < L.cin; ++ci)
+        for (int t = 0; t < L.k; ++t) hw[((size_t)n * L.k + t) * L.cin + ci] = T::host_from_float(w->data[((size_t)n * L.cin + ci) * L.k + t]);
+    if ((rc = h->pool.alloc(&L.W, hw.size(), false))) return rc;
+    FH_CHECK_HIP(hipMemcpy(L.W, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
+    h->convs.push_back(L);
+  }
+  // ---- feature projection (LayerNorm + Linear)
+  if ((rc = load_ln(h, tt, W2 + "feature_projection.layer_norm", h->C, &h->fp_ln))) return rc;
+  if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {W2 + "feature_projection.projection"}, h->D, h->C, &h->fp_proj))) return rc;
+  // ---- positional conv embedding, weight-norm folded: w = g * v / ||v||, norm over (out, in) per tap (dim = 2)
+  {
+    const std::string p = W2 + "encoder.pos_conv_embed.conv.";
+    const int cpg = h->D / c.pos_groups, K = c.pos_k;
+    const float_tensor_t* v = tt.find(p + "parametrizations.weight.original1");
+    const float_tensor_t* g = tt.find(p + "parametrizations.weight.original0");
+    if (!v) {
+      v = tt.find(p + "weight_v");
+      g = tt.find(p + "weight_g");
+    }
+    const float_tensor_t* plain = tt.find(p + "weight");
+    const float_tensor_t* src = v ? v : plain;
+    if (!src || (v && !g)) {
+      fh_set_error("missing checkpoint tensor '%sweight' (or its weight-norm pair original0/original1, weight_g/weight_v)", p.c_str());
+      return FLOAT_E_MISSING;
+    }
+    FH_REQUIRE(src->ndim == 3 && src->shape[0] == h->D && src->shape[1] == cpg && src->shape[2] == K, "pos_conv_embed weight must be (%d,%d,%d)",
+               h->D, cpg, K);
+    std::vector<float> wf((size_t)h->D * cpg * K);
+    if (v) {
+      FH_REQUIRE(TensorTable::numel(g) == K, "pos_conv_embed weight_g must have %d elements", K);
+      for (int t = 0; t < K; ++t) {
+        double n2 = 0.0;
+        for (size_t oc = 0; oc < (size_t)h->D * cpg; ++oc) n2 += (double)v->data[oc * K + t] * v->data[oc * K + t];
+        const float sc = g->data[t] / (float)sqrt(n2);
+        for (size_t oc = 0; oc < (size_t)h->D * cpg; ++oc) wf[oc * K + t] = v->data[oc * K + t] * sc;
+      }
+    } else {
+      memcpy(wf.data(), plain->data, wf.size() * sizeof(float));
+    }
+    int merge = 1;
+    while ((cpg * merge) % 32 != 0 && merge < c.pos_groups) merge *= 2;
+    const int GP = cpg * merge;
+    FH_REQUIRE(GP % 32 == 0 && GP <= 128 && c.pos_groups % merge == 0, "positional conv with %d channels per group is not supported", cpg);
+    h->pos_gp = GP;
+    h->pos_pairs = c.pos_groups / merge;
+    std::vector<u16> hw((size_t)h->pos_pairs * K * GP * GP, T::host_from_float(0.f));
+    for (int o = 0; o < h->D; ++o) {
+      const int grp = o / cpg, pair = grp / merge, ol = o - pair * GP;
+      for (int ci = 0; ci < cpg; ++ci) {
+        const int cl = (grp % merge) * cpg + ci;  // input channel inside the merged slab
+        for (int t = 0; t < K; ++t) hw[(((size_t)pair * K + t) * GP + ol) * GP + cl] = T::host_from_float(wf[((size_t)o * cpg + ci) * K + t]);
+      }
+    }
+    if ((rc = h->pool.alloc(&h->pos_w, hw.size(), false))) return rc;
+    FH_CHECK_HIP(hipMemcpy(h->pos_w, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
+    const float_tensor_t* b = need(tt, p + "bias");
+    if (!b) return FLOAT_E_MISSING;
+    if ((rc = upload(&h->pool, b->data, h->D, &h->pos_b))) return rc;
+  }
+  if ((rc = load_ln(h, tt, W2 + "encoder.layer_norm", h->D, &h->enc_ln))) return rc;
+  // ---- transformer layers (post-LN, do_stable_layer_norm = false)
+  h->layers.resize(c.layers);
+  for (int l = 0; l < c.layers; ++l) {
+    const std::string p = W2 + "encoder.layers." + std::to_string(l) + ".";
+    TLayer& L = h->layers[l];
+    if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {p + "attention.q_proj", p + "attention.k_proj", p + "attention.v_proj"}, h->D, h->D, &L.qkv)))
+      return rc;
+    if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {p + "attention.out_proj"}, h->D, h->D, &L.out))) return rc;
+    if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {p + "feed_forward.intermediate_dense"}, c.intermediate, h->D, &L.ff1))) return rc;
+    if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {p + "feed_forward.output_dense"}, h->D, c.intermediate, &L.ff2))) return rc;
+    if ((rc = load_ln(h, tt, p + "layer_norm", h->D, &L.ln1))) return rc;
+    if ((rc = load_ln(h, tt, p + "final_layer_norm", h->D, &L.ln2))) return rc;
+  }
+  // ---- audio projection: Linear(layers*D | D -> dim_w) + LayerNorm + SiLU (FLOAT.py:338-342)
+  const int din = c.only_last ? h->D : c.layers * h->D;
+  if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {"audio_projection.0"}, c.dim_w, din, &h->aproj))) return rc;
+  if ((rc = load_ln(h, tt, "audio_projection.1", c.dim_w, &h->aproj_ln))) return rc;
+  fmt_gemm_prime(c.dtype);
+  return FLOAT_OK;
+}
+
+int ensure_workspace(float_aud* h, int n_samples, int Tn, hipStream_t st) {
+  if ((size_t)n_samples <= h->cap_samples && Tn <= h->cap_T) return FLOAT_OK;
+  const float_aud_cfg_t& c = h->cfg;
+  FH_CHECK_HIP(hipStreamSynchronize(st));  // earlier calls may still use the old buffers
+  h->ws.release();
+  h->ws = DevicePool();
+  const size_t ns = std::max((size_t)n_samples, h->cap_samples);
+  const int Tc = std::max(Tn, h->cap_T);
+  const size_t L0 = (ns - c.conv_kernel[0]) / c.conv_stride[0] + 1;
+  const size_t L1 = c.n_conv > 1 ? (L0 - c.conv_kernel[1]) / c.conv_stride[1] + 1 : 1;
+  const int Mp = round_up(Tc, 80) + 80;
+  const int D = h->D, C = h->C;
+  int rc = 0;
+  auto A = [&](auto** p, size_t n) {
+    if (!rc) rc = h->ws.alloc(p, n, true);
+  };
+  A(&h->fa, L0 * C + 64);
+  A(&h->fb, L1 * C + 64);
+  A(&h->part, ((L0 + 63) / 64) * C * 2);
+  A(&h->scsh, (size_t)2 * C);
+  A(&h->x16, (size_t)Mp * C);
+  A(&h->hp16, (size_t)Mp * D);
+  A(&h->qkv16, (size_t)Mp * 3 * D);
+  A(&h->att16, (size_t)Mp * D);
+  A(&h->hid16, (size_t)Mp * c.intermediate);
+  A(&h->stack16, (size_t)Mp * h->aproj.K);
+  A(&h->hproj, (size_t)Mp * D);
+  A(&h->pos, (size_t)Mp * D);
+  A(&h->h, (size_t)Mp * D);
+  A(&h->h1, (size_t)Mp * D);
+  A(&h->y, (size_t)Mp * D);
+  A(&h->yproj, (size_t)Mp * c.dim_w);
+  if (rc) return rc;
+  h->cap_samples = ns;
+  h->cap_T = Tc;
+  h->Mp = Mp;
+  return FLOAT_OK;
+}
+
+template <class T>
+int launch_ln(int D, const AudLnArgs& g, hipStream_t st) {
+  dim3 grid((g.M + 3) / 4);
+  switch (D / 256) {
+    case 1: hipLaunchKernelGGL((aud_ln_kernel<T, 1>), grid, dim3(256), 0, st, g); break;
+    case 2: hipLaunchKernelGGL((aud_ln_kernel<T, 2>), grid, dim3(256), 0, st, g); break;
+    case 3: hipLaunchKernelGGL((aud_ln_kernel<T, 3>), grid, dim3(256), 0, st, g); break;
+    case 4: hipLaunchKernelGGL((aud_ln_kernel<T, 4>), grid, dim3(256), 0, st, g); break;
+    default: fh_set_error("LayerNorm width %d unsupported", D); return FLOAT_E_INVALID;
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+template <class T>
+int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* wa, hipStream_t st) {
+  const float_aud_cfg_t& c = h->cfg;
+  const int C = h->C, D = h->D;
+  int rc;
+  if ((rc = ensure_workspace(h, n_samples, Tn, st))) return rc;
+  // ---- feature extractor
+  int L = (n_samples - c.conv_kernel[0]) / c.conv_stride[0] + 1;
+  {
+    const int tchunk = 64, nchunk = (L + tchunk - 1) / tchunk;
+    FH_REQUIRE(c.conv_kernel[0] == 10, "first conv kernel must be 10 (got %d)", c.conv_kernel[0]);
+    hipLaunchKernelGGL((aud_conv0_stats_kernel<10>), dim3(nchunk, (C + 255) / 256), dim3(256), 0, st, a, n_samples, h->w0, c.conv_stride[0], L, C,
+                       tchunk, h->part);
+    hipLaunchKernelGGL(aud_gn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, h->part, nchunk, C, L, h->gn.g, h->gn.b, 1e-5f, h->scsh);
+    const size_t tot = (size_t)L * (C / 8);
+    hipLaunchKernelGGL((aud_conv0_apply_kernel<T, 10>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, h->w0, c.conv_stride[0], L, C,
+                       h->scsh, h->fa);
+  }
+  u16 *cur = h->fa, *nxt = h->fb;
+  for (const ConvL& Lc : h->convs) {
+    const int Lo = (L - Lc.k) / Lc.stride + 1;
+    FH_REQUIRE(Lo >= 1, "audio too short for the feature extractor (%d samples)", n_samples);
+    AudGemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.A = cur;
+    g.lda = (long long)Lc.stride * Lc.cin;
+    g.W = Lc.W;
+    g.out = nxt;
+    g.M = Lo;
+    g.N = Lc.cout;
+    g.K = Lc.k * Lc.cin;
+    g.ldc = Lc.cout;
+    g.act = 1;
+    hipLaunchKernelGGL((aud_gemm_tile_kernel<T>), dim3((Lo + 127) / 128, Lc.cout / 64), dim3(256), 0, st, g);
+    std::swap(cur, nxt);
+    L = Lo;
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  // ---- interpolate to Tn frames + feature-projection LayerNorm -> packed x16; projection -> hproj (fp32)
+  {
+    dim3 grid((Tn + 3) / 4);
+    switch (C / 256) {
+      case 1: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 1>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, h->x16); break;
+      case 2: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 2>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, h->x16); break;
+      default: fh_set_error("conv_dim %d unsupported", C); return FLOAT_E_INVALID;
+    }
+    GemmArgs g = fmt_gemm_args(h->x16, h->fp_proj, Tn);
+    g.out_f32 = h->hproj;
+    g.ldo = D;
+    if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
+  }
+  // ---- encoder: hidden = LayerNorm(hidden + gelu(pos_conv(hidden)))
+  {
+    dim3 grid((Tn + 15) / 16, h->pos_pairs);
+#define POS_CASE(GP) \
+  case GP: hipLaunchKernelGGL((aud_posconv_kernel<T, GP>), grid, dim3(256), 0, st, h->hproj, Tn, D, h->pos_w, h->pos_b, c.pos_k, c.pos_k / 2, h->pos); break;
+    switch (h->pos_gp) {
+      POS_CASE(32) POS_CASE(64) POS_CASE(96) POS_CASE(128)
+      default: fh_set_error("merged positional group width %d unsupported", h->pos_gp); return FLOAT_E_INVALID;
+    }
+#undef POS_CASE
+    AudLnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = h->hproj;
+    g.res = h->pos;
+    g.gamma = h->enc_ln.g;
+    g.beta = h->enc_ln.b;
+    g.eps = c.ln_eps;
+    g.out_f32 = h->h;
+    g.out_p16 = h->hp16;
+    g.M = Tn;
+    if ((rc = launch_ln<T>(D, g, st))) return rc;
+  }
+  const int stack_kb = h->aproj.K / 32;
+  for (int l = 0; l < c.layers; ++l) {
+    const TLayer& Ly = h->layers[l];
+    {
+      GemmArgs g = fmt_gemm_args(h->hp16, Ly.qkv, Tn);
+      g.out16 = h->qkv16;
+      g.ldo16 = 3 * D;
+      if ((rc = fmt_gemm_run(c.dtype, EPI_T16, g, st))) return rc;
+    }
+    {
+      const size_t smem = (size_t)4 * (64 + Tn) * sizeof(float);
+      hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), smem, st, h->qkv16, Tn, D, c.heads, h->att16);
+    }
+    {
+      GemmArgs g = fmt_gemm_args(h->att16, Ly.out, Tn);
+      g.out_f32 = h->y;
+      g.ldo = D;
+      if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
+    }
+    {  // hidden = layer_norm(residual + attention)
+      AudLnArgs g;
+      memset(&g, 0, sizeof(g));
+      g.a = h->y;
+      g.res = h->h;
+      g.gamma = Ly.ln1.g;
+      g.beta = Ly.ln1.b;
+      g.eps = c.ln_eps;
+      g.out_f32 = h->h1;
+      g.out_p16 = h->hp16;
+      g.M = Tn;
+      if ((rc = launch_ln<T>(D, g, st))) return rc;
+    }
+    {
+      GemmArgs g = fmt_gemm_args(h->hp16, Ly.ff1, Tn);
+      g.out16 = h->hid16;
+      g.ldo16 = Ly.ff2.K / 32;
+      if ((rc = fmt_gemm_run(c.dtype, EPI_GELUERF_P16, g, st))) return rc;
+    }
+    {
+      GemmArgs g = fmt_gemm_args(h->hid16, Ly.ff2, Tn);
+      g.out_f32 = h->y;
+      g.ldo = D;
+      if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
+    }
+    {  // hidden = final_layer_norm(hidden + feed_forward(hidden)); also hidden_states[l + 1] of the stack
+      AudLnArgs g;
+      memset(&g, 0, sizeof(g));
+      g.a = h->y;
+      g.res = h->h1;
+      g.gamma = Ly.ln2.g;
+      g.beta = Ly.ln2.b;
+      g.eps = c.ln_eps;
+      g.out_f32 = h->h;
+      g.out_p16 = h->hp16;
+      if (!c.only_last || l == c.layers - 1) {
+        g.out_stack = h->stack16;
+        g.stack_col = c.only_last ? 0 : l * D;
+        g.stack_kb = stack_kb;
+      }
+      g.M = Tn;
+      if ((rc = launch_ln<T>(D, g, st))) return rc;
+    }
+  }
+  // ---- audio projection: Linear -> LayerNorm -> SiLU
+  {
+    GemmArgs g = fmt_gemm_args(h->stack16, h->aproj, Tn);
+    g.out_f32 = h->yproj;
+    g.ldo = c.dim_w;
+    if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
+    AudLnArgs n;
+    memset(&n, 0, sizeof(n));
+    n.a = h->yproj;
+    n.gamma = h->aproj_ln.g;
+    n.beta = h->aproj_ln.b;
+    n.eps = 1e-5f;  // nn.LayerNorm default (FLOAT.py:340)
+    n.out_f32 = wa;
+    n.M = Tn;
+    n.silu = 1;
+    if ((rc = launch_ln<T>(c.dim_w, n, st))) return rc;
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int float_aud_create(const float_aud_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors, float_aud_t** out) {
+  FH_REQUIRE(cfg && tensors && out, "null argument to float_aud_create");
+  FH_REQUIRE(cfg->n_conv >= 2 && cfg->n_conv <= 8, "n_conv must be in [2,8] (got %d)", cfg->n_conv);
+  for (int i = 0; i < cfg->n_conv; ++i) {
+    FH_REQUIRE(cfg->conv_dim[i] == cfg->conv_dim[0] && cfg->conv_dim[i] % 256 == 0 && cfg->conv_dim[i] <= 512,
+               "conv_dim must be one value, 256 or 512 (layer %d: %d)", i, cfg->conv_dim[i]);
+    FH_REQUIRE(cfg->conv_kernel[i] >= 1 && cfg->conv_stride[i] >= 1, "bad conv kernel/stride at layer %d", i);
+  }
+  FH_REQUIRE(cfg->hidden % 256 == 0 && cfg->hidden <= 1024, "hidden size %d unsupported (multiple of 256, <= 1024)", cfg->hidden);
+  FH_REQUIRE(cfg->heads > 0 && cfg->hidden / cfg->heads == 64 && cfg->hidden % cfg->heads == 0, "head dim must be 64 (hidden %d, heads %d)",
+             cfg->hidden, cfg->heads);
+  FH_REQUIRE(cfg->intermediate % 128 == 0 && cfg->layers >= 1, "bad intermediate size / layer count");
+  FH_REQUIRE(cfg->pos_k % 4 == 0 && cfg->pos_groups >= 1 && cfg->hidden % cfg->pos_groups == 0, "bad positional conv shape");
+  FH_REQUIRE(cfg->dim_w % 256 == 0 && cfg->dim_w <= 1024, "dim_w %d unsupported", cfg->dim_w);
+  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
+  float_aud* h = new float_aud();
+  h->cfg = *cfg;
+  TensorTable tt(tensors, n_tensors);
+  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);
+  if (rc) {
+    float_aud_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return FLOAT_OK;
+}
+
+void float_aud_destroy(float_aud_t* h) {
+  if (!h) return;
+  h->pool.release();
+  h->ws.release();
+  delete h;
+}
+
+int float_aud_inference(float_aud_t* h, const float* a, int32_t n_samples, int32_t seq_len, float* wa, void* stream) {
+  FH_REQUIRE(h && a && wa, "null argument to float_aud_inference");
+  FH_REQUIRE(seq_len >= 1, "seq_len must be >= 1 (got %d)", seq_len);
+  FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
+  hipStream_t st = (hipStream_t)stream;
+  return h->cfg.dtype == FLOAT_DT_BF16 ? inference_impl<BF16>(h, a, n_samples, seq_len, wa, st)
+                                       : inference_impl<FP16>(h, a, n_samples, seq_len, wa, st);
+}
+
+}  // extern "C"

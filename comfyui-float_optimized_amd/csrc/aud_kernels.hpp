@@ -1,0 +1,430 @@
+// HIP kernels of the audio conditioning encoder: wav2vec2-base as the
+// reference drives it (src/nodes/models/wav2vec2.py:33-98,184-197: feature extractor -> linear
+// interpolation to T video frames -> feature projection -> transformer encoder with all hidden states) and the
+// 12x768 -> 512 audio projection (FLOAT.py:338-342).  The arithmetic of the transformers package is restated
+// from its published module definitions (Wav2Vec2FeatureEncoder / FeatureProjection / PositionalConvEmbedding /
+// EncoderLayer, feat_extract_norm = "group", do_stable_layer_norm = false: the bundled wav2vec2_base config).
+// The transformer's Linear layers run on the FMT's weight-streaming GEMM (fmt_gemm.hpp); this file holds the rest.
+#pragma once
+#include "common.hpp"
+#include "fmt_pack.hpp"
+
+// ------------------------------------------------------------------------------------------
+// Layer 0 of the feature extractor: Conv1d(1 -> C, k, stride, no bias) -> GroupNorm(C groups = per-channel
+// statistics over time, affine) -> GELU.  The conv is 10 MACs per output, so it is recomputed by the
+// statistics pass and by the apply pass instead of being stored in fp32.
+// Pass 1: partial (sum, sum of squares) per (time chunk, channel).
+template <int KW>
+__global__ __launch_bounds__(256) void aud_conv0_stats_kernel(const float* __restrict__ x, int n_samples, const float* __restrict__ w,
+                                                              int stride, int L, int C, int tchunk, float* __restrict__ part) {
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  if (c >= C) return;
+  float wk[KW];
+#pragma unroll
+  for (int k = 0; k < KW; ++k) wk[k] = w[c * KW + k];
+  const int t0 = blockIdx.x * tchunk, t1 = min(t0 + tchunk, L);
+  float s = 0.f, s2 = 0.f;
+  for (int t = t0; t < t1; ++t) {
+    const float* xp = x + (size_t)t * stride;
+    float y = 0.f;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) y += wk[k] * xp[k];
+    s += y;
+    s2 += y * y;
+  }
+  part[((size_t)blockIdx.x * C + c) * 2 + 0] = s;
+  part[((size_t)blockIdx.x * C + c) * 2 + 1] = s2;
+}
+
+// Pass 2: per-channel scale = gamma * rstd, shift = beta - mean * scale (GroupNorm eps), fp64 final sums.
+__global__ void aud_gn_final_kernel(const float* __restrict__ part, int nchunk, int C, int L, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float eps, float* __restrict__ scale_shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, s2 = 0.0;
+  for (int i = 0; i < nchunk; ++i) {
+    s += (double)part[((size_t)i * C + c) * 2 + 0];
+    s2 += (double)part[((size_t)i * C + c) * 2 + 1];
+  }
+  const double mean = s / L;
+  const double var = fmax(s2 / L - mean * mean, 0.0);  // biased variance, like torch group_norm
+  const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+  scale_shift[c] = sc;
+  scale_shift[C + c] = beta[c] - (float)mean * sc;
+}
+
+// Pass 3: y = gelu(conv * scale + shift) -> NLC 16-bit [L][C]; one thread = one time step x 8 channels.
+template <class T, int KW>
+__global__ __launch_bounds__(256) void aud_conv0_apply_kernel(const float* __restrict__ x, const float* __restrict__ w, int stride, int L,
+                                                              int C, const float* __restrict__ scale_shift, u16* __restrict__ out) {
+  const int c8 = C >> 3;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)L * c8) return;
+  const int cg = (int)(idx % c8);
+  const size_t t = idx / c8;
+  float xv[KW];
+#pragma unroll
+  for (int k = 0; k < KW; ++k) xv[k] = x[t * stride + k];
+  uint4 o;
+  u16* oe = reinterpret_cast<u16*>(&o);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int c = cg * 8 + i;
+    float y = 0.f;
+#pragma unroll
+    for (int k = 0; k < KW; ++k) y += w[c * KW + k] * xv[k];
+    oe[i] = T::from_float(fh_gelu_erf(y * scale_shift[c] + scale_shift[C + c]));
+  }
+  *reinterpret_cast<uint4*>(out + t * C + cg * 8) = o;
+}
+
+// ------------------------------------------------------------------------------------------
+// Conv1d(Cin -> N, k, stride, no padding) + GELU on NLC 16-bit activations, as ONE GEMM: row t of the A operand
+// is the contiguous window x[t*stride .. t*stride + k) x Cin of the input buffer, i.e. A is row-major with
+// leading dimension stride*Cin and K = k*Cin (rows overlap; nothing is copied).  W is [N][K] with K ordered
+// (tap, channel).  128 x 64 output tile per workgroup, K in steps of 64 through swizzled, double-buffered LDS
+// (64-byte half-rows, 16-byte chunk index XOR (row>>1)&3: conflict-free ds_read_b128, as in the decoder);
+// the global loads of step s+1 are issued before the MFMAs of step s.  Operands swapped (D = W A^T) so a lane
+// holds 4 consecutive output channels of one row.
+struct AudGemmArgs {
+  const u16* A;
+  long long lda;  // elements between consecutive rows of A
+  const u16* W;   // [N][K]
+  const float* bias;  // [N] or nullptr
+  u16* out;       // [M][ldc]
+  int M, N, K, ldc, act;  // act 1: GELU(erf)
+};
+
+template <class T>
+__global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
+  constexpr int BM = 128, BN = 64, BK = 64;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // staging: A tile = 128 rows x 8 chunks (16 B) = 1024 chunks -> 4 per thread; B tile = 64 x 8 = 512 -> 2 per thread
+  // LDS image per operand: [half h = chunk>>2][row][4 chunks], chunk' = (chunk&3) ^ ((row>>1)&3)
+  auto lds_off = [](int rows, int row, int chunk) { return ((chunk >> 2) * rows + row) * 64 + (((chunk & 3) ^ ((row >> 1) & 3)) << 4); };
+  u32x4 ra[4], rb[2];
+  auto issue = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256, row = e >> 3, ch = e & 7;
+      const int m = m0 + row;
+      ra[i] = (m < g.M) ? *reinterpret_cast<const u32x4*>(g.A + (size_t)m * g.lda + k0 + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256, row = e >> 3, ch = e & 7;
+      rb[i] = *reinterpret_cast<const u32x4*>(g.W + (size_t)(n0 + row) * g.K + k0 + ch * 8);
+    }
+  };
+  auto commit = [&](int buf) {
+    unsigned char* sA = smem + buf * (BM + BN) * BK * 2;
+    unsigned char* sB = sA + BM * BK * 2;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * 256;
+      *reinterpret_cast<u32x4*>(sA + lds_off(BM, e >> 3, e & 7)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256;
+      *reinterpret_cast<u32x4*>(sB + lds_off(BN, e >> 3, e & 7)) = rb[i];
+    }
+  };
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nsteps = g.K / BK;
+  issue(0);
+  commit(0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nsteps) issue((s + 1) * BK);
+    const unsigned char* sA = smem + buf * (BM + BN) * BK * 2;
+    const unsigned char* sB = sA + BM * BK * 2;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      u32x4 a[2], b[4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const u32x4*>(sA + lds_off(BM, w * 32 + i * 16 + r16, kb * 4 + q));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + lds_off(BN, j * 16 + r16, kb * 4 + q));
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = T::mfma(b[j], a[i], acc[i][j]);
+    }
+    if (s + 1 < nsteps) {
+      commit(buf ^ 1);  // last read in step s-1; a barrier has passed since
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m0 + w * 32 + i * 16 + r16;
+    if (m >= g.M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j * 16 + q * 4;
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (g.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] += bb.x;
+        v[1] += bb.y;
+        v[2] += bb.z;
+        v[3] += bb.w;
+      }
+      if (g.act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fh_gelu_erf(v[r]);
+      }
+      ushort4 o;
+      o.x = T::from_float(v[0]);
+      o.y = T::from_float(v[1]);
+      o.z = T::from_float(v[2]);
+      o.w = T::from_float(v[3]);
+      *reinterpret_cast<ushort4*>(g.out + (size_t)m * g.ldc + n) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// linear_interpolation(features, seq_len) (wav2vec2.py:184-197: F.interpolate(mode='linear', align_corners=True)
+// along time) fused with the feature projection's LayerNorm (Wav2Vec2FeatureProjection.layer_norm, affine).
+// One wave per output frame; writes the packed 16-bit A operand of the projection GEMM (K = C).
+template <class T, int NV>
+__global__ __launch_bounds__(256) void aud_interp_ln_kernel(const u16* __restrict__ f, int L, int Tn, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float eps, u16* __restrict__ out) {
+  constexpr int C = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= Tn) return;
+  const float scale = (Tn > 1) ? (float)(L - 1) / (float)(Tn - 1) : 0.f;
+  const float src = scale * (float)t;
+  const int i0 = min((int)src, L - 1), i1 = min(i0 + 1, L - 1);
+  const float l1 = src - (float)i0, l0 = 1.f - l1;
+  float v[NV][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    const ushort4 a = *reinterpret_cast<const ushort4*>(f + (size_t)i0 * C + c);
+    const ushort4 b = *reinterpret_cast<const ushort4*>(f + (size_t)i1 * C + c);
+    v[i][0] = l0 * T::to_float(a.x) + l1 * T::to_float(b.x);
+    v[i][1] = l0 * T::to_float(a.y) + l1 * T::to_float(b.y);
+    v[i][2] = l0 * T::to_float(a.z) + l1 * T::to_float(b.z);
+    v[i][3] = l0 * T::to_float(a.w) + l1 * T::to_float(b.w);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mu = wave_sum(s) * (1.f / C);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s2 += (v[i][e] - mu) * (v[i][e] - mu);
+  const float rstd = rsqrtf(wave_sum(s2) * (1.f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+    ushort4 o;
+    o.x = T::from_float((v[i][0] - mu) * rstd * gm.x + bt.x);
+    o.y = T::from_float((v[i][1] - mu) * rstd * gm.y + bt.y);
+    o.z = T::from_float((v[i][2] - mu) * rstd * gm.z + bt.z);
+    o.w = T::from_float((v[i][3] - mu) * rstd * gm.w + bt.w);
+    *reinterpret_cast<ushort4*>(out + fmt_pack_off(t, c, C / 32)) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// y = LayerNorm(a + res) * gamma + beta (eps), one wave per row, D = NV*256:
+//   the encoder's first LayerNorm (hidden + positional embedding), each layer's post-attention and final
+//   LayerNorm (Wav2Vec2EncoderLayer.forward), and the audio projection's LayerNorm + SiLU (FLOAT.py:338-342).
+// Outputs (each optional): fp32 row-major (the residual stream), packed 16-bit A operand of the next GEMM
+// (KB = D/32), and a second packed copy at column offset `stack_col` of a wider operand (KB = stack_kb): the
+// (T, layers*D) stack of hidden states that feeds the audio projection (FLOAT.py:345-352).
+struct AudLnArgs {
+  const float* a;
+  const float* res;  // or nullptr
+  const float *gamma, *beta;
+  float eps;
+  float* out_f32;
+  u16* out_p16;
+  u16* out_stack;
+  int stack_col, stack_kb;
+  int M, silu;
+};
+
+template <class T, int NV>
+__global__ __launch_bounds__(256) void aud_ln_kernel(AudLnArgs g) {
+  constexpr int D = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= g.M) return;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    v[i] = *reinterpret_cast<const float4*>(g.a + (size_t)row * D + c);
+    if (g.res) {
+      const float4 r = *reinterpret_cast<const float4*>(g.res + (size_t)row * D + c);
+      v[i].x += r.x;
+      v[i].y += r.y;
+      v[i].z += r.z;
+      v[i].w += r.w;
+    }
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mu = wave_sum(s) * (1.f / D);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float d0 = v[i].x - mu, d1 = v[i].y - mu, d2 = v[i].z - mu, d3 = v[i].w - mu;
+    s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+  }
+  const float rstd = rsqrtf(wave_sum(s2) * (1.f / D) + g.eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(g.gamma + c);
+    const float4 bt = *reinterpret_cast<const float4*>(g.beta + c);
+    float4 y;
+    y.x = (v[i].x - mu) * rstd * gm.x + bt.x;
+    y.y = (v[i].y - mu) * rstd * gm.y + bt.y;
+    y.z = (v[i].z - mu) * rstd * gm.z + bt.z;
+    y.w = (v[i].w - mu) * rstd * gm.w + bt.w;
+    if (g.silu) {
+      y.x = fh_silu(y.x);
+      y.y = fh_silu(y.y);
+      y.z = fh_silu(y.z);
+      y.w = fh_silu(y.w);
+    }
+    if (g.out_f32) *reinterpret_cast<float4*>(g.out_f32 + (size_t)row * D + c) = y;
+    if (g.out_p16 || g.out_stack) {
+      ushort4 o;
+      o.x = T::from_float(y.x);
+      o.y = T::from_float(y.y);
+      o.z = T::from_float(y.z);
+      o.w = T::from_float(y.w);
+      if (g.out_p16) *reinterpret_cast<ushort4*>(g.out_p16 + fmt_pack_off(row, c, D / 32)) = o;
+      if (g.out_stack) *reinterpret_cast<ushort4*>(g.out_stack + fmt_pack_off(row, g.stack_col + c, g.stack_kb)) = o;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wav2Vec2PositionalConvEmbedding: grouped Conv1d(D, D, k = 128, padding 64, groups 16) on the time axis, drop
+// the last output (even kernel), GELU.  Weight-norm is folded on the host.  Two adjacent groups are merged into
+// one block-diagonal 96 x 96 slab per tap so that K per tap is 3 MFMA k-blocks (48 channels per group is not a
+// multiple of 32); the zero blocks cost 2x the flops of a 2.4 GFLOP layer.
+//   workgroup = (16 output frames, group pair); its 4 waves split the taps, partial sums meet in LDS.
+//   A fragments are converted from the fp32 residual stream on the fly; W is [pair][tap][96 out][96 in] 16-bit.
+template <class T, int GP /* channels per merged group */>
+__global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restrict__ x, int Tn, int D, const u16* __restrict__ W,
+                                                          const float* __restrict__ bias, int ktaps, int pad, float* __restrict__ out) {
+  constexpr int NT = GP / 16, KBN = GP / 32;
+  __shared__ float red[4][16][GP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int t0 = blockIdx.x * 16, gp = blockIdx.y;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int tpw = ktaps / 4;
+  for (int kk = w * tpw; kk < (w + 1) * tpw; ++kk) {
+    const int t = t0 + r16 + kk - pad;
+    const bool ok = t >= 0 && t < Tn;
+    const float* xr = x + (size_t)(ok ? t : 0) * D + gp * GP + q * 8;
+    const u16* wr = W + (((size_t)gp * ktaps + kk) * GP + r16) * GP + q * 8;
+#pragma unroll
+    for (int kb = 0; kb < KBN; ++kb) {
+      u32x4 a = u32x4{0u, 0u, 0u, 0u};
+      if (ok) {
+        const float4 f0 = *reinterpret_cast<const float4*>(xr + kb * 32);
+        const float4 f1 = *reinterpret_cast<const float4*>(xr + kb * 32 + 4);
+        a[0] = (unsigned)T::from_float(f0.x) | ((unsigned)T::from_float(f0.y) << 16);
+        a[1] = (unsigned)T::from_float(f0.z) | ((unsigned)T::from_float(f0.w) << 16);
+        a[2] = (unsigned)T::from_float(f1.x) | ((unsigned)T::from_float(f1.y) << 16);
+        a[3] = (unsigned)T::from_float(f1.z) | ((unsigned)T::from_float(f1.w) << 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const u32x4 b = *reinterpret_cast<const u32x4*>(wr + (size_t)j * 16 * GP + kb * 32);
+        acc[j] = T::mfma(a, b, acc[j]);  // D[row = frame q*4+reg][col = channel r16]
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[w][q * 4 + r][j * 16 + r16] = acc[j][r];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < 16 * GP; idx += 256) {
+    const int r = idx / GP, c = idx % GP;
+    const int t = t0 + r;
+    if (t >= Tn) continue;
+    const float v = red[0][r][c] + red[1][r][c] + red[2][r][c] + red[3][r][c] + bias[gp * GP + c];
+    out[(size_t)t * D + gp * GP + c] = fh_gelu_erf(v);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wav2Vec2Attention (eager): softmax(q k^T * head_dim^-0.5) v over ALL frames, no mask.  One wave per (query,
+// head): lanes own keys (scores) and then head dimensions (weighted sum of V).  Head dim 64.  qkv is row-major
+// 16-bit [T][3*D] (q | k | v); the output is the packed A operand of out_proj (K = D).
+template <class T>
+__global__ __launch_bounds__(256) void aud_attn_kernel(const u16* __restrict__ qkv, int Tn, int D, int heads, u16* __restrict__ out) {
+  constexpr int HD = 64;
+  extern __shared__ float sm[];  // per wave: q[64] + p[Tn]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int qi = blockIdx.x * 4 + w, h = blockIdx.y;
+  float* sq = sm + (size_t)w * (HD + Tn);
+  float* sp = sq + HD;
+  const bool live = qi < Tn;
+  const int ld = 3 * D;
+  if (live) sq[lane] = T::to_float(qkv[(size_t)qi * ld + h * HD + lane]) * 0.125f;  // head_dim^-0.5 = 1/8
+  __syncthreads();
+  if (!live) return;
+  float mx = -INFINITY;
+  for (int j = lane; j < Tn; j += 64) {
+    const u16* kp = qkv + (size_t)j * ld + D + h * HD;
+    float dot = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; c += 8) {
+      const uint4 u = *reinterpret_cast<const uint4*>(kp + c);
+      const u16* e = reinterpret_cast<const u16*>(&u);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dot += sq[c + i] * T::to_float(e[i]);
+    }
+    sp[j] = dot;
+    mx = fmaxf(mx, dot);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f;
+  for (int j = lane; j < Tn; j += 64) {
+    const float p = __expf(sp[j] - mx);
+    sp[j] = p;
+    sum += p;
+  }
+  sum = wave_sum(sum);
+  __builtin_amdgcn_wave_barrier();
+  __threadfence_block();
+  const u16* vp = qkv + 2 * D + h * HD + lane;
+  float acc = 0.f;
+  int j = 0;
+  for (; j + 4 <= Tn; j += 4) {
+    const float v0 = T::to_float(vp[(size_t)(j + 0) * ld]), v1 = T::to_float(vp[(size_t)(j + 1) * ld]);
+    const float v2 = T::to_float(vp[(size_t)(j + 2) * ld]), v3 = T::to_float(vp[(size_t)(j + 3) * ld]);
+    acc += sp[j] * v0 + sp[j + 1] * v1 + sp[j + 2] * v2 + sp[j + 3] * v3;
+  }
+  for (; j < Tn; ++j) acc += sp[j] * T::to_float(vp[(size_t)j * ld]);
+  out[fmt_pack_off(qi, h * HD + lane, D / 32)] = T::from_float(acc / sum);
+}

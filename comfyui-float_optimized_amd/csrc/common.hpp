@@ -110,6 +110,9 @@ __device__ __forceinline__ float fh_gelu_tanh(float x) {
   const float u = k0 * (x + 0.044715f * x * x * x);
   return x * __frcp_rn(1.f + __expf(-2.f * u));
 }
+__device__ __forceinline__ float fh_gelu_erf(float x) {  // exact GELU: 0.5 x (1 + erf(x / sqrt(2)))
+  return 0.5f * x * (1.f + erff(x * 0.70710678118654752f));
+}
 __device__ __forceinline__ float fh_lrelu_s2(float x) {  // leaky_relu(x, 0.2) * sqrt(2)
   return (x > 0.f ? x : 0.2f * x) * 1.4142135623730951f;
 }

@@ -2,15 +2,12 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include "fmt_gemm.hpp"
 #include "fmt_kernels.hpp"
 
 namespace {
 
-struct Lin {
-  u16* W = nullptr;     // packed [N/16][K/32][64][8] 16-bit (fmt_pack_off), K padded to 128
-  float* b = nullptr;   // [N]
-  int N = 0, K = 0;
-};
+typedef FmtLin Lin;
 
 struct Blk {
   Lin qkv, proj, fc1, fc2;
@@ -63,8 +60,8 @@ namespace {
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
 template <class T>
-int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
-                Lin* out) {
+int pack_linear_pool(DevicePool* pool, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
+                     Lin* out) {
   // Concatenate the named Linear layers along N (used to fuse every adaLN projection into one GEMM).
   const int Kp = round_up(K, 128);
   const int N = N_each * (int)names.size();
@@ -91,13 +88,18 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
     n0 += N_each;
   }
   int rc;
-  if ((rc = h->pool.alloc(&out->W, hw.size(), false))) return rc;
-  if ((rc = h->pool.alloc(&out->b, hb.size(), false))) return rc;
+  if ((rc = pool->alloc(&out->W, hw.size(), false))) return rc;
+  if ((rc = pool->alloc(&out->b, hb.size(), false))) return rc;
   FH_CHECK_HIP(hipMemcpy(out->W, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMemcpy(out->b, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
   out->N = N;
   out->K = Kp;
   return FLOAT_OK;
+}
+
+template <class T>
+int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K, Lin* out) {
+  return pack_linear_pool<T>(&h->pool, tt, names, N_each, K, out);
 }
 
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
@@ -208,6 +210,7 @@ void prime_kernels() {
   prime_epi<T, EPI_XEMBED>();
   prime_epi<T, EPI_CFG>();
   prime_epi<T, EPI_PARTIAL>();
+  prime_epi<T, EPI_GELUERF_P16>();
   GemmArgs g;
   memset(&g, 0, sizeof(g));
   (void)launch_wide<T>(g, true, nullptr);
@@ -777,6 +780,58 @@ int create_impl(float_fmt* h, const TensorTable& tt) {
 }
 
 }  // namespace
+
+
+// ---------------------------------------------------------------- GEMM service (fmt_gemm.hpp)
+int fmt_pack_linear(DevicePool* pool, int dtype, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
+                    FmtLin* out) {
+  return dtype == FLOAT_DT_BF16 ? pack_linear_pool<BF16>(pool, tt, names, N_each, K, out)
+                                : pack_linear_pool<FP16>(pool, tt, names, N_each, K, out);
+}
+
+int fmt_pack_linear_raw(DevicePool* pool, int dtype, const float* w, const float* b, int N, int K, FmtLin* out) {
+  std::vector<float> zeros;
+  if (!b) {
+    zeros.assign(N, 0.f);
+    b = zeros.data();
+  }
+  float_tensor_t t[2];
+  memset(t, 0, sizeof(t));
+  t[0].name = "raw.weight";
+  t[0].data = w;
+  t[0].ndim = 2;
+  t[0].shape[0] = N;
+  t[0].shape[1] = K;
+  t[1].name = "raw.bias";
+  t[1].data = b;
+  t[1].ndim = 1;
+  t[1].shape[0] = N;
+  TensorTable tt(t, 2);
+  return fmt_pack_linear(pool, dtype, tt, {"raw"}, N, K, out);
+}
+
+GemmArgs fmt_gemm_args(const u16* A, const FmtLin& L, int M) { return base_args(A, L, M); }
+
+void fmt_gemm_prime(int dtype) {
+  if (dtype == FLOAT_DT_BF16) prime_kernels<BF16>();
+  else prime_kernels<FP16>();
+}
+
+template <class T>
+static int gemm_run_t(int epi, const GemmArgs& g, hipStream_t s) {
+  switch (epi) {
+    case EPI_F32: return run_gemm<T, EPI_F32>(g, s);
+    case EPI_T16: return run_gemm<T, EPI_T16>(g, s);
+    case EPI_SILU_P16: return run_gemm<T, EPI_SILU_P16>(g, s);
+    case EPI_GELU_P16: return run_gemm<T, EPI_GELU_P16>(g, s);
+    case EPI_GELUERF_P16: return run_gemm<T, EPI_GELUERF_P16>(g, s);
+    default: fh_set_error("fmt_gemm_run: epilogue %d is not exported", epi); return FLOAT_E_INVALID;
+  }
+}
+
+int fmt_gemm_run(int dtype, int epi, GemmArgs g, hipStream_t s) {
+  return dtype == FLOAT_DT_BF16 ? gemm_run_t<BF16>(epi, g, s) : gemm_run_t<FP16>(epi, g, s);
+}
 
 extern "C" {
 

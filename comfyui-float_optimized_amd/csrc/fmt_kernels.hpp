@@ -13,48 +13,7 @@
 // blockIdx.y, i.e. by a multiple of gridDim.x (a multiple of 8), so they sit on one XCD's L2.
 #pragma once
 #include "common.hpp"
-
-enum {
-  EPI_F32 = 0,       // out_f32 = acc + bias                                   (row-major fp32)
-  EPI_T16 = 1,       // out16   = T(acc + bias)                                (row-major, feeds attention)
-  EPI_SILU_P16 = 2,  // out16   = T(silu(acc + bias))                          (packed, feeds a GEMM)
-  EPI_GELU_P16 = 3,  // out16   = T(gelu_tanh(acc + bias))                     (packed, feeds a GEMM)
-  EPI_GATE_RES = 4,  // out_f32 += gate * (acc + bias)                         (FMT.py:174-175)
-  EPI_XEMBED = 5,    // out_f32[b*ntok + r] = acc + bias + pos[r], b < bc       (FMT.py:319-320)
-  EPI_CFG = 6,       // CFG combine (+ Euler update) on the final linear        (FMT.py:375-399)
-  EPI_PARTIAL = 7    // slab[ks][row][n] = acc  (split-K slice ks, no bias): summed, gated and added to the
-                     // residual stream by the LayerNorm kernel that follows (fmt_lnmod_kernel<.., KS>)
-};
-
-// element offset of (row, k) in a packed operand with KB = K/32 k-blocks
-__host__ __device__ __forceinline__ size_t fmt_pack_off(int row, int k, int KB) {
-  return ((size_t)((row >> 4) * KB + (k >> 5)) * 64 + (row & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
-}
-
-struct GemmArgs {
-  const u16* A;   // packed [row tiles][KB][64][8]; pad rows/columns are zero
-  const u16* W;   // packed [N/16][KB][64][8]
-  const float* bias;
-  int K, M, N;    // K padded to a multiple of 128
-  int mblk;       // number of row blocks (grid = N/BN * mblk workgroups)
-  float* out_f32;
-  int ldo;
-  u16* out16;
-  int ldo16;      // row-major leading dim (EPI_T16) or KB of the consumer (packed epilogues)
-  const float* gate;
-  int ldg;
-  const float* pos;
-  int bc, ntok, n_prev;
-  // EPI_CFG
-  float a_cfg, r_cfg, e_cfg, dt;
-  float* vout;   // (ntok, N) combined velocity (float_fmt_eval) or nullptr
-  float* xcur;   // (ntok - n_prev, N) Euler state or nullptr
-  u16* xin16;    // next evaluation's x_embedder input, packed with KB = ldx
-  int ldx;
-  // EPI_PARTIAL: K is cut into ksplit slices, one per workgroup; slice ks writes out_f32 + ks * slab_stride
-  int ksplit;
-  size_t slab_stride;
-};
+#include "fmt_pack.hpp"
 
 template <class T, int MTW, int NT, int NW, int EPI>
 __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
@@ -227,7 +186,7 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         float* o = g.out_f32 + (size_t)ks * g.slab_stride + (size_t)row * g.ldo + nb;
         *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
-      } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16) {
+      } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16 || EPI == EPI_GELUERF_P16) {
         uint4 u;
         u16* e = reinterpret_cast<u16*>(&u);
 #pragma unroll
@@ -235,6 +194,7 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
           float x = v[i];
           if constexpr (EPI == EPI_SILU_P16) x = fh_silu(x);
           if constexpr (EPI == EPI_GELU_P16) x = fh_gelu_tanh(x);
+          if constexpr (EPI == EPI_GELUERF_P16) x = fh_gelu_erf(x);
           e[i] = T::from_float(x);
         }
         if constexpr (EPI == EPI_T16) *reinterpret_cast<uint4*>(g.out16 + (size_t)row * g.ldo16 + nb) = u;

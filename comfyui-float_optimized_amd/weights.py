@@ -183,3 +183,62 @@ def synth_encoder_state(size=512, dim=512, dim_motion=20, seed=0):
     sd["fc.4.weight"] = _randn(seed, "fc.4.weight", (dim_motion, dim))
     sd["fc.4.bias"] = _randn(seed, "fc.4.bias", (dim_motion,), 0.1)
     return sd
+
+
+def synth_audio_state(cfg, seed=0):
+    """AudioEncoder weights in the reference layout (`audio_encoder.` prefix stripped): transformers' Wav2Vec2Model
+    keys under `wav2vec2.` (FLOAT.py:318,326) and `audio_projection.{0,1}` (FLOAT.py:338-342).  cfg: AudioConfig.
+    Scales keep activations O(1) through the GELU conv stack and the post-LayerNorm encoder."""
+    sd = {}
+    p = "wav2vec2."
+    cin = 1
+    for i, (co, k) in enumerate(zip(cfg.conv_dim, cfg.conv_kernel)):
+        q = p + "feature_extractor.conv_layers.%d." % i
+        sd[q + "conv.weight"] = _randn(seed, q + "conv.weight", (co, cin, k), math.sqrt(2.0 / (cin * k)))
+        if i == 0:
+            sd[q + "layer_norm.weight"] = 1.0 + _randn(seed, q + "layer_norm.weight", (co,), 0.1)
+            sd[q + "layer_norm.bias"] = _randn(seed, q + "layer_norm.bias", (co,), 0.1)
+        cin = co
+    D, C = cfg.hidden_size, cfg.conv_dim[-1]
+
+    def lin(name, n, k, std=None):
+        sd[name + ".weight"] = _randn(seed, name + ".weight", (n, k), std if std is not None else 1.0 / math.sqrt(k))
+        sd[name + ".bias"] = _randn(seed, name + ".bias", (n,), 0.05)
+
+    def ln(name, n):
+        sd[name + ".weight"] = 1.0 + _randn(seed, name + ".weight", (n,), 0.1)
+        sd[name + ".bias"] = _randn(seed, name + ".bias", (n,), 0.1)
+
+    sd[p + "masked_spec_embed"] = _randn(seed, p + "masked_spec_embed", (D,))  # unused at inference (mask_time_indices=None)
+    ln(p + "feature_projection.layer_norm", C)
+    lin(p + "feature_projection.projection", D, C)
+    q = p + "encoder.pos_conv_embed.conv."
+    cpg, K = D // cfg.num_conv_pos_embedding_groups, cfg.num_conv_pos_embeddings
+    v = _randn(seed, q + "v", (D, cpg, K))
+    sd[q + "parametrizations.weight.original1"] = v
+    sd[q + "parametrizations.weight.original0"] = (v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt() * (1.0 / math.sqrt(cpg * K))
+                                                   * (1.0 + _randn(seed, q + "g", (1, 1, K), 0.1)))
+    sd[q + "bias"] = _randn(seed, q + "bias", (D,), 0.05)
+    ln(p + "encoder.layer_norm", D)
+    for l in range(cfg.num_hidden_layers):
+        q = p + "encoder.layers.%d." % l
+        for nm in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            lin(q + "attention." + nm, D, D)
+        ln(q + "layer_norm", D)
+        lin(q + "feed_forward.intermediate_dense", cfg.intermediate_size, D)
+        lin(q + "feed_forward.output_dense", D, cfg.intermediate_size)
+        ln(q + "final_layer_norm", D)
+    din = D if cfg.only_last_features else D * cfg.num_hidden_layers
+    lin("audio_projection.0", cfg.dim_w, din)
+    ln("audio_projection.1", cfg.dim_w)
+    return sd
+
+
+def synth_waveform(seconds, seed=1, sr=16000):
+    """SURVEY.md 8d synthetic audio: 0.1 N(0,1) + 0.3 sin(2 pi 220 t), then zero-mean / unit-variance like
+    Wav2Vec2FeatureExtractor(do_normalize=True) (generate.py:69-73).  Returns (1, N) fp32."""
+    n = int(round(seconds * sr))
+    t = np.arange(n, dtype=np.float64) / sr
+    w = 0.1 * np.random.RandomState(seed).standard_normal(n) + 0.3 * np.sin(2 * np.pi * 220.0 * t)
+    w = (w - w.mean()) / np.sqrt(w.var() + 1e-7)
+    return torch.from_numpy(w.astype(np.float32))[None]

@@ -179,6 +179,42 @@ int float_enc_forward(float_enc_t* h, const float* img, float* s_r, float* lam, 
 int float_enc_feats16(float_enc_t* h, const void** feats16, int32_t* channels, int32_t max_feats,
                       int32_t* n_out);
 
+/* ---------------------------------------------------------------- audio encoder --- */
+/* Audio conditioning, once per clip: AudioEncoder.inference (reference
+ * src/nodes/models/float/FLOAT.py:370-375) = Wav2VecModel.forward(input_values, seq_len,
+ * output_hidden_states=True) (src/nodes/models/wav2vec2.py:33-98: feature extractor ->
+ * linear_interpolation(align_corners=True) to seq_len frames (:184-197) -> feature projection -> encoder),
+ * hidden_states[1:] stacked per frame (FLOAT.py:345-352) and audio_projection = Linear -> LayerNorm ->
+ * SiLU (FLOAT.py:338-342).  The wav2vec2 arithmetic itself lives in the `transformers` package
+ * (requirements.txt:8, not vendored); it is restated from that package's module definitions for the bundled
+ * wav2vec2_base config (src/nodes/model_configs/wav2vec2_base/config.json: feat_extract_norm "group",
+ * conv_bias false, do_stable_layer_norm false, eager attention without mask).
+ * Checkpoint keys: `wav2vec2.*` and `audio_projection.{0,1}.*` (prefix `audio_encoder.` stripped);
+ * the positional conv accepts `parametrizations.weight.original0/1`, `weight_g/weight_v` or a plain `weight`. */
+typedef struct {
+  int32_t n_conv;              /* feature-extractor layers (7) */
+  int32_t conv_dim[8], conv_kernel[8], conv_stride[8];
+  int32_t hidden, layers, heads, intermediate;   /* 768, 12, 12, 3072 */
+  int32_t pos_k, pos_groups;   /* num_conv_pos_embeddings 128, groups 16 */
+  int32_t dim_w;               /* 512 */
+  int32_t only_last;           /* opt.only_last_features */
+  int32_t dtype;               /* FLOAT_DT_* of activations / weights; statistics and the residual stream are fp32 */
+  float ln_eps;                /* layer_norm_eps 1e-5 */
+} float_aud_cfg_t;
+
+typedef struct float_aud float_aud_t;
+
+int float_aud_create(const float_aud_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors,
+                     float_aud_t** out);
+void float_aud_destroy(float_aud_t* h);
+
+/* a: (n_samples) fp32 device, the normalised 16 kHz waveform already replicate-padded by the caller to a
+ * multiple of seq_len * sampling_rate / fps when needed (FLOAT.py:371-373);  wa: (seq_len, dim_w) fp32.
+ * Exception to the no-allocation rule: the workspace is (re)grown, after a stream synchronise, when a clip is
+ * longer than any seen before. */
+int float_aud_inference(float_aud_t* h, const float* a, int32_t n_samples, int32_t seq_len, float* wa,
+                        void* stream);
+
 /* ---------------------------------------------------------------- misc ------------ */
 int float_hip_abi_version(void);
 const char* float_last_error(void);

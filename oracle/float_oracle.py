@@ -439,3 +439,113 @@ def encode_appearance(sd, img, dtype=torch.float32):
         lam = equal_linear(lam, sd["fc.%d.weight" % i], sd["fc.%d.bias" % i])
         i += 1
     return s_r, feats, lam
+
+
+# ------------------------------------------------------------------------- audio conditioning encoder
+# SURVEY.md section 8f row 2.  The reference subclasses transformers' Wav2Vec2Model (wav2vec2.py:10) and only
+# overrides forward to insert the interpolation (wav2vec2.py:66-68); the module arithmetic below restates the
+# `transformers` package (requirements.txt:8 `transformers>=4`; 5.15.0 installed where the goldens were made):
+# Wav2Vec2FeatureEncoder / GroupNormConvLayer / NoLayerNormConvLayer / FeatureProjection /
+# PositionalConvEmbedding / SamePadLayer / Encoder / EncoderLayer / Attention (eager) / FeedForward, for
+# feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False (model_configs/wav2vec2_base/config.json).
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))  # ACT2FN["gelu"] = exact GELU
+
+
+def _ln_affine(x, w, b, eps):
+    mu = x.mean(dim=-1, keepdim=True)
+    var = ((x - mu) ** 2).mean(dim=-1, keepdim=True)
+    return (x - mu) / torch.sqrt(var + eps) * w + b
+
+
+def wav2vec_features(sd, cfg, a, dtype=torch.float32):
+    """feature_extractor(input_values) (wav2vec2.py:64-65): (B,N) -> (B,C,L)."""
+    p = "wav2vec2.feature_extractor.conv_layers."
+    h = a.to(dtype)[:, None]
+    for i, s in enumerate(cfg.conv_stride):
+        h = F.conv1d(h, sd[p + "%d.conv.weight" % i].to(dtype), stride=s)
+        if i == 0:  # GroupNorm(num_groups = C): per-channel statistics over time, eps 1e-5, affine
+            mu = h.mean(dim=2, keepdim=True)
+            var = ((h - mu) ** 2).mean(dim=2, keepdim=True)
+            h = (h - mu) / torch.sqrt(var + 1e-5) * sd[p + "0.layer_norm.weight"].to(dtype)[None, :, None] \
+                + sd[p + "0.layer_norm.bias"].to(dtype)[None, :, None]
+        h = _gelu(h)
+    return h
+
+
+def linear_interpolation(feat, seq_len):
+    """wav2vec2.py:184-197: F.interpolate(features^T, size=seq_len, mode='linear', align_corners=True)^T, written
+    out: src = t (L-1)/(T-1); out = (1-w) f[floor(src)] + w f[floor(src)+1].  feat (B,L,C)."""
+    B, L, C = feat.shape
+    if seq_len == 1:
+        return feat[:, :1]
+    scale = torch.tensor((L - 1) / (seq_len - 1), dtype=torch.float32)
+    src = scale * torch.arange(seq_len, dtype=torch.float32)
+    i0 = src.floor().long().clamp(max=L - 1)
+    i1 = (i0 + 1).clamp(max=L - 1)
+    w = (src - i0.float()).to(feat.dtype)[None, :, None]
+    return (1 - w) * feat[:, i0] + w * feat[:, i1]
+
+
+def pos_conv_weight(sd, dtype=torch.float32):
+    """weight_norm(conv, dim=2): w = g * v / ||v||, the norm taken over (out, in) for every tap."""
+    p = "wav2vec2.encoder.pos_conv_embed.conv."
+    if p + "parametrizations.weight.original1" in sd:
+        g, v = sd[p + "parametrizations.weight.original0"].to(dtype), sd[p + "parametrizations.weight.original1"].to(dtype)
+    elif p + "weight_v" in sd:
+        g, v = sd[p + "weight_g"].to(dtype), sd[p + "weight_v"].to(dtype)
+    else:
+        return sd[p + "weight"].to(dtype)
+    return g * v / v.pow(2).sum(dim=(0, 1), keepdim=True).sqrt()
+
+
+def wav2vec_encoder(sd, cfg, h, dtype=torch.float32):
+    """Wav2Vec2Encoder.forward without mask: returns the list hidden_states[1:] (one (B,T,D) per layer)."""
+    p = "wav2vec2.encoder."
+    g = lambda k: sd[p + k].to(dtype)  # noqa: E731
+    K = cfg.num_conv_pos_embeddings
+    pos = F.conv1d(h.transpose(1, 2), pos_conv_weight(sd, dtype), g("pos_conv_embed.conv.bias"), padding=K // 2,
+                   groups=cfg.num_conv_pos_embedding_groups)
+    if K % 2 == 0:
+        pos = pos[:, :, :-1]  # Wav2Vec2SamePadLayer
+    h = h + _gelu(pos).transpose(1, 2)
+    h = _ln_affine(h, g("layer_norm.weight"), g("layer_norm.bias"), cfg.layer_norm_eps)
+    H = cfg.num_attention_heads
+    hd = cfg.hidden_size // H
+    outs = []
+    for l in range(cfg.num_hidden_layers):
+        q = "layers.%d." % l
+        lin = lambda x, n: x @ g(q + n + ".weight").T + g(q + n + ".bias")  # noqa: E731
+        B, T, D = h.shape
+        qh = lin(h, "attention.q_proj").view(B, T, H, hd).transpose(1, 2)
+        kh = lin(h, "attention.k_proj").view(B, T, H, hd).transpose(1, 2)
+        vh = lin(h, "attention.v_proj").view(B, T, H, hd).transpose(1, 2)
+        att = torch.softmax(qh @ kh.transpose(-1, -2) * hd ** -0.5, dim=-1) @ vh
+        att = lin(att.transpose(1, 2).reshape(B, T, D), "attention.out_proj")
+        h = _ln_affine(h + att, g(q + "layer_norm.weight"), g(q + "layer_norm.bias"), cfg.layer_norm_eps)
+        ff = lin(_gelu(lin(h, "feed_forward.intermediate_dense")), "feed_forward.output_dense")
+        h = _ln_affine(h + ff, g(q + "final_layer_norm.weight"), g(q + "final_layer_norm.bias"), cfg.layer_norm_eps)
+        outs.append(h)
+    return outs
+
+
+def audio_encoder_inference(sd, cfg, a, seq_len, sampling_rate=16000, fps=25.0, dtype=torch.float32):
+    """AudioEncoder.inference (FLOAT.py:370-375): replicate-pad to a multiple of seq_len*sr/fps, wav2vec2 hidden
+    states of every layer stacked per frame (FLOAT.py:345-352), audio_projection (FLOAT.py:338-342).
+    a (B,N) normalised waveform -> wa (B,seq_len,dim_w)."""
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    need = int(seq_len * sampling_rate / fps)
+    if a.shape[1] % need != 0:
+        a = F.pad(a[:, None], (0, need - a.shape[1]), mode="replicate")[:, 0]
+    f = wav2vec_features(sd, cfg, a, dtype).transpose(1, 2)
+    f = linear_interpolation(f, seq_len)
+    f = _ln_affine(f, sd["wav2vec2.feature_projection.layer_norm.weight"], sd["wav2vec2.feature_projection.layer_norm.bias"],
+                   cfg.layer_norm_eps)
+    h = f @ sd["wav2vec2.feature_projection.projection.weight"].T + sd["wav2vec2.feature_projection.projection.bias"]
+    hs = wav2vec_encoder(sd, cfg, h, dtype)
+    x = hs[-1] if cfg.only_last_features else torch.stack(hs, dim=1).permute(0, 2, 1, 3).reshape(h.shape[0], h.shape[1], -1)
+    y = x @ sd["audio_projection.0.weight"].T + sd["audio_projection.0.bias"]
+    y = _ln_affine(y, sd["audio_projection.1.weight"], sd["audio_projection.1.bias"], 1e-5)
+    return y * torch.sigmoid(y)

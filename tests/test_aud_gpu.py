@@ -1,0 +1,72 @@
+"""GPU parity of the audio conditioning operator (float_aud_*) against goldens made
+from the reference's AudioEncoder (transformers' Wav2Vec2Model underneath) and against the live CPU oracle,
+through the C ABI.  16-bit activations / weights, fp32 accumulation, statistics and residual stream.
+Stated tolerance on wa (rel-L2): fp16 3e-3, bf16 2.5e-2 (measured 9e-4 / 8e-3 on the base config)."""
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import golden, load_pkg, rel_l2
+
+pkg = load_pkg()
+W, C = pkg.weights, pkg.config
+pytestmark = pytest.mark.gpu
+
+TOL = {"fp16": 3e-3, "bf16": 2.5e-2}
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_audio_golden(tag, dtype):
+    g = golden("aud_" + tag)
+    cfg = C.small_audio_config() if tag == "small" else C.AudioConfig()
+    sd = W.synth_audio_state(cfg, seed=g["seed"])
+    enc = pkg.audio.AudioEncoderHIP(sd, cfg, "cuda:0", dtype)
+    wa = enc.inference(W.synth_waveform(g["seconds"], seed=g["seed"] + 1), int(g["T"])).cpu()
+    e = rel_l2(wa, g["wa"])
+    print(tag, dtype, "wa rel-L2 %.3e max|d| %.3e" % (e, float((wa - g["wa"]).abs().max())))
+    assert wa.shape == g["wa"].shape and e < TOL[dtype]
+
+
+def test_audio_live_oracle_lengths_and_determinism():
+    """Ragged lengths: replicate padding (FLOAT.py:371-373), a clip longer than the first (workspace regrowth),
+    only_last_features, batch of two, bitwise run-to-run determinism."""
+    cfg = C.small_audio_config()
+    sd = W.synth_audio_state(cfg, seed=21)
+    enc = pkg.audio.AudioEncoderHIP(sd, cfg, "cuda:0", "fp16")
+    for seconds, T in ((0.5, 13), (3.1, 78), (1.0, 25)):
+        a = W.synth_waveform(seconds, seed=int(seconds * 10))
+        got = enc.inference(a, T)
+        want = O.audio_encoder_inference(sd, cfg, a, T)
+        assert rel_l2(got.cpu(), want) < TOL["fp16"], (seconds, T)
+        assert torch.equal(got, enc.inference(a, T))
+    a2 = torch.cat([W.synth_waveform(1.0, seed=4), W.synth_waveform(1.0, seed=5)])
+    got = enc.inference(a2, 25).cpu()
+    assert rel_l2(got, O.audio_encoder_inference(sd, cfg, a2, 25)) < TOL["fp16"]
+    cfg2 = C.small_audio_config()
+    cfg2.only_last_features = True
+    sd2 = W.synth_audio_state(cfg2, seed=22)
+    enc2 = pkg.audio.AudioEncoderHIP(sd2, cfg2, "cuda:0", "fp16")
+    a = W.synth_waveform(1.0, seed=6)
+    assert rel_l2(enc2.inference(a, 25).cpu(), O.audio_encoder_inference(sd2, cfg2, a, 25)) < TOL["fp16"]
+
+
+def test_audio_weight_norm_key_variants_and_errors():
+    cfg = C.small_audio_config()
+    sd = W.synth_audio_state(cfg, seed=23)
+    a = W.synth_waveform(1.0, seed=7)
+    base = pkg.audio.AudioEncoderHIP(sd, cfg, "cuda:0", "fp16").inference(a, 25)
+    p = "wav2vec2.encoder.pos_conv_embed.conv."
+    legacy = {k: v for k, v in sd.items() if "parametrizations" not in k}
+    legacy[p + "weight_g"] = sd[p + "parametrizations.weight.original0"]
+    legacy[p + "weight_v"] = sd[p + "parametrizations.weight.original1"]
+    assert torch.equal(base, pkg.audio.AudioEncoderHIP(legacy, cfg, "cuda:0", "fp16").inference(a, 25))
+    plain = {k: v for k, v in sd.items() if "parametrizations" not in k}
+    plain[p + "weight"] = O.pos_conv_weight(sd)
+    assert rel_l2(pkg.audio.AudioEncoderHIP(plain, cfg, "cuda:0", "fp16").inference(a, 25).cpu(), base.cpu()) < 1e-3
+    with pytest.raises(KeyError):
+        pkg.audio.AudioEncoderHIP({k: v for k, v in sd.items() if "layers.1.feed_forward" not in k}, cfg, "cuda:0")
+    bad = C.small_audio_config()
+    bad.hidden_size, bad.num_attention_heads = 320, 5  # LayerNorm width not a multiple of 256
+    with pytest.raises(ValueError):
+        pkg.audio.AudioEncoderHIP(sd, bad, "cuda:0")

@@ -131,3 +131,19 @@ def test_encoder(size):
         assert f.shape[-1] == 8 << i
         assert rel_l2(f[:, :, ::st, ::st], g["feat%d" % i]) < TOL_REL
         assert rel_l2(f.mean(dim=(2, 3)), g["feat%d_mean" % i]) < TOL_REL
+
+
+@pytest.mark.parametrize("tag", ["small", "base"])
+def test_audio_encoder(tag):
+    """AudioEncoder.inference (FLOAT.py:370-375) on transformers' wav2vec2 (wav2vec2.py:33-98)."""
+    g = golden("aud_" + tag)
+    cfg = C.small_audio_config() if tag == "small" else C.AudioConfig()
+    sd = W.synth_audio_state(cfg, seed=g["seed"])
+    a = W.synth_waveform(g["seconds"], seed=g["seed"] + 1)
+    wa = O.audio_encoder_inference(sd, cfg, a, int(g["T"]))
+    assert wa.shape == g["wa"].shape and rel_l2(wa, g["wa"]) < TOL_REL
+    # the interpolated feature sequence on its own (wav2vec2.py:100-121 feature_extract)
+    need = int(g["T"]) * 640
+    ap = a if a.shape[1] % need == 0 else torch.nn.functional.pad(a[:, None], (0, need - a.shape[1]), mode="replicate")[:, 0]
+    f = O.linear_interpolation(O.wav2vec_features(sd, cfg, ap).transpose(1, 2), int(g["T"]))
+    assert rel_l2(f[:, :, ::8], g["feat_interp"]) < TOL_REL

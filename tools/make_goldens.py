@@ -315,6 +315,26 @@ def gen_encoder(ns, size, seed, sparse):
     save("enc_%d" % size, **arrs)
 
 
+def gen_audio(ns, tag, cfg, seed, seconds, T):
+    """AudioEncoder.inference of the reference itself (FLOAT.py:304-375 on transformers' Wav2Vec2Model through
+    wav2vec2.py:33-98) with seeded synthetic weights and the SURVEY 8d synthetic waveform."""
+    print("[audio encoder %s]" % tag)
+    sd = weights.synth_audio_state(cfg, seed=seed)
+    opt = ns.base_options.BaseOptions()
+    opt.dim_w, opt.only_last_features = cfg.dim_w, cfg.only_last_features
+    enc = ns.FLOAT.AudioEncoder(opt, cfg.to_hf())
+    r = enc.load_state_dict(sd, strict=True)
+    enc.eval()
+    a = weights.synth_waveform(seconds, seed=seed + 1)
+    with torch.no_grad():
+        wa = enc.inference(a, seq_len=T)
+        feat = enc.wav2vec2.feature_extract(a if a.shape[1] % int(T * 640) == 0 else
+                                            torch.nn.functional.pad(a[:, None], (0, int(T * 640) - a.shape[1]), mode="replicate")[:, 0], T)
+    o = O.audio_encoder_inference(sd, cfg, a, T)
+    print("  oracle-ref max|d| %.3e rel %.3e ; |wa| rms %.3f" % (maxdiff(o, wa) + (float(wa.pow(2).mean().sqrt()),)))
+    save("aud_%s" % tag, seed=seed, seconds=seconds, T=T, wa=wa, feat_interp=feat[:, :, ::8])
+
+
 def gen_node_surface(ns):
     """Widget/return contracts of the three north-star nodes and the batch/seed schedule of
     FloatProcess.floatprocess (nodes.py:189-222), captured from the reference classes themselves."""
@@ -373,6 +393,10 @@ def gen_node_surface(ns):
 
 def main():
     ns = ref_import.load()
+    if os.environ.get("GOLDENS_ONLY") == "aud":
+        gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
+        gen_audio(ns, "base", config.AudioConfig(), seed=1300, seconds=2.0, T=50)
+        return
     if os.environ.get("GOLDENS_ONLY") == "enc":
         gen_encoder(ns, 64, seed=1000, sparse=False)
         gen_encoder(ns, 512, seed=1100, sparse=True)
@@ -395,6 +419,8 @@ def main():
     gen_dec(ns, 512, seed=800, n_frames=2, sparse=True)
     gen_encoder(ns, 64, seed=1000, sparse=False)
     gen_encoder(ns, 512, seed=1100, sparse=True)
+    gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
+    gen_audio(ns, "base", config.AudioConfig(), seed=1300, seconds=2.0, T=50)
 
 
 if __name__ == "__main__":
