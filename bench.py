@@ -185,12 +185,12 @@ def main():
         try:
             # once-per-clip host-side stage (PyTorch-ROCm, not part of `value`): appearance encoder + Direction +
             # wav2vec2-base audio encoder with random weights on synthetic image/audio (SURVEY.md 8d inputs)
-            hm = pkg.host_models
             enc = pkg.encoder.EncoderHIP(pkg.weights.synth_encoder_state(args.size, seed=1), args.size, cfg.dim_w, 20, dev,
                                          args.dec_dtype, direction_weight=dec_sd["direction.weight"])
-            aud = hm.AudioEncoderHost().to(dev)
+            acfg = pkg.config.AudioConfig()
+            aud = pkg.audio.AudioEncoderHIP(pkg.weights.synth_audio_state(acfg, seed=1), acfg, dev, args.dec_dtype)
             img = torch.rand(1, 3, args.size, args.size, device=dev) * 2 - 1
-            wav = torch.randn(1, int(args.seconds * 16000), device=dev)
+            wav = pkg.weights.synth_waveform(args.seconds, seed=1).to(dev)
 
             def timed(fn):
                 fn()
@@ -204,11 +204,10 @@ def main():
                 enc.encode_image_into_latent(img, want_feats=False)
                 enc.hand_feats_to(hp.dec)
 
-            def aud_stage():
-                with torch.no_grad():
-                    aud.inference(wav, seq_len=T)
+            def aud_stage():  # waveform -> wa (T, 512): wav2vec2-base + audio projection (HIP operator float_aud_*)
+                aud.inference(wav, seq_len=T)
             extra["stage_ms"]["appearance_encoder_hip"] = timed(enc_stage)
-            extra["stage_ms"]["audio_encoder_host_pytorch"] = timed(aud_stage)
+            extra["stage_ms"]["audio_encoder_hip"] = timed(aud_stage)
             hp.dec.set_feats(feats)  # restore the bench's synthetic features
             del aud, enc
         except Exception as e:  # conditioning is plumbing; never fail the bench for it

@@ -1,15 +1,11 @@
 """Host-side (PyTorch on ROCm or CPU) producers of the hot path's inputs.  These run ONCE per
 clip and are plumbing, not part of the HIP hot path ("OUT OF SCOPE for HIP").
-The appearance encoder and Direction are NOT here any more: they are the HIP operator `float_enc_*`
-(encoder.py in this package).
+The appearance encoder + Direction and the audio encoder (wav2vec2-base + projection) are NOT here any more:
+they are the HIP operators `float_enc_*` / `float_aud_*` (encoder.py / audio.py in this package, SURVEY.md
+section 8f rows 1-2).  What is left:
 
-  * audio encoder       wav2vec2-base hidden states, interpolated to T frames *before* the
-                        transformer, 12x768 -> 512 projection + LayerNorm + SiLU (FLOAT.py:304-375,
-                        wav2vec2.py:33-98,184-197)
   * image / audio pre-processing of the simple node (generate.py:29-39, 69-73)
-
-Sub-module names are the reference's checkpoint keys so the split checkpoint layout
-(audio_projections/projection.safetensors, audio/wav2vec2-base-960h) loads unchanged.
+  * the speech-emotion classifier used only by emotion="none" (wav2vec2-large-xlsr, FLOAT.py:378-401)
 """
 import math
 
@@ -42,39 +38,6 @@ def preprocess_audio(waveform, sample_rate, target_rate=16000):
         n = int(round(w.shape[-1] * target_rate / sample_rate))
         w = F.interpolate(w[None, None], size=n, mode="linear", align_corners=False)[0, 0]
     return ((w - w.mean()) / torch.sqrt(w.var(unbiased=False) + 1e-7))[None]
-
-
-class AudioEncoderHost(torch.nn.Module):
-    """wav2vec2 with the feature sequence interpolated to T frames before the transformer
-    (wav2vec2.py:66-68) + the 12x768 -> 512 projection head (FLOAT.py:338-342, 345-352)."""
-
-    def __init__(self, config=None, dim_w=512, only_last_features=False):
-        super().__init__()
-        from transformers import Wav2Vec2Config, Wav2Vec2Model
-        self.config = config or Wav2Vec2Config()
-        self.wav2vec2 = Wav2Vec2Model(self.config)
-        self.only_last = only_last_features
-        d_in = self.config.hidden_size * (1 if only_last_features else self.config.num_hidden_layers)
-        self.audio_projection = torch.nn.Sequential(torch.nn.Linear(d_in, dim_w), torch.nn.LayerNorm(dim_w), torch.nn.SiLU())
-        self.eval()
-
-    @torch.no_grad()
-    def inference(self, a, seq_len, sampling_rate=16000, fps=25.0):
-        """a (B,N) normalised waveform -> wa (B,seq_len,512) (FLOAT.py:370-375)."""
-        need = int(seq_len * sampling_rate / fps)
-        if a.shape[1] % need != 0:
-            a = F.pad(a[:, None], (0, need - a.shape[1]), mode="replicate")[:, 0]
-        m = self.wav2vec2
-        f = m.feature_extractor(a).transpose(1, 2)
-        f = F.interpolate(f.transpose(1, 2), size=seq_len, align_corners=True, mode="linear").transpose(1, 2)
-        h, _ = m.feature_projection(f)
-        out = m.encoder(h, output_hidden_states=not self.only_last, return_dict=True)
-        if self.only_last:
-            x = out.last_hidden_state
-        else:
-            x = torch.stack(out.hidden_states[1:], dim=1).permute(0, 2, 1, 3)
-            x = x.reshape(x.shape[0], x.shape[1], -1)
-        return self.audio_projection(x)
 
 
 class EmotionHost(torch.nn.Module):

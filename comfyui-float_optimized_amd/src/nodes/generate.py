@@ -6,7 +6,8 @@ import os
 import torch
 
 from ... import host_models, weights
-from ...config import FmtConfig
+from ...audio import AudioEncoderHIP
+from ...config import AudioConfig, FmtConfig, small_audio_config
 from ...encoder import EncoderHIP
 from ...fmt import draw_noise
 from ...pipeline import FloatHotPath
@@ -53,7 +54,10 @@ class InferenceAgent:
         # decoder so the skip features go to it without an fp32 round trip
         self.enc = EncoderHIP(parts["enc"], opt.input_size, opt.dim_w, getattr(opt, "dim_m", 20), self.rank,
                               dtype=self.G.dec.dtype, direction_weight=parts["dec"]["direction.weight"])
-        self.audio_encoder = parts["audio_encoder"].to(self.rank)
+        # wav2vec2 + audio projection as one HIP operator (float_aud_*)
+        aud_sd, aud_cfg = parts["audio_encoder"]
+        self.audio_encoder = AudioEncoderHIP(aud_sd, aud_cfg, self.rank, dtype=os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16"),
+                                             sampling_rate=opt.sampling_rate, fps=opt.fps)
         ser = parts.get("emotion_encoder")
         self.emotion_encoder = ser.to(self.rank) if ser is not None else None
         # callable(a) -> (1,7) softmax scores; None disables emotion="none" (speech-to-emotion)
@@ -69,12 +73,9 @@ class InferenceAgent:
             raise FileNotFoundError("Checkpoint file not found: %s" % path)
         from safetensors.torch import load_file
         parts = split_unified(load_file(path, device="cpu"))
-        enc = host_models.AudioEncoderHost(dim_w=opt.dim_w, only_last_features=opt.only_last_features)
-        missing = enc.wav2vec2.load_state_dict(parts["wav2vec"], strict=False)
-        if missing.missing_keys:
-            main_logger.warning("wav2vec2 keys missing from checkpoint: %s", missing.missing_keys[:5])
-        enc.audio_projection.load_state_dict(parts["proj"], strict=True)
-        parts["audio_encoder"] = enc
+        aud_sd = {"wav2vec2." + k: v for k, v in parts["wav2vec"].items()}
+        aud_sd.update({"audio_projection." + k: v for k, v in parts["proj"].items()})
+        parts["audio_encoder"] = (aud_sd, AudioConfig(dim_w=opt.dim_w, only_last_features=opt.only_last_features))
         if parts["ser"]:
             ser = host_models.EmotionHost()
             miss = ser.load_state_dict(parts["ser"], strict=False)
@@ -92,33 +93,35 @@ class InferenceAgent:
         small = Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
                                conv_dim=(32, 32, 32, 32, 32, 32, 32), num_conv_pos_embeddings=16,
                                num_conv_pos_embedding_groups=4)
+        acfg = small_audio_config()
+        acfg.dim_w = opt.dim_w
         return dict(enc=weights.synth_encoder_state(opt.input_size, seed=seed), dec=weights.synth_decoder_state(opt.input_size, seed=seed),
                     fmt=weights.synth_fmt_state(cfg, seed=seed),
-                    audio_encoder=host_models.AudioEncoderHost(small, dim_w=opt.dim_w),
+                    audio_encoder=(weights.synth_audio_state(acfg, seed=seed), acfg),
                     emotion_encoder=host_models.EmotionHost(small))
 
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
     def conditions(self, ref_img, ref_audio, emo=None):
-        """Once-per-clip stage: image -> (s_r, feats, r_s) on the HIP encoder; audio -> (wa, T) and
-        emotion -> we on the host-side PyTorch encoders."""
+        """Once-per-clip stage: image -> (s_r, feats, r_s) and audio -> (wa, T) on the HIP operators; the
+        speech-emotion classifier (only for emotion='none') is the one host-side PyTorch model left."""
         o = self.opt
         s = host_models.preprocess_image(ref_img[0] if ref_img.dim() == 4 else ref_img, o.input_size).to(self.rank)
         a = host_models.preprocess_audio(ref_audio["waveform"][0], ref_audio["sample_rate"], o.sampling_rate).to(self.rank)
-        # the once-per-clip PyTorch encoders run with deterministic MIOpen/rocBLAS algorithms so that a seed
-        # reproduces a clip bit for bit (the HIP operators are deterministic by construction)
         s_r, _, _, r_s = self.enc.encode_image_into_latent(s, want_feats=False)  # FLOAT.py:283-291
         self.enc.hand_feats_to(self.G.dec)
         feats = None  # already in the decoder (NHWC 16-bit)
-        with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):
-            T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
-            wa = self.audio_encoder.inference(a, seq_len=T, sampling_rate=o.sampling_rate, fps=o.fps)
+        T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
+        wa = self.audio_encoder.inference(a, seq_len=T)
         if emo is None or str(emo).lower() == "none":
             if self.emotion_predictor is None:
                 raise NotImplementedError(
                     "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198) but the checkpoint has "
                     "no `emotion_encoder.wav2vec2_for_emotion.` weights - pick an emotion or attach agent.emotion_predictor")
-            we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
+            # deterministic MIOpen/rocBLAS algorithms so that a seed reproduces a clip bit for bit (the HIP operators
+            # are deterministic by construction)
+            with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):
+                we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
         else:
             we = host_models.emotion_one_hot(emo, self.rank)
         return dict(s_r=s_r, feats=feats, r_s=r_s, wa=wa, we=we, T=T)
