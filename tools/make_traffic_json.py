@@ -15,7 +15,7 @@ def per_class(d):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            cls = "fmt_gemm" if n.startswith("void fmt_gemm") else ("dec_conv" if n.startswith("void dec_conv") else None)
+            cls = "fmt_gemm" if n.startswith("void fmt_gemm") else ("dec_conv" if n.startswith(("void dec_conv", "void dec_zconv")) else None)
             if cls:
                 out[cls][0] += float(r["Counter_Value"])
                 out[cls][1] += 1

@@ -1,0 +1,12 @@
+set -x
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+O=gpurun_out/s2_final; mkdir -p $O
+python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json | cut -c1-300
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --no-cpu-baseline --no-roofline > $O/stats.log 2>&1
+find $O/stats -name "*kernel_trace.csv" -delete
+for w in fmt dec; do for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_$w -o p -- python3 tools/profile_hotpath.py --what $w > $O/pmc_${c}_$w.log 2>&1
+  find $O/pmc_${c}_$w -name "*kernel_trace.csv" -delete
+done; done
+python tools/make_traffic_json.py $O/pmc_FETCH_SIZE_fmt,$O/pmc_FETCH_SIZE_dec $O/pmc_WRITE_SIZE_fmt,$O/pmc_WRITE_SIZE_dec $O/pmc_traffic.json
+du -sh $O
