@@ -103,10 +103,11 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
 }
 
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
-template <class T, int MTW>
+int g_fmt_wide_variant = 2;  // FLOAT_FMT_WIDE_VARIANT: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2 (measured best: all 180 rows in one workgroup, weights read once), 3 = 192 x 4
+template <class T, int MTW, int KCH>
 int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
-  constexpr int smem = 2 * MTW * 4 * 1024;
-  auto kern = fmt_gemm_wide_kernel<T, MTW>;
+  constexpr int smem = 2 * MTW * KCH * 1024;
+  auto kern = fmt_gemm_wide_kernel<T, MTW, KCH>;
   if (prime) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       (void)hipGetLastError();
@@ -124,14 +125,24 @@ template <class T>
 int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
   const int mt = (g.M + 15) / 16;
   if (prime) {
-    (void)launch_wide_t<T, 4>(g, true, s);
-    (void)launch_wide_t<T, 5>(g, true, s);
-    (void)launch_wide_t<T, 6>(g, true, s);
+    (void)launch_wide_t<T, 4, 4>(g, true, s);
+    (void)launch_wide_t<T, 5, 4>(g, true, s);
+    (void)launch_wide_t<T, 6, 4>(g, true, s);
+    (void)launch_wide_t<T, 6, 2>(g, true, s);
+    (void)launch_wide_t<T, 12, 2>(g, true, s);
+    (void)launch_wide_t<T, 12, 4>(g, true, s);
     return FLOAT_OK;
   }
-  if (mt <= 4) return launch_wide_t<T, 4>(g, false, s);
-  if (mt <= 12) return launch_wide_t<T, 6>(g, false, s);
-  return launch_wide_t<T, 5>(g, false, s);
+  if (mt <= 4) return launch_wide_t<T, 4, 4>(g, false, s);
+  if (mt <= 12) {
+    switch (g_fmt_wide_variant) {
+      case 1: return launch_wide_t<T, 6, 2>(g, false, s);
+      case 2: return launch_wide_t<T, 12, 2>(g, false, s);
+      case 3: return launch_wide_t<T, 12, 4>(g, false, s);
+      default: return launch_wide_t<T, 6, 4>(g, false, s);
+    }
+  }
+  return launch_wide_t<T, 5, 4>(g, false, s);
 }
 bool g_fmt_wide = true;  // FLOAT_FMT_WIDE=0 falls back to the generic tiling (A/B measurement)
 
@@ -167,7 +178,7 @@ int launch_gemm_t(GemmArgs g, bool prime, hipStream_t s) {
   X(3, 1, NW, EPI) X(3, 2, NW, EPI) X(3, 4, NW, EPI) X(5, 1, NW, EPI) X(5, 2, NW, EPI) X(5, 4, NW, EPI) X(4, 1, NW, EPI) \
   X(4, 2, NW, EPI) X(6, 2, NW, EPI) X(2, 1, NW, EPI) X(1, 1, NW, EPI)
 #define FMT_FOR_SPLIT(X, EPI) FMT_SPLIT_SHAPES(X, 4, EPI) FMT_SPLIT_SHAPES(X, 8, EPI) FMT_SPLIT_SHAPES(X, 16, EPI)
-#define FMT_FOR_FULL(X, EPI) X(12, 2, 4, EPI) X(15, 2, 4, EPI) X(12, 1, 4, EPI) X(15, 1, 4, EPI)
+#define FMT_FOR_FULL(X, EPI) X(12, 2, 4, EPI) X(15, 2, 4, EPI) X(12, 1, 4, EPI) X(15, 1, 4, EPI) X(12, 1, 8, EPI) X(15, 1, 8, EPI)
 
 template <class T, int EPI>
 int launch_gemm(const GemmArgs& g, int mtw, int nt, int nw, bool prime, hipStream_t s) {
@@ -198,6 +209,8 @@ void prime_epi() {
       (void)launch_gemm<T, EPI>(g, 12, nt, 4, true, nullptr);
       (void)launch_gemm<T, EPI>(g, 15, nt, 4, true, nullptr);
     }
+    (void)launch_gemm<T, EPI>(g, 12, 1, 8, true, nullptr);
+    (void)launch_gemm<T, EPI>(g, 15, 1, 8, true, nullptr);
   }
 }
 template <class T>
@@ -221,6 +234,7 @@ void prime_kernels() {
 struct Tiling {
   int mtw, nt, nw;
 };
+int g_fmt_full_nw = 8;  // FLOAT_FMT_FULL_NW: waves of the full-height (CFG epilogue) tiling
 int g_fmt_plan_override[6] = {0, 0, 0, 0, 0, 0};  // FLOAT_FMT_PLAN="mtw,nt,nw (narrow), mtw,nt,nw (wide)": tuning aid
 int pick_nw(int K, int forced) {
   const int KB = K / 32;
@@ -233,7 +247,9 @@ Tiling pick_tiling(int M, int N, int K, bool need_full_rows) {
   const int mt = (M + 15) / 16;
   if (need_full_rows) {
     if (mt <= 4) return {4, 1, pick_nw(K, 0)};
-    return {mt <= 12 ? 12 : 15, 1, 4};  // 16 columns per workgroup: twice the workgroups of the 32-column tile
+    // 16 columns per workgroup: twice the workgroups of the 32-column tile; 8 K-splitting waves keep twice
+    // the operand bytes in flight (each of the 32 workgroups streams the whole 393 KB activation operand)
+    return {mt <= 12 ? 12 : 15, 1, (g_fmt_full_nw == 8 && (K / 32) % 8 == 0) ? 8 : 4};
   }
   int split = mt <= 4 ? 4 : (mt <= 12 ? 3 : 5);
   if (mt <= 2) split = mt;
@@ -853,6 +869,8 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   h->Kx = round_up(cfg->dim_w, 128);
   if (const char* wd = getenv("FLOAT_FMT_WIDE")) g_fmt_wide = atoi(wd) != 0;
   if (const char* v = getenv("FLOAT_FMT_FC2_SPLIT")) g_fmt_fc2_split = atoi(v);
+  if (const char* v = getenv("FLOAT_FMT_FULL_NW")) g_fmt_full_nw = atoi(v);
+  if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
     sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],

@@ -40,8 +40,17 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
       by = id / nbx;
     }
     if constexpr (EPI == EPI_PARTIAL) {
-      ks = bx / nbn;
-      bx = bx % nbn;
+      if ((nbx & 7) == 0 && (8 % g.ksplit) == 0) {
+        // K slice <-> XCD affinity: the 8/ksplit XCDs that own slice ks fetch only that slice of the
+        // activations (r01 PMC: with slices spread over all XCDs fc2 fetched its 1.5 MB operand 8 times,
+        // 12.6 MB against 8.4 MB of weights)
+        const int P = 8 / g.ksplit, x = bx & 7;
+        ks = x / P;
+        bx = (bx >> 3) * P + (x % P);
+      } else {
+        ks = bx / nbn;
+        bx = bx % nbn;
+      }
     }
   }
   const int nb0 = bx * NT;
@@ -242,9 +251,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
 //     straight to registers, non-temporal;
 //   * operands are swapped (D = W_tile * A_tile^T) so a lane holds 4 consecutive columns of one row and
 //     the fp32 result is stored as float4.
-template <class T, int MTW>
+template <class T, int MTW, int KCH /* k-blocks (of 32) per LDS chunk */>
 __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
-  constexpr int KCH = 4;                   // k-blocks (of 32) per LDS chunk
   constexpr int NF = MTW * KCH;            // 1-KiB A fragments per chunk
   constexpr int NFW = (NF + 3) / 4;        // fragments staged by one wave
   extern __shared__ __attribute__((aligned(16))) unsigned char sA[];  // [2][MTW][KCH][1 KiB]
