@@ -172,6 +172,11 @@ struct DevicePool {
   }
 };
 
+// Direction (styledecoder.py:428-444) helpers shared by the encoder and the decoder operators (enc_api.hip):
+// Q of the Householder QR of (W + 1e-8) with LAPACK sign conventions, and y = alpha * W x + b in fp32.
+void fh_direction_q(const float* w, int dim, int dim_motion, std::vector<float>* Q);
+int fh_linear_f32(const float* x, const float* W, const float* b, float alpha, float* y, int N, int K, hipStream_t s);
+
 // Kernel-class profiling (float_profile_ms): events recorded on the caller's stream.
 struct ProfileSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;

@@ -44,6 +44,8 @@ struct float_dec {
   float* bm = nullptr;    // [Stot]
   float* cin_hwc = nullptr;  // ConstantInput as [4][4][512]
   bool feats_set = false;
+  float* dirQ = nullptr;  // [style_dim][motion_dim] of QR(direction.weight + 1e-8) (styledecoder.py:435-436), if present
+  int motion_dim = 0;
   // workspace.  Frames go through the decoder in three nested batches:
   //   style batch (<= kStyleCap frames): every style modulation + demod factor in two launches;
   //   low batch   (<= lo_frames): levels up to 32x32, where one frame is only 16..1024 pixels and
@@ -599,12 +601,29 @@ int float_dec_create(const float_dec_cfg_t* cfg, const float_tensor_t* tensors, 
   h->cfg = *cfg;
   TensorTable tt(tensors, n_tensors);
   int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);
+  if (!rc) {
+    if (const float_tensor_t* dw = tt.find("direction.weight")) {
+      if (dw->ndim == 2 && dw->shape[0] == cfg->style_dim) {
+        std::vector<float> Q;
+        h->motion_dim = (int)dw->shape[1];
+        fh_direction_q(dw->data, cfg->style_dim, h->motion_dim, &Q);
+        rc = h->pool.alloc(&h->dirQ, Q.size(), false);
+        if (!rc && hipMemcpy(h->dirQ, Q.data(), Q.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = FLOAT_E_HIP;
+      }
+    }
+  }
   if (rc) {
     float_dec_destroy(h);
     return rc;
   }
   *out = h;
   return FLOAT_OK;
+}
+
+int float_dec_direction(float_dec_t* h, const float* lam, float* r_s, void* stream) {
+  FH_REQUIRE(h && lam && r_s, "null argument to float_dec_direction");
+  FH_REQUIRE(h->dirQ != nullptr, "the decoder checkpoint has no (style_dim, motion_dim) 'direction.weight'");
+  return fh_linear_f32(lam, h->dirQ, nullptr, 1.0f, r_s, h->cfg.style_dim, h->motion_dim, (hipStream_t)stream);
 }
 
 void float_dec_destroy(float_dec_t* h) {

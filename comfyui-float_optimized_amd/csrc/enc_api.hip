@@ -187,10 +187,8 @@ int create_impl(float_enc* h, const TensorTable& tt) {
   if (const float_tensor_t* dw = tt.find("direction.weight")) {  // Direction (styledecoder.py:431-436)
     FH_REQUIRE(dw->ndim == 2 && dw->shape[0] == c.dim && dw->shape[1] == c.dim_motion, "direction.weight must be (%d,%d)", c.dim,
                c.dim_motion);
-    std::vector<double> A((size_t)c.dim * c.dim_motion), Qd;
-    for (size_t k = 0; k < A.size(); ++k) A[k] = (double)(dw->data[k] + 1e-8f);  // weight + 1e-8 in fp32, as the reference adds it
-    householder_q(A, c.dim, c.dim_motion, &Qd);
-    std::vector<float> Qf(Qd.begin(), Qd.end());
+    std::vector<float> Qf;
+    fh_direction_q(dw->data, c.dim, c.dim_motion, &Qf);
     if ((rc = h->pool.alloc(&h->Q, Qf.size(), false))) return rc;
     FH_CHECK_HIP(hipMemcpy(h->Q, Qf.data(), Qf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
@@ -294,6 +292,19 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
 }
 
 }  // namespace
+
+void fh_direction_q(const float* w, int dim, int dim_motion, std::vector<float>* Q) {
+  std::vector<double> A((size_t)dim * dim_motion), Qd;
+  for (size_t k = 0; k < A.size(); ++k) A[k] = (double)(w[k] + 1e-8f);  // weight + 1e-8 in fp32, as the reference adds it
+  householder_q(A, dim, dim_motion, &Qd);
+  Q->assign(Qd.begin(), Qd.end());
+}
+
+int fh_linear_f32(const float* x, const float* W, const float* b, float alpha, float* y, int N, int K, hipStream_t s) {
+  hipLaunchKernelGGL(enc_linear_kernel, dim3((N + 3) / 4), dim3(256), 0, s, x, W, b, alpha, y, N, K);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
 
 extern "C" {
 

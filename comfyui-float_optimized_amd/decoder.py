@@ -59,6 +59,19 @@ class SynthesisHIP:
         return self._run(native.lib().float_dec_frames, s_r, r_d, (self.size, self.size, 3))
 
     @torch.no_grad()
+    def direction(self, lam):
+        """Direction.forward (styledecoder.py:428-444): (B, motion_dim) -> (B, style_dim) = lam @ Q^T."""
+        lam = lam.to(self.device, torch.float32).contiguous()
+        if lam.dim() != 2:
+            raise ValueError("direction input must be (B, motion_dim), got %s" % (tuple(lam.shape),))
+        out = torch.empty(lam.shape[0], self.style_dim, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            for b in range(lam.shape[0]):
+                native.check(native.lib().float_dec_direction(self._h, native.dev_ptr(lam[b]), native.dev_ptr(out[b]),
+                                                              native.stream_ptr(self.device)))
+        return out
+
+    @torch.no_grad()
     def synthesis_raw(self, s_r, r_d):
         """Un-clamped Synthesis.forward output (T, 3, H, W) (styledecoder.py:532-534)."""
         return self._run(native.lib().float_dec_frames_raw, s_r, r_d, (3, self.size, self.size))

@@ -1,6 +1,7 @@
-"""Node surface of ComfyUI-FLOAT_Optimized on the MI355X hot path (reference src/nodes/__init__.py).
-Only the three north-star nodes are registered: Load FLOAT Models (Opt), FLOAT Process (Opt) and
-FLOAT Advanced Options."""
+"""Node surface of ComfyUI-FLOAT_Optimized on the MI355X hot path (reference src/nodes/__init__.py): the three
+north-star nodes - Load FLOAT Models (Opt), FLOAT Process (Opt), FLOAT Advanced Options - and the very-advanced (VA)
+loaders / stage nodes that expose the operators of the path one by one (display names carry the module's "(VA)"
+suffix like the reference's register_nodes does)."""
 import logging
 
 __version__ = "0.1.0"
@@ -16,6 +17,13 @@ main_logger = logging.getLogger(NODES_NAME)
 from .nodes import LoadFloatModels, FloatProcess  # noqa: E402
 from .nodes_adv import FloatAdvancedParameters  # noqa: E402
 
+from . import nodes_vadv, nodes_vadv_loader  # noqa: E402
+
 _NODES = (LoadFloatModels, FloatProcess, FloatAdvancedParameters)
-NODE_CLASS_MAPPINGS = {c.UNIQUE_NAME: c for c in _NODES}
+_VA_NODES = (nodes_vadv_loader.LoadFloatEncoderModel, nodes_vadv_loader.LoadFloatSynthesisModel, nodes_vadv_loader.LoadFMTModel,
+             nodes_vadv_loader.LoadWav2VecModel, nodes_vadv_loader.LoadAudioProjectionLayer, nodes_vadv.ApplyFloatEncoder,
+             nodes_vadv.FloatGetIdentityReferenceVA, nodes_vadv.FloatSampleMotionSequenceRD_VA, nodes_vadv.ApplyFloatSynthesis,
+             nodes_vadv.FloatAudioPreprocessAndFeatureExtract, nodes_vadv.FloatApplyAudioProjection)
+NODE_CLASS_MAPPINGS = {c.UNIQUE_NAME: c for c in _NODES + _VA_NODES}
 NODE_DISPLAY_NAME_MAPPINGS = {c.UNIQUE_NAME: c.DISPLAY_NAME for c in _NODES}
+NODE_DISPLAY_NAME_MAPPINGS.update({c.UNIQUE_NAME: c.DISPLAY_NAME + " " + nodes_vadv.SUFFIX for c in _VA_NODES})

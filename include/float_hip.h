@@ -142,6 +142,10 @@ int float_dec_frames(float_dec_t* h, const float* s_r, const float* r_d, int32_t
 int float_dec_frames_raw(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames,
                          float* out_chw, void* stream);
 
+/* Direction.forward (styledecoder.py:428-444; FLOAT.py:289-291, nodes_vadv.py:479-533): r_s = lam @ Q^T with
+ * Q from the QR of (direction.weight + 1e-8), factorised once at create time.  lam: (motion_dim), r_s: (style_dim). */
+int float_dec_direction(float_dec_t* h, const float* lam, float* r_s, void* stream);
+
 /* Same hand-over without the fp32 round trip: feats16[i] = (R_i, R_i, C_i) NHWC 16-bit device buffers
  * of element type `dtype` (must equal the decoder's), e.g. the ones float_enc_feats16 returns. */
 int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_feats, int32_t dtype,

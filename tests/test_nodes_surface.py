@@ -104,3 +104,57 @@ def test_unified_checkpoint_split():
 def importlib_generate():
     import importlib
     return importlib.import_module(pkg.__name__ + ".src.nodes.generate")
+
+
+VA = json.load(open(os.path.join(GOLDEN, "node_surface_va.json")))
+VA_BUILT = ("LoadFloatEncoderModel", "LoadFloatSynthesisModel", "LoadFMTModel", "LoadWav2VecModel", "LoadAudioProjectionLayer",
+            "ApplyFloatEncoder", "FloatGetIdentityReferenceVA", "FloatSampleMotionSequenceRD_VA", "ApplyFloatSynthesis",
+            "FloatAudioPreprocessAndFeatureExtract", "FloatApplyAudioProjection")
+
+
+def test_va_node_contracts():
+    """Very-advanced loaders / stage nodes: same widgets (name, order, type, default, range), return tuples and names as
+    the reference classes (nodes_vadv_loader.py, nodes_vadv.py); file / device lists depend on the host."""
+    for name in VA_BUILT:
+        cls, ref = nodes[name], VA[name]
+        for attr in ("RETURN_TYPES", "RETURN_NAMES"):
+            assert list(getattr(cls, attr)) == ref[attr], (name, attr)
+        for attr in ("FUNCTION", "CATEGORY", "UNIQUE_NAME", "DISPLAY_NAME"):
+            assert getattr(cls, attr) == ref[attr], (name, attr)
+        it, rit = _norm(cls.INPUT_TYPES()), ref["INPUT_TYPES"]
+        assert list(it["required"].keys()) == list(rit["required"].keys()), name
+        assert it.get("optional", {}) == rit.get("optional", {}), name
+        for k, v in rit["required"].items():
+            if k == "target_device" or k.endswith("_file") or k == "model_folder":
+                assert isinstance(it["required"][k][0], list) and it["required"][k][0], (name, k)
+                if k != "target_device":
+                    assert it["required"][k][0] == v[0], (name, k)  # default file name when the folder is empty
+            else:
+                assert it["required"][k] == v, (name, k)
+        assert pkg.NODE_DISPLAY_NAME_MAPPINGS[name] == ref["DISPLAY_NAME"] + " " + ref["SUFFIX"]
+    # the emotion-recognition nodes of the reference are not part of this build
+    assert set(VA) - set(VA_BUILT) == {"LoadEmotionRecognitionModel", "FloatExtractEmotionWithCustomModel",
+                                       "FloatExtractEmotionWithCustomModelDyn"}
+
+
+def test_va_part_extraction(tmp_path, monkeypatch):
+    """utils/downloader.py:35-42 layout: a part that is missing on disk is cut out of the unified FLOAT.safetensors with
+    its prefix stripped; with neither file the loader raises FileNotFoundError."""
+    import importlib
+    from safetensors.torch import load_file, save_file
+    L = importlib.import_module(pkg.__name__ + ".src.nodes.nodes_vadv_loader")
+    monkeypatch.setenv("FLOAT_MODELS_DIR", str(tmp_path))
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        L.ensure_model_part_exists("fmt", L.FMT_SUBDIR, "fmt.safetensors")
+    os.makedirs(tmp_path / "float")
+    uni = {"fmt.x_embedder.proj.weight": torch.ones(4, 2), "motion_autoencoder.enc.fc.0.bias": torch.zeros(3),
+           "audio_encoder.audio_projection.0.weight": torch.full((2, 2), 2.0)}
+    save_file(uni, str(tmp_path / "float" / "FLOAT.safetensors"))
+    p = L.ensure_model_part_exists("fmt", L.FMT_SUBDIR, "fmt.safetensors")
+    assert p == str(tmp_path / "float" / "fmt" / "fmt.safetensors") and list(load_file(p)) == ["x_embedder.proj.weight"]
+    p = L.ensure_model_part_exists("projection", L.AUDIO_PROJ_DIR, "projection.safetensors")
+    assert list(load_file(p)) == ["0.weight"]
+    assert L.safe_parse_list_str("[1, 3, 3, 1]") == [1, 3, 3, 1]
+    with pytest.raises(ValueError):
+        L.safe_parse_list_str("__import__('os')")

@@ -1,0 +1,105 @@
+"""The very-advanced node graph end to end on the GPU: split checkpoint files -> VA loaders (architecture inferred from the
+tensors) -> Apply FLOAT Encoder -> Get Identity Reference -> audio nodes -> Sample Motion Sequence RD -> Apply FLOAT Synthesis,
+checked against the same operators driven directly and against the CPU oracle."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import load_pkg, rel_l2
+
+pkg = load_pkg()
+W, C = pkg.weights, pkg.config
+pytestmark = pytest.mark.gpu
+SIZE = 64
+
+
+@pytest.fixture(scope="module")
+def models(tmp_path_factory):
+    from safetensors.torch import save_file
+    root = tmp_path_factory.mktemp("models")
+    os.environ["FLOAT_MODELS_DIR"] = str(root)
+    fcfg, acfg = C.FmtConfig(), C.small_audio_config()
+    acfg.dim_w = 512
+    sds = dict(enc=W.synth_encoder_state(SIZE, seed=31), dec=W.synth_decoder_state(SIZE, seed=31), fmt=W.synth_fmt_state(fcfg, seed=31),
+               aud=W.synth_audio_state(acfg, seed=31))
+    cont = lambda d: {k: v.contiguous() for k, v in d.items()}  # noqa: E731
+    os.makedirs(root / "float" / "motion_autoencoder")
+    save_file(cont(sds["enc"]), str(root / "float" / "motion_autoencoder" / "encoder.safetensors"))
+    # decoder and fmt only exist inside the unified file: the loaders must extract them
+    uni = {"motion_autoencoder.dec." + k: v for k, v in sds["dec"].items()}
+    uni.update({"fmt." + k: v for k, v in sds["fmt"].items()})
+    save_file(cont(uni), str(root / "float" / "FLOAT.safetensors"))
+    wdir = root / "audio" / "wav2vec2-base-960h"
+    os.makedirs(wdir)
+    save_file(cont({k: v for k, v in sds["aud"].items() if k.startswith("wav2vec2.")}), str(wdir / "model.safetensors"))
+    acfg.to_hf().save_pretrained(str(wdir))
+    os.makedirs(root / "float" / "audio_projections")
+    save_file(cont({k[len("audio_projection."):]: v for k, v in sds["aud"].items() if k.startswith("audio_projection.")}),
+              str(root / "float" / "audio_projections" / "projection.safetensors"))
+    return dict(root=root, sds=sds, fcfg=fcfg, acfg=acfg)
+
+
+def test_va_graph(models):
+    n = pkg.NODE_CLASS_MAPPINGS
+    dev = "cuda:0"
+    size, dim_w, dim_m, enc = n["LoadFloatEncoderModel"]().load_encoder_infer_arch("encoder.safetensors", dev, False)
+    dec, dsize, style_dim, motion_dim = n["LoadFloatSynthesisModel"]().load_synthesis_infer_arch("decoder.safetensors", dev, 1, "[1, 3, 3, 1]", False)
+    fmt, fps, fopts, chunk = n["LoadFMTModel"]().load_fmt_model("fmt.safetensors", dev, False, 7, 8, 2, 10, 25.0, 2.0)
+    assert (size, dim_w, dim_m) == (SIZE, 512, 20) and (dsize, style_dim, motion_dim) == (SIZE, 512, 20)
+    assert fps == 25.0 and chunk == 60 and fopts["dim_h"] == 1024 and fopts["fmt_depth"] == 8 and fopts["dim_a"] == 512
+    assert abs(fopts["mlp_ratio"] - 4.0) < 1e-9 and os.path.exists(models["root"] / "float" / "fmt" / "fmt.safetensors")
+    sr, pipe = n["LoadWav2VecModel"]().load_float_wav2vec_model("wav2vec2-base-960h", dev)
+    proj, din, dim_a = n["LoadAudioProjectionLayer"]().load_projection_layer("projection.safetensors", dev)
+    assert sr == 16000 and (din, dim_a) == (512, 512)  # 2 layers x 256
+
+    img = torch.from_numpy(np.random.RandomState(5).rand(2, SIZE, SIZE, 3).astype(np.float32))
+    pipe_app, lam, _ = n["ApplyFloatEncoder"]().apply_encoder(img, enc)
+    assert pipe_app["h_source"].shape == (2, 512) and lam.shape == (2, 20) and len(pipe_app["feats"]) == 4
+    o_s, o_f, o_l = O.encode_appearance(models["sds"]["enc"], img.permute(0, 3, 1, 2) * 2 - 1)
+    assert rel_l2(pipe_app["h_source"], o_s) < 2e-3 and rel_l2(lam, o_l) < 2e-3
+    _, r_s = n["FloatGetIdentityReferenceVA"]().get_identity_reference_batch(lam, dec)
+    assert rel_l2(r_s, O.direction(models["sds"]["dec"], lam)) < 1e-5
+
+    wav = torch.cat([W.synth_waveform(1.0, seed=8), W.synth_waveform(1.0, seed=9)])[:, None]
+    feats, T, a_norm, _, _, fps2 = n["FloatAudioPreprocessAndFeatureExtract"]().extract_features_with_custom_model(
+        {"waveform": wav, "sample_rate": 16000}, pipe, 25.0, False)
+    assert T == 25 and feats.shape == (2, 25, 512) and fps2 == 25.0
+    (wa,) = n["FloatApplyAudioProjection"]().apply_projection(feats, proj)
+    assert rel_l2(wa, O.audio_encoder_inference(models["sds"]["aud"], models["acfg"], a_norm, 25)) < 3e-3
+
+    we = torch.softmax(torch.randn(2, 1, 7, generator=torch.Generator().manual_seed(1)), -1)
+    S = n["FloatSampleMotionSequenceRD_VA"]()
+    args = dict(r_s_latent=r_s, wa_latent=wa, we_latent=we, audio_num_frames=T, float_fmt_model=fmt, a_cfg_scale=2.0, r_cfg_scale=1.0,
+                e_cfg_scale=1.0, include_r_cfg=False, nfe=4, torchdiffeq_ode_method="euler", ode_atol=1e-5, ode_rtol=1e-5,
+                audio_dropout_prob=0.1, ref_dropout_prob=0.1, emotion_dropout_prob=0.1, fix_noise_seed=True, seed=15)
+    r_d, _ = S.sample_rd_sequence_va(**args)
+    assert r_d.shape == (2, 25, 512) and torch.equal(r_d, S.sample_rd_sequence_va(**args)[0])
+    noise = pkg.fmt.draw_noise(1, 2, models["fcfg"], 15, device="cuda:0")
+    assert torch.equal(r_d, fmt.sample(r_s, wa, we, noise, 4, 2.0, 1.0, 1.0).cpu())
+    want = O.sample_rd(models["sds"]["fmt"], models["fcfg"], r_s[:1], wa[:1], we[:1], noise[:, :1].cpu(), 4, 2.0, 1.0, 1.0)
+    assert rel_l2(r_d[:1], want) < 5e-3
+
+    r_d = r_d * 0.3
+    frames, _ = n["ApplyFloatSynthesis"]().apply_synthesis(pipe_app, dec, r_d[:, :3])
+    assert frames.shape == (6, SIZE, SIZE, 3) and frames.min() >= 0 and frames.max() <= 1
+    direct = dec.decode_latent_into_processed_images(pipe_app["h_source"][1:2], r_d[1, :3], [f[1:2] for f in pipe_app["feats"]]).cpu()
+    assert torch.equal(frames[3:], direct)
+    empty, _ = n["ApplyFloatSynthesis"]().apply_synthesis(pipe_app, dec, r_d[:, :0])
+    assert empty.shape == (0, SIZE, SIZE, 3)
+
+
+def test_va_errors(models):
+    n = pkg.NODE_CLASS_MAPPINGS
+    _, _, _, enc = n["LoadFloatEncoderModel"]().load_encoder_infer_arch("encoder.safetensors", "cuda:0", False)
+    with pytest.raises(ValueError):
+        n["ApplyFloatEncoder"]().apply_encoder(torch.zeros(1, 32, 32, 3), enc)
+    with pytest.raises(ValueError):
+        n["LoadFloatSynthesisModel"]().load_synthesis_infer_arch("decoder.safetensors", "cuda:0", 2, "[1, 3, 3, 1]", False)
+    with pytest.raises(ValueError):
+        n["LoadFMTModel"]().load_fmt_model("fmt.safetensors", "cuda:0", False, 600, 8, 2, 10, 25.0, 2.0)  # dim_a <= 0
+    with pytest.raises(FileNotFoundError):
+        n["LoadAudioProjectionLayer"]().load_projection_layer("nope.safetensors", "cuda:0")

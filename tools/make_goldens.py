@@ -391,8 +391,39 @@ def gen_node_surface(ns):
     print("  wrote node_surface.json")
 
 
+def gen_node_surface_va(ns):
+    """Contracts of the very-advanced loaders / stage nodes captured from the reference classes (nodes_vadv_loader.py,
+    nodes_vadv.py): widget names, types, defaults and ranges (tooltips dropped - they are prose, not contract), return
+    tuples, FUNCTION / CATEGORY / names."""
+    import importlib
+    import json
+    print("[node surface VA]")
+
+    def strip(o):
+        if isinstance(o, dict):
+            return {k: strip(v) for k, v in o.items() if k != "tooltip"}
+        if isinstance(o, (list, tuple)):
+            return [strip(v) for v in o]
+        return o
+    out = {}
+    for m in ("nodes_vadv_loader", "nodes_vadv"):
+        mod = importlib.import_module("floatref.src.nodes." + m)
+        for name in dir(mod):
+            c = getattr(mod, name)
+            if isinstance(c, type) and hasattr(c, "UNIQUE_NAME") and c.__module__ == mod.__name__:
+                out[name] = dict(INPUT_TYPES=strip(c.INPUT_TYPES()), RETURN_TYPES=list(c.RETURN_TYPES), RETURN_NAMES=list(c.RETURN_NAMES),
+                                 FUNCTION=c.FUNCTION, CATEGORY=c.CATEGORY, UNIQUE_NAME=c.UNIQUE_NAME, DISPLAY_NAME=c.DISPLAY_NAME,
+                                 SUFFIX=getattr(mod, "SUFFIX", None))
+    with open(os.path.join(GOLD, "node_surface_va.json"), "w") as f:
+        json.dump(out, f, indent=1, default=str)
+    print("  wrote node_surface_va.json (%d classes)" % len(out))
+
+
 def main():
     ns = ref_import.load()
+    if os.environ.get("GOLDENS_ONLY") == "va":
+        gen_node_surface_va(ns)
+        return
     if os.environ.get("GOLDENS_ONLY") == "aud":
         gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
         gen_audio(ns, "base", config.AudioConfig(), seed=1300, seconds=2.0, T=50)
@@ -402,6 +433,7 @@ def main():
         gen_encoder(ns, 512, seed=1100, sparse=True)
         return
     gen_node_surface(ns)
+    gen_node_surface_va(ns)
     if os.environ.get("GOLDENS_ONLY") == "nodes":
         return
     gen_e2e_config1(ns)
