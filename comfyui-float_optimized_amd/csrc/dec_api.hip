@@ -461,11 +461,16 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   const int lpp = L.C / 8, gpb = 256 / lpp;
   static const int pix_env = getenv("FLOAT_DEC_FLOW_PIX") ? atoi(getenv("FLOAT_DEC_FLOW_PIX")) : 0;  // tuning aid
   const int pix = pix_env ? pix_env : (lpp <= 8 ? 4 : 2);
-  const int max_bx = (R * R / pix + gpb - 1) / gpb;
-  const int bx = std::max(1, std::min(max_bx, (2048 + n - 1) / n));
-  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx, n), dim3(256), 0, st, g);
-  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx, n), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx, n), dim3(256), 0, st, g);
+  const int step = gpb * pix;  // pixels one workgroup covers per iteration
+  const int max_bx = (R * R + step - 1) / step;
+  static const int wg_env = getenv("FLOAT_DEC_FLOW_WGS") ? atoi(getenv("FLOAT_DEC_FLOW_WGS")) : 2048;
+  int bx = std::max(1, std::min(max_bx, (wg_env + n - 1) / n));
+  if (bx >= 8) bx &= ~7;  // bands in multiples of 8: band <-> XCD affinity (dec_flow_kernel)
+  g.band_pix = ((R * R + bx - 1) / bx + step - 1) / step * step;
+  g.nbands = bx = (R * R + g.band_pix - 1) / g.band_pix;
+  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n), dim3(256), 0, st, g);
+  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n), dim3(256), 0, st, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }

@@ -681,6 +681,7 @@ struct FlowArgs {
   int final_mode;      // 0: none, 1: HWC clamp(-1,1)*0.5+0.5 (FLOAT.py:149-152), 2: raw CHW
   int write_pyr;       // store flow_out / rgb_out (0 on the last level: nobody reads them)
   int F, R, C, ld_s;
+  int nbands, band_pix;  // the image is cut into nbands runs of band_pix consecutive pixels (multiple of gpb*PIX)
 };
 
 __device__ __forceinline__ float up2_tap(const float* __restrict__ prev, int f, int Rp, int Y, int X, int j) {
@@ -721,7 +722,22 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   const int C = g.C;
   const int lpp = C >> 3;            // lanes per pixel (4..64)
   const int gpb = 256 / lpp;         // lane groups per block
-  const int f = blockIdx.y;
+  // Block -> (band of consecutive pixels, frame).  All frames of one band run back to back on ONE XCD (block ids
+  // congruent mod 8 share an XCD), so the band's slice of the skip features is fetched into that XCD's L2 once
+  // and serves every frame of the batch; a plain (x = pixels, y = frame) grid swept the whole 16.8 MB map per
+  // frame and sent the bilinear gathers to the Infinity Cache.
+  int f, band;
+  {
+    const int id = blockIdx.x, nb = g.nbands;
+    if ((nb & 7) == 0) {
+      const int slot = id >> 3;
+      f = slot % g.F;
+      band = (slot / g.F) * 8 + (id & 7);
+    } else {
+      f = id / nb;
+      band = id % nb;
+    }
+  }
   const int sub = threadIdx.x % lpp, grp = threadIdx.x / lpp;
   const int c0 = sub * 8;
   for (int c = threadIdx.x; c < C; c += 256) {
@@ -740,7 +756,8 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   const float b1 = g.b1[jch], b2 = g.b2[jch];
   const int R = g.R, npix = R * R, Rp = R >> 1;
   const float fR = (float)R;
-  for (int p0 = (blockIdx.x * gpb + grp) * PIX; p0 < npix; p0 += gridDim.x * gpb * PIX) {
+  const int pend = min(npix, (band + 1) * g.band_pix);
+  for (int p0 = band * g.band_pix + grp * PIX; p0 < pend; p0 += gpb * PIX) {
     const int Y = p0 / R, X0 = p0 - Y * R;  // R % PIX == 0: the PIX pixels share a row
     const size_t po0 = (size_t)f * npix + p0;
     uint4 xu[PIX];
