@@ -18,9 +18,13 @@ class AudioEncoderHIP:
         self.device = torch.device(device)
         self.dtype = dtype
         self.sampling_rate, self.fps = sampling_rate, fps
-        pref = "audio_encoder."
-        sd = {(k[len(pref):] if k.startswith(pref) else k): v for k, v in state_dict.items()
-              if not k.endswith("masked_spec_embed")}  # only used when mask_time_indices is given (never at inference)
+        sd = {}
+        for k, v in state_dict.items():
+            for pref in ("audio_encoder.", "emotion_encoder.wav2vec2_for_emotion."):
+                if k.startswith(pref):
+                    k = k[len(pref):]
+            if not k.endswith("masked_spec_embed"):  # only used when mask_time_indices is given (never at inference)
+                sd[k] = v
         c = self.cfg
         n = len(c.conv_dim)
         if n > 8 or len(c.conv_kernel) != n or len(c.conv_stride) != n:
@@ -32,6 +36,10 @@ class AudioEncoderHIP:
         ncfg.hidden, ncfg.layers, ncfg.heads, ncfg.intermediate = c.hidden_size, c.num_hidden_layers, c.num_attention_heads, c.intermediate_size
         ncfg.pos_k, ncfg.pos_groups = c.num_conv_pos_embeddings, c.num_conv_pos_embedding_groups
         ncfg.dim_w, ncfg.only_last, ncfg.dtype, ncfg.ln_eps = c.dim_w, int(c.only_last_features), native.DTYPES[dtype], c.layer_norm_eps
+        if c.feat_extract_norm not in ("group", "layer"):
+            raise ValueError("feat_extract_norm must be 'group' or 'layer', got %r" % (c.feat_extract_norm,))
+        ncfg.feat_norm_layer, ncfg.stable_ln = int(c.feat_extract_norm == "layer"), int(c.do_stable_layer_norm)
+        ncfg.conv_bias, ncfg.num_labels = int(c.conv_bias), int(c.num_labels)
         arr, keep = native.tensor_table(sd)
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -61,4 +69,38 @@ class AudioEncoderHIP:
             for b in range(a.shape[0]):
                 native.check(native.lib().float_aud_inference(self._h, native.dev_ptr(a[b]), a.shape[1], int(seq_len),
                                                               native.dev_ptr(out[b]), native.stream_ptr(self.device)))
+        return out
+
+
+class Audio2EmotionHIP(AudioEncoderHIP):
+    """Speech-to-emotion (reference Audio2Emotion, FLOAT.py:378-401, on Wav2Vec2ForSpeechClassification,
+    wav2vec2_ser.py:41-118): the wav2vec2-large variant of the same operator with the classification head.
+    state_dict keys: `wav2vec2.*`, `classifier.{dense,out_proj}.*` (prefix `emotion_encoder.wav2vec2_for_emotion.` stripped)."""
+
+    id2label = {0: "angry", 1: "disgust", 2: "fear", 3: "happy", 4: "neutral", 5: "sad", 6: "surprise"}  # FLOAT.py:390
+
+    def __init__(self, state_dict, cfg: AudioConfig = None, device="cuda:0", dtype="fp16"):
+        from .config import emotion_audio_config
+        cfg = cfg or emotion_audio_config()
+        if not cfg.num_labels:
+            raise ValueError("Audio2EmotionHIP needs a config with num_labels > 0")
+        super().__init__(state_dict, cfg, device, dtype)
+
+    def inference(self, a, seq_len):
+        raise TypeError("the speech-emotion model has no audio projection; use predict_emotion")
+
+    @torch.no_grad()
+    def predict_emotion(self, a, prev_a=None):
+        """FLOAT.py:396-401: a (B,N) normalised waveform -> softmax scores (B, num_labels)."""
+        if prev_a is not None:
+            a = torch.cat([prev_a, a], dim=1)
+        a = a.to(self.device, torch.float32)
+        if a.dim() == 1:
+            a = a[None]
+        a = a.contiguous()
+        out = torch.empty(a.shape[0], self.cfg.num_labels, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            for b in range(a.shape[0]):
+                native.check(native.lib().float_aud_classify(self._h, native.dev_ptr(a[b]), a.shape[1], native.dev_ptr(out[b]),
+                                                             native.stream_ptr(self.device)))
         return out

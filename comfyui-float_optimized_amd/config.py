@@ -55,6 +55,11 @@ class AudioConfig:
     layer_norm_eps: float = 1e-5
     dim_w: int = 512
     only_last_features: bool = False
+    # wav2vec2-large family switches (the speech-emotion model, model_configs/emotion_ser/config.json)
+    feat_extract_norm: str = "group"
+    do_stable_layer_norm: bool = False
+    conv_bias: bool = False
+    num_labels: int = 0       # > 0: classification head instead of the audio projection
 
     def to_hf(self):
         """The same shape as a transformers Wav2Vec2Config (eager attention, group-norm feature extractor)."""
@@ -64,18 +69,31 @@ class AudioConfig:
                               num_hidden_layers=self.num_hidden_layers, num_attention_heads=self.num_attention_heads,
                               intermediate_size=self.intermediate_size, num_conv_pos_embeddings=self.num_conv_pos_embeddings,
                               num_conv_pos_embedding_groups=self.num_conv_pos_embedding_groups, layer_norm_eps=self.layer_norm_eps,
-                              feat_extract_norm="group", conv_bias=False, do_stable_layer_norm=False, attn_implementation="eager")
+                              feat_extract_norm=self.feat_extract_norm, conv_bias=self.conv_bias,
+                              do_stable_layer_norm=self.do_stable_layer_norm, attn_implementation="eager",
+                              **({"num_labels": self.num_labels} if self.num_labels else {}))
 
     @classmethod
-    def from_hf(cls, hf, dim_w=512, only_last_features=False):
-        if getattr(hf, "feat_extract_norm", "group") != "group" or getattr(hf, "do_stable_layer_norm", False) or getattr(hf, "conv_bias", False):
-            raise ValueError("only the wav2vec2-base family (feat_extract_norm='group', no conv bias, post-LayerNorm encoder) is supported")
+    def from_hf(cls, hf, dim_w=512, only_last_features=False, num_labels=0):
         return cls(tuple(hf.conv_dim), tuple(hf.conv_kernel), tuple(hf.conv_stride), hf.hidden_size, hf.num_hidden_layers,
                    hf.num_attention_heads, hf.intermediate_size, hf.num_conv_pos_embeddings, hf.num_conv_pos_embedding_groups,
-                   hf.layer_norm_eps, dim_w, only_last_features)
+                   hf.layer_norm_eps, dim_w, only_last_features, getattr(hf, "feat_extract_norm", "group"),
+                   bool(getattr(hf, "do_stable_layer_norm", False)), bool(getattr(hf, "conv_bias", False)), num_labels)
 
 
 def small_audio_config():
     """Reduced wav2vec2 shape for fast parity tests (same head dim 64, LayerNorm widths multiples of 256)."""
     return AudioConfig(conv_dim=(256,) * 7, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
                        num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=16, dim_w=256)
+
+
+def emotion_audio_config():
+    """The speech-emotion recogniser: wav2vec2-large-xlsr shape of model_configs/emotion_ser/config.json with 7 labels."""
+    return AudioConfig(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16, intermediate_size=4096,
+                       feat_extract_norm="layer", do_stable_layer_norm=True, conv_bias=True, num_labels=7)
+
+
+def small_emotion_config():
+    return AudioConfig(conv_dim=(256,) * 7, hidden_size=256, num_hidden_layers=2, num_attention_heads=4, intermediate_size=512,
+                       num_conv_pos_embeddings=16, num_conv_pos_embedding_groups=16, feat_extract_norm="layer",
+                       do_stable_layer_norm=True, conv_bias=True, num_labels=7)

@@ -8,13 +8,15 @@
 
 namespace {
 
-struct ConvL {
-  u16* W = nullptr;  // [N][k*Cin], K ordered (tap, channel)
-  int cin = 0, cout = 0, k = 0, stride = 0;
-};
-
 struct LnP {
   float *g = nullptr, *b = nullptr;
+};
+
+struct ConvL {
+  u16* W = nullptr;  // [N][k*Cin], K ordered (tap, channel)
+  float* bias = nullptr;  // conv_bias = true (speech-emotion model)
+  LnP ln;                 // feat_extract_norm = "layer": LayerNorm over channels after the conv
+  int cin = 0, cout = 0, k = 0, stride = 0;
 };
 
 struct TLayer {
@@ -32,7 +34,10 @@ struct float_aud {
   DevicePool ws;    // workspace, regrown when a longer clip arrives
   int C = 0, D = 0;
   float* w0 = nullptr;  // [C][k0] fp32
-  LnP gn;               // GroupNorm affine of layer 0
+  float* b0 = nullptr;  // conv bias of layer 0 (conv_bias) or nullptr
+  LnP gn;               // GroupNorm (or, feat_norm_layer, LayerNorm) affine of layer 0
+  float *cls_dense_w = nullptr, *cls_dense_b = nullptr, *cls_out_w = nullptr, *cls_out_b = nullptr;  // classification head
+  float *pooled = nullptr, *cls_h = nullptr, *cls_logits = nullptr;
   std::vector<ConvL> convs;  // layers 1..n-1
   LnP fp_ln;
   FmtLin fp_proj;
@@ -91,7 +96,9 @@ int create_impl(float_aud* h, const TensorTable& tt) {
     if (!w) return FLOAT_E_MISSING;
     FH_REQUIRE(w->ndim == 3 && w->shape[0] == h->C && w->shape[1] == 1 && w->shape[2] == c.conv_kernel[0],
                "conv_layers.0.conv.weight must be (%d,1,%d)", h->C, c.conv_kernel[0]);
-    FH_REQUIRE(tt.find(p + "conv.bias") == nullptr, "conv_bias=true feature extractors are not supported");
+    const float_tensor_t* cb = tt.find(p + "conv.bias");
+    FH_REQUIRE((cb != nullptr) == (c.conv_bias != 0), "conv_bias=%d but '%sconv.bias' is %s", c.conv_bias, p.c_str(), cb ? "present" : "absent");
+    if (cb && (rc = upload(&h->pool, cb->data, (size_t)h->C, &h->b0))) return rc;
     if ((rc = upload(&h->pool, w->data, (size_t)h->C * c.conv_kernel[0], &h->w0))) return rc;
     if ((rc = load_ln(h, tt, p + "layer_norm", h->C, &h->gn))) return rc;
   }
@@ -106,8 +113,12 @@ int create_impl(float_aud* h, const TensorTable& tt) {
     L.stride = c.conv_stride[i];
     FH_REQUIRE(w->ndim == 3 && w->shape[0] == L.cout && w->shape[1] == L.cin && w->shape[2] == L.k, "conv_layers.%d.conv.weight must be (%d,%d,%d)",
                i, L.cout, L.cin, L.k);
-    FH_REQUIRE(tt.find(p + "conv.bias") == nullptr && tt.find(p + "layer_norm.weight") == nullptr,
-               "only feat_extract_norm='group' without conv bias is supported (conv layer %d)", i);
+    const float_tensor_t* cb = tt.find(p + "conv.bias");
+    FH_REQUIRE((cb != nullptr) == (c.conv_bias != 0), "conv_bias=%d but conv layer %d %s a bias", c.conv_bias, i, cb ? "has" : "lacks");
+    if (cb && (rc = upload(&h->pool, cb->data, (size_t)L.cout, &L.bias))) return rc;
+    FH_REQUIRE((tt.find(p + "layer_norm.weight") != nullptr) == (c.feat_norm_layer != 0),
+               "feat_norm_layer=%d does not match the checkpoint (conv layer %d)", c.feat_norm_layer, i);
+    if (c.feat_norm_layer && (rc = load_ln(h, tt, p + "layer_norm", L.cout, &L.ln))) return rc;
     std::vector<u16> hw((size_t)L.cout * L.k * L.cin);
     for (int n = 0; n < L.cout; ++n)
       for (int ci = 0; ci < L.cin; ++ci)
@@ -183,10 +194,28 @@ int create_impl(float_aud* h, const TensorTable& tt) {
     if ((rc = load_ln(h, tt, p + "layer_norm", h->D, &L.ln1))) return rc;
     if ((rc = load_ln(h, tt, p + "final_layer_norm", h->D, &L.ln2))) return rc;
   }
-  // ---- audio projection: Linear(layers*D | D -> dim_w) + LayerNorm + SiLU (FLOAT.py:338-342)
-  const int din = c.only_last ? h->D : c.layers * h->D;
-  if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {"audio_projection.0"}, c.dim_w, din, &h->aproj))) return rc;
-  if ((rc = load_ln(h, tt, "audio_projection.1", c.dim_w, &h->aproj_ln))) return rc;
+  if (c.num_labels > 0) {
+    // ---- classification head (wav2vec2_ser.py:23-38): dense -> tanh -> out_proj, fp32
+    const float_tensor_t* dw = need(tt, "classifier.dense.weight");
+    const float_tensor_t* db = need(tt, "classifier.dense.bias");
+    const float_tensor_t* ow = need(tt, "classifier.out_proj.weight");
+    const float_tensor_t* ob = need(tt, "classifier.out_proj.bias");
+    if (!dw || !db || !ow || !ob) return FLOAT_E_MISSING;
+    FH_REQUIRE(TensorTable::numel(dw) == (int64_t)h->D * h->D && TensorTable::numel(ow) == (int64_t)c.num_labels * h->D,
+               "classifier head must be dense (%d,%d) and out_proj (%d,%d)", h->D, h->D, c.num_labels, h->D);
+    if ((rc = upload(&h->pool, dw->data, (size_t)h->D * h->D, &h->cls_dense_w))) return rc;
+    if ((rc = upload(&h->pool, db->data, (size_t)h->D, &h->cls_dense_b))) return rc;
+    if ((rc = upload(&h->pool, ow->data, (size_t)c.num_labels * h->D, &h->cls_out_w))) return rc;
+    if ((rc = upload(&h->pool, ob->data, (size_t)c.num_labels, &h->cls_out_b))) return rc;
+    if ((rc = h->pool.alloc(&h->pooled, (size_t)h->D))) return rc;
+    if ((rc = h->pool.alloc(&h->cls_h, (size_t)h->D))) return rc;
+    if ((rc = h->pool.alloc(&h->cls_logits, (size_t)std::max(c.num_labels, 16)))) return rc;
+  } else {
+    // ---- audio projection: Linear(layers*D | D -> dim_w) + LayerNorm + SiLU (FLOAT.py:338-342)
+    const int din = c.only_last ? h->D : c.layers * h->D;
+    if ((rc = fmt_pack_linear(&h->pool, c.dtype, tt, {"audio_projection.0"}, c.dim_w, din, &h->aproj))) return rc;
+    if ((rc = load_ln(h, tt, "audio_projection.1", c.dim_w, &h->aproj_ln))) return rc;
+  }
   fmt_gemm_prime(c.dtype);
   return FLOAT_OK;
 }
@@ -216,13 +245,13 @@ int ensure_workspace(float_aud* h, int n_samples, int Tn, hipStream_t st) {
   A(&h->qkv16, (size_t)Mp * 3 * D);
   A(&h->att16, (size_t)Mp * D);
   A(&h->hid16, (size_t)Mp * c.intermediate);
-  A(&h->stack16, (size_t)Mp * h->aproj.K);
+  A(&h->stack16, (size_t)Mp * std::max(h->aproj.K, 128));
   A(&h->hproj, (size_t)Mp * D);
   A(&h->pos, (size_t)Mp * D);
   A(&h->h, (size_t)Mp * D);
   A(&h->h1, (size_t)Mp * D);
   A(&h->y, (size_t)Mp * D);
-  A(&h->yproj, (size_t)Mp * c.dim_w);
+  A(&h->yproj, (size_t)Mp * std::max(c.dim_w, 256));
   if (rc) return rc;
   h->cap_samples = ns;
   h->cap_T = Tc;
@@ -244,17 +273,35 @@ int launch_ln(int D, const AudLnArgs& g, hipStream_t st) {
   return FLOAT_OK;
 }
 
+// Length of the feature sequence the extractor produces for n_samples (before any interpolation).
+int feature_len(const float_aud_cfg_t& c, int n_samples) {
+  long L = n_samples;
+  for (int i = 0; i < c.n_conv; ++i) {
+    if (L < c.conv_kernel[i]) return 0;
+    L = (L - c.conv_kernel[i]) / c.conv_stride[i] + 1;
+  }
+  return (int)L;
+}
+
+// Tn: number of frames fed to the transformer: seq_len (interpolated, audio conditioning) or, Tn <= 0, the
+// extractor's own length (speech-emotion model, no interpolation).  wa: (Tn, dim_w) or scores: (num_labels).
 template <class T>
-int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* wa, hipStream_t st) {
+int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* out, hipStream_t st) {
   const float_aud_cfg_t& c = h->cfg;
   const int C = h->C, D = h->D;
   int rc;
+  const int Lfeat = feature_len(c, n_samples);
+  FH_REQUIRE(Lfeat >= 1, "audio too short for the feature extractor (%d samples)", n_samples);
+  if (Tn <= 0) Tn = Lfeat;
   if ((rc = ensure_workspace(h, n_samples, Tn, st))) return rc;
   // ---- feature extractor
   int L = (n_samples - c.conv_kernel[0]) / c.conv_stride[0] + 1;
-  {
+  FH_REQUIRE(c.conv_kernel[0] == 10, "first conv kernel must be 10 (got %d)", c.conv_kernel[0]);
+  if (c.feat_norm_layer) {
+    hipLaunchKernelGGL((aud_conv0_ln_kernel<T, 10>), dim3((L + 3) / 4), dim3(256), 0, st, a, h->w0, h->b0, c.conv_stride[0], L, C, h->gn.g, h->gn.b,
+                       1e-5f, h->fa);
+  } else {
     const int tchunk = 64, nchunk = (L + tchunk - 1) / tchunk;
-    FH_REQUIRE(c.conv_kernel[0] == 10, "first conv kernel must be 10 (got %d)", c.conv_kernel[0]);
     hipLaunchKernelGGL((aud_conv0_stats_kernel<10>), dim3(nchunk, (C + 255) / 256), dim3(256), 0, st, a, n_samples, h->w0, c.conv_stride[0], L, C,
                        tchunk, h->part);
     hipLaunchKernelGGL(aud_gn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, h->part, nchunk, C, L, h->gn.g, h->gn.b, 1e-5f, h->scsh);
@@ -265,24 +312,29 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* w
   u16 *cur = h->fa, *nxt = h->fb;
   for (const ConvL& Lc : h->convs) {
     const int Lo = (L - Lc.k) / Lc.stride + 1;
-    FH_REQUIRE(Lo >= 1, "audio too short for the feature extractor (%d samples)", n_samples);
     AudGemmArgs g;
     memset(&g, 0, sizeof(g));
     g.A = cur;
     g.lda = (long long)Lc.stride * Lc.cin;
     g.W = Lc.W;
+    g.bias = Lc.bias;
     g.out = nxt;
     g.M = Lo;
     g.N = Lc.cout;
     g.K = Lc.k * Lc.cin;
     g.ldc = Lc.cout;
-    g.act = 1;
+    g.act = c.feat_norm_layer ? 0 : 1;
     hipLaunchKernelGGL((aud_gemm_tile_kernel<T>), dim3((Lo + 127) / 128, Lc.cout / 64), dim3(256), 0, st, g);
+    if (c.feat_norm_layer) {  // LayerNorm over channels + GELU, in place
+      dim3 grid((Lo + 3) / 4);
+      if (Lc.cout == 512) hipLaunchKernelGGL((aud_rowln_gelu_kernel<T, 2>), grid, dim3(256), 0, st, nxt, Lo, Lc.ln.g, Lc.ln.b, 1e-5f);
+      else hipLaunchKernelGGL((aud_rowln_gelu_kernel<T, 1>), grid, dim3(256), 0, st, nxt, Lo, Lc.ln.g, Lc.ln.b, 1e-5f);
+    }
     std::swap(cur, nxt);
     L = Lo;
   }
   FH_CHECK_HIP(hipGetLastError());
-  // ---- interpolate to Tn frames + feature-projection LayerNorm -> packed x16; projection -> hproj (fp32)
+  // ---- (interpolate to Tn frames +) feature-projection LayerNorm -> packed x16; projection -> hproj (fp32)
   {
     dim3 grid((Tn + 3) / 4);
     switch (C / 256) {
@@ -295,7 +347,27 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* w
     g.ldo = D;
     if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
   }
-  // ---- encoder: hidden = LayerNorm(hidden + gelu(pos_conv(hidden)))
+  // ---- encoder.  Post-LayerNorm (wav2vec2-base): hidden = LN(hidden + gelu(pos_conv(hidden))), then per layer
+  // h = LN(h + attn(h)); h = LN(h + ffn(h)).  Stable (pre-)LayerNorm (the speech-emotion model): hidden += pos, per layer
+  // h += attn(LN(h)); h += ffn(LN(h)); one LayerNorm after the last layer.  `h->h` is the fp32 residual stream,
+  // `h->hp16` the packed operand of the next GEMM in both cases.
+  auto ln = [&](const float* a_in, const float* res, const LnP& p, float* o32, u16* o16, int keep_sum, u16* stack, int stack_col) {
+    AudLnArgs g;
+    memset(&g, 0, sizeof(g));
+    g.a = a_in;
+    g.res = res;
+    g.gamma = p.g;
+    g.beta = p.b;
+    g.eps = c.ln_eps;
+    g.out_f32 = o32;
+    g.out_p16 = o16;
+    g.keep_sum = keep_sum;
+    g.out_stack = stack;
+    g.stack_col = stack_col;
+    g.stack_kb = h->aproj.K / 32;
+    g.M = Tn;
+    return launch_ln<T>(D, g, st);
+  };
   {
     dim3 grid((Tn + 15) / 16, h->pos_pairs);
 #define POS_CASE(GP) \
@@ -305,19 +377,10 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* w
       default: fh_set_error("merged positional group width %d unsupported", h->pos_gp); return FLOAT_E_INVALID;
     }
 #undef POS_CASE
-    AudLnArgs g;
-    memset(&g, 0, sizeof(g));
-    g.a = h->hproj;
-    g.res = h->pos;
-    g.gamma = h->enc_ln.g;
-    g.beta = h->enc_ln.b;
-    g.eps = c.ln_eps;
-    g.out_f32 = h->h;
-    g.out_p16 = h->hp16;
-    g.M = Tn;
-    if ((rc = launch_ln<T>(D, g, st))) return rc;
+    if (c.stable_ln) rc = ln(h->hproj, h->pos, h->layers[0].ln1, h->h, h->hp16, 1, nullptr, 0);
+    else rc = ln(h->hproj, h->pos, h->enc_ln, h->h, h->hp16, 0, nullptr, 0);
+    if (rc) return rc;
   }
-  const int stack_kb = h->aproj.K / 32;
   for (int l = 0; l < c.layers; ++l) {
     const TLayer& Ly = h->layers[l];
     {
@@ -336,19 +399,8 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* w
       g.ldo = D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
     }
-    {  // hidden = layer_norm(residual + attention)
-      AudLnArgs g;
-      memset(&g, 0, sizeof(g));
-      g.a = h->y;
-      g.res = h->h;
-      g.gamma = Ly.ln1.g;
-      g.beta = Ly.ln1.b;
-      g.eps = c.ln_eps;
-      g.out_f32 = h->h1;
-      g.out_p16 = h->hp16;
-      g.M = Tn;
-      if ((rc = launch_ln<T>(D, g, st))) return rc;
-    }
+    // post-LN: h1 = layer_norm(h + attn);  stable: h1 = h + attn, operand = final_layer_norm(h1)
+    if ((rc = ln(h->y, h->h, c.stable_ln ? Ly.ln2 : Ly.ln1, h->h1, h->hp16, c.stable_ln, nullptr, 0))) return rc;
     {
       GemmArgs g = fmt_gemm_args(h->hp16, Ly.ff1, Tn);
       g.out16 = h->hid16;
@@ -361,27 +413,25 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* w
       g.ldo = D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
     }
-    {  // hidden = final_layer_norm(hidden + feed_forward(hidden)); also hidden_states[l + 1] of the stack
-      AudLnArgs g;
-      memset(&g, 0, sizeof(g));
-      g.a = h->y;
-      g.res = h->h1;
-      g.gamma = Ly.ln2.g;
-      g.beta = Ly.ln2.b;
-      g.eps = c.ln_eps;
-      g.out_f32 = h->h;
-      g.out_p16 = h->hp16;
-      if (!c.only_last || l == c.layers - 1) {
-        g.out_stack = h->stack16;
-        g.stack_col = c.only_last ? 0 : l * D;
-        g.stack_kb = stack_kb;
-      }
-      g.M = Tn;
-      if ((rc = launch_ln<T>(D, g, st))) return rc;
+    if (c.stable_ln) {
+      // h = h1 + ffn; operand = next layer's layer_norm(h), or, after the last layer, h = encoder.layer_norm(h)
+      const bool last = l == c.layers - 1;
+      if ((rc = ln(h->y, h->h1, last ? h->enc_ln : h->layers[l + 1].ln1, h->h, last ? nullptr : h->hp16, last ? 0 : 1, nullptr, 0))) return rc;
+    } else {
+      // h = final_layer_norm(h1 + ffn): also hidden_states[l + 1] of the stack (FLOAT.py:345-352)
+      const bool stack = c.num_labels == 0 && (!c.only_last || l == c.layers - 1);
+      if ((rc = ln(h->y, h->h1, Ly.ln2, h->h, h->hp16, 0, stack ? h->stack16 : nullptr, c.only_last ? 0 : l * D))) return rc;
     }
   }
-  // ---- audio projection: Linear -> LayerNorm -> SiLU
-  {
+  if (c.num_labels > 0) {
+    // ---- mean over time -> dense -> tanh -> out_proj -> softmax (wav2vec2_ser.py:58-75,94-96; FLOAT.py:396-401)
+    hipLaunchKernelGGL(aud_meanpool_kernel, dim3((D + 255) / 256), dim3(256), 0, st, h->h, Tn, D, h->pooled);
+    hipLaunchKernelGGL(aud_dense_kernel, dim3((D + 3) / 4), dim3(256), 0, st, h->pooled, h->cls_dense_w, h->cls_dense_b, h->cls_h, D, D, 1);
+    hipLaunchKernelGGL(aud_dense_kernel, dim3((c.num_labels + 3) / 4), dim3(256), 0, st, h->cls_h, h->cls_out_w, h->cls_out_b, h->cls_logits,
+                       c.num_labels, D, 0);
+    hipLaunchKernelGGL(aud_softmax_kernel, dim3(1), dim3(64), 0, st, h->cls_logits, out, c.num_labels);
+  } else {
+    // ---- audio projection: Linear -> LayerNorm -> SiLU
     GemmArgs g = fmt_gemm_args(h->stack16, h->aproj, Tn);
     g.out_f32 = h->yproj;
     g.ldo = c.dim_w;
@@ -392,7 +442,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* w
     n.gamma = h->aproj_ln.g;
     n.beta = h->aproj_ln.b;
     n.eps = 1e-5f;  // nn.LayerNorm default (FLOAT.py:340)
-    n.out_f32 = wa;
+    n.out_f32 = out;
     n.M = Tn;
     n.silu = 1;
     if ((rc = launch_ln<T>(c.dim_w, n, st))) return rc;
@@ -418,7 +468,8 @@ int float_aud_create(const float_aud_cfg_t* cfg, const float_tensor_t* tensors, 
              cfg->hidden, cfg->heads);
   FH_REQUIRE(cfg->intermediate % 128 == 0 && cfg->layers >= 1, "bad intermediate size / layer count");
   FH_REQUIRE(cfg->pos_k % 4 == 0 && cfg->pos_groups >= 1 && cfg->hidden % cfg->pos_groups == 0, "bad positional conv shape");
-  FH_REQUIRE(cfg->dim_w % 256 == 0 && cfg->dim_w <= 1024, "dim_w %d unsupported", cfg->dim_w);
+  FH_REQUIRE(cfg->num_labels > 0 || (cfg->dim_w % 256 == 0 && cfg->dim_w <= 1024), "dim_w %d unsupported", cfg->dim_w);
+  FH_REQUIRE(cfg->num_labels >= 0 && cfg->num_labels <= 64, "num_labels %d unsupported", cfg->num_labels);
   FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
   float_aud* h = new float_aud();
   h->cfg = *cfg;
@@ -439,8 +490,18 @@ void float_aud_destroy(float_aud_t* h) {
   delete h;
 }
 
+int float_aud_classify(float_aud_t* h, const float* a, int32_t n_samples, float* scores, void* stream) {
+  FH_REQUIRE(h && a && scores, "null argument to float_aud_classify");
+  FH_REQUIRE(h->cfg.num_labels > 0, "this handle was created with the audio projection head (num_labels = 0)");
+  FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
+  hipStream_t st = (hipStream_t)stream;
+  return h->cfg.dtype == FLOAT_DT_BF16 ? inference_impl<BF16>(h, a, n_samples, 0, scores, st)
+                                       : inference_impl<FP16>(h, a, n_samples, 0, scores, st);
+}
+
 int float_aud_inference(float_aud_t* h, const float* a, int32_t n_samples, int32_t seq_len, float* wa, void* stream) {
   FH_REQUIRE(h && a && wa, "null argument to float_aud_inference");
+  FH_REQUIRE(h->cfg.num_labels == 0, "this handle was created with the classification head (num_labels = %d)", h->cfg.num_labels);
   FH_REQUIRE(seq_len >= 1, "seq_len must be >= 1 (got %d)", seq_len);
   FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
   hipStream_t st = (hipStream_t)stream;

@@ -259,6 +259,7 @@ struct AudLnArgs {
   u16* out_stack;
   int stack_col, stack_kb;
   int M, silu;
+  int keep_sum;  // 1: out_f32 = a + res (the un-normalised residual stream of a pre-LayerNorm encoder), 0: the LayerNorm output
 };
 
 template <class T, int NV>
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(256) void aud_ln_kernel(AudLnArgs g) {
       y.z = fh_silu(y.z);
       y.w = fh_silu(y.w);
     }
-    if (g.out_f32) *reinterpret_cast<float4*>(g.out_f32 + (size_t)row * D + c) = y;
+    if (g.out_f32) *reinterpret_cast<float4*>(g.out_f32 + (size_t)row * D + c) = g.keep_sum ? v[i] : y;
     if (g.out_p16 || g.out_stack) {
       ushort4 o;
       o.x = T::from_float(y.x);
@@ -427,4 +428,122 @@ __global__ __launch_bounds__(256) void aud_attn_kernel(const u16* __restrict__ q
   }
   for (; j < Tn; ++j) acc += sp[j] * T::to_float(vp[(size_t)j * ld]);
   out[fmt_pack_off(qi, h * HD + lane, D / 32)] = T::from_float(acc / sum);
+}
+
+// ------------------------------------------------------------------------------------------
+// feat_extract_norm = "layer" (wav2vec2-large / the speech-emotion model, Wav2Vec2LayerNormConvLayer): every conv is
+// followed by LayerNorm over the CHANNELS of each time step (affine) and GELU.
+// Layer 0: Conv1d(1 -> C, k = 10) + bias, LayerNorm, GELU; one wave per time step, 8 channels per lane (C = 512).
+template <class T, int KW>
+__global__ __launch_bounds__(256) void aud_conv0_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                           int stride, int L, int C, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, u16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (t >= L) return;
+  float xv[KW];
+#pragma unroll
+  for (int k = 0; k < KW; ++k) xv[k] = x[(size_t)t * stride + k];
+  const int per = C / 64;  // channels per lane (<= 8), contiguous
+  float y[8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    y[i] = 0.f;
+    if (i < per) {
+      const int c = lane * per + i;
+      float a = bias ? bias[c] : 0.f;
+#pragma unroll
+      for (int k = 0; k < KW; ++k) a += w[c * KW + k] * xv[k];
+      y[i] = a;
+      s += a;
+    }
+  }
+  const float mu = wave_sum(s) / (float)C;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < per) s2 += (y[i] - mu) * (y[i] - mu);
+  const float rstd = rsqrtf(wave_sum(s2) / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < per) {
+      const int c = lane * per + i;
+      out[(size_t)t * C + c] = T::from_float(fh_gelu_erf((y[i] - mu) * rstd * gamma[c] + beta[c]));
+    }
+}
+
+// Layers 1..n-1: the conv GEMM stores conv + bias (16-bit, row-major); this pass normalises each row over its C channels
+// (affine) and applies GELU in place.  One wave per row.
+template <class T, int NV>
+__global__ __launch_bounds__(256) void aud_rowln_gelu_kernel(u16* __restrict__ x, int M, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps) {
+  constexpr int C = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float v[NV][4];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const ushort4 a = *reinterpret_cast<const ushort4*>(x + (size_t)row * C + i * 256 + lane * 4);
+    v[i][0] = T::to_float(a.x);
+    v[i][1] = T::to_float(a.y);
+    v[i][2] = T::to_float(a.z);
+    v[i][3] = T::to_float(a.w);
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mu = wave_sum(s) * (1.f / C);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s2 += (v[i][e] - mu) * (v[i][e] - mu);
+  const float rstd = rsqrtf(wave_sum(s2) * (1.f / C) + eps);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = i * 256 + lane * 4;
+    const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
+    const float4 bt = *reinterpret_cast<const float4*>(beta + c);
+    ushort4 o;
+    o.x = T::from_float(fh_gelu_erf((v[i][0] - mu) * rstd * gm.x + bt.x));
+    o.y = T::from_float(fh_gelu_erf((v[i][1] - mu) * rstd * gm.y + bt.y));
+    o.z = T::from_float(fh_gelu_erf((v[i][2] - mu) * rstd * gm.z + bt.z));
+    o.w = T::from_float(fh_gelu_erf((v[i][3] - mu) * rstd * gm.w + bt.w));
+    *reinterpret_cast<ushort4*>(x + (size_t)row * C + c) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Classification head of the speech-emotion model (wav2vec2_ser.py:23-38,58-75,94-96; FLOAT.py:396-401):
+// mean over time -> dense -> tanh -> out_proj -> softmax.  fp32; one workgroup.
+__global__ __launch_bounds__(256) void aud_meanpool_kernel(const float* __restrict__ h, int Tn, int D, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  float s = 0.f;
+  for (int t = 0; t < Tn; ++t) s += h[(size_t)t * D + c];
+  out[c] = s / (float)Tn;
+}
+
+// y = act(W x + b), one wave per output; act 1 = tanh
+__global__ __launch_bounds__(256) void aud_dense_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                                        float* __restrict__ y, int N, int K, int act) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += x[k] * W[(size_t)n * K + k];
+  s = wave_sum(s);
+  if (lane == 0) {
+    s += b[n];
+    y[n] = act ? tanhf(s) : s;
+  }
+}
+
+__global__ void aud_softmax_kernel(const float* __restrict__ x, float* __restrict__ y, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float m = -INFINITY;
+  for (int i = 0; i < n; ++i) m = fmaxf(m, x[i]);
+  float s = 0.f;
+  for (int i = 0; i < n; ++i) s += expf(x[i] - m);
+  for (int i = 0; i < n; ++i) y[i] = expf(x[i] - m) / s;
 }

@@ -1,11 +1,11 @@
 """Host-side (PyTorch on ROCm or CPU) producers of the hot path's inputs.  These run ONCE per
 clip and are plumbing, not part of the HIP hot path ("OUT OF SCOPE for HIP").
-The appearance encoder + Direction and the audio encoder (wav2vec2-base + projection) are NOT here any more:
-they are the HIP operators `float_enc_*` / `float_aud_*` (encoder.py / audio.py in this package, SURVEY.md
-section 8f rows 1-2).  What is left:
+The appearance encoder + Direction, the audio encoder (wav2vec2-base + projection) and the speech-emotion classifier
+(wav2vec2-large + head) are NOT here: they are the HIP operators `float_enc_*` / `float_aud_*` (encoder.py / audio.py in
+this package).  What is left is tensor plumbing:
 
   * image / audio pre-processing of the simple node (generate.py:29-39, 69-73)
-  * the speech-emotion classifier used only by emotion="none" (wav2vec2-large-xlsr, FLOAT.py:378-401)
+  * the one-hot emotion vector of a named emotion (FLOAT.py:196-200)
 """
 import math
 
@@ -38,33 +38,6 @@ def preprocess_audio(waveform, sample_rate, target_rate=16000):
         n = int(round(w.shape[-1] * target_rate / sample_rate))
         w = F.interpolate(w[None, None], size=n, mode="linear", align_corners=False)[0, 0]
     return ((w - w.mean()) / torch.sqrt(w.var(unbiased=False) + 1e-7))[None]
-
-
-class EmotionHost(torch.nn.Module):
-    """Speech-emotion recogniser (Audio2Emotion, FLOAT.py:378-401; wav2vec2_ser.py:52-118): wav2vec2 encoder,
-    mean-pool over time, Linear -> tanh -> Linear head, softmax over the 7 labels.  Sub-module names
-    (`wav2vec2`, `classifier.dense`, `classifier.out_proj`) are the checkpoint keys under
-    `emotion_encoder.wav2vec2_for_emotion.`."""
-
-    def __init__(self, config=None, num_labels=7):
-        super().__init__()
-        from transformers import Wav2Vec2Config, Wav2Vec2Model
-        # wav2vec2-large-xlsr shape of the bundled emotion_ser config when none is given
-        self.config = config or Wav2Vec2Config(hidden_size=1024, num_hidden_layers=24, num_attention_heads=16,
-                                               intermediate_size=4096, feat_extract_norm="layer",
-                                               do_stable_layer_norm=True)
-        self.wav2vec2 = Wav2Vec2Model(self.config)
-        self.classifier = torch.nn.Module()
-        self.classifier.dense = torch.nn.Linear(self.config.hidden_size, self.config.hidden_size)
-        self.classifier.out_proj = torch.nn.Linear(self.config.hidden_size, num_labels)
-        self.eval()
-
-    @torch.no_grad()
-    def predict_emotion(self, a):
-        """a (B,N) normalised waveform -> softmax scores (B,7) (FLOAT.py:396-401)."""
-        h = self.wav2vec2(a, return_dict=True).last_hidden_state.mean(dim=1)
-        logits = self.classifier.out_proj(torch.tanh(self.classifier.dense(h)))
-        return torch.softmax(logits, dim=1)
 
 
 EMOTION_LABELS = ["angry", "disgust", "fear", "happy", "neutral", "sad", "surprise"]  # FLOAT.py:390

@@ -38,7 +38,8 @@ class EncCfg(C.Structure):
 class AudCfg(C.Structure):
     _fields_ = [("n_conv", C.c_int32), ("conv_dim", C.c_int32 * 8), ("conv_kernel", C.c_int32 * 8), ("conv_stride", C.c_int32 * 8)] + \
                [(n, C.c_int32) for n in ("hidden", "layers", "heads", "intermediate", "pos_k", "pos_groups", "dim_w", "only_last",
-                                         "dtype")] + [("ln_eps", C.c_float)]
+                                         "dtype")] + [("ln_eps", C.c_float)] + \
+               [(n, C.c_int32) for n in ("feat_norm_layer", "stable_ln", "conv_bias", "num_labels")]
 
 
 _F = C.POINTER(C.c_float)
@@ -73,6 +74,7 @@ _SIGNATURES = {
     "float_enc_forward": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "float_aud_create": (C.c_int, [C.POINTER(AudCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_aud_destroy": (None, [C.c_void_p]),
+    "float_aud_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_aud_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_enc_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
 }

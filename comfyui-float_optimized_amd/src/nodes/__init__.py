@@ -23,7 +23,9 @@ _NODES = (LoadFloatModels, FloatProcess, FloatAdvancedParameters)
 _VA_NODES = (nodes_vadv_loader.LoadFloatEncoderModel, nodes_vadv_loader.LoadFloatSynthesisModel, nodes_vadv_loader.LoadFMTModel,
              nodes_vadv_loader.LoadWav2VecModel, nodes_vadv_loader.LoadAudioProjectionLayer, nodes_vadv.ApplyFloatEncoder,
              nodes_vadv.FloatGetIdentityReferenceVA, nodes_vadv.FloatSampleMotionSequenceRD_VA, nodes_vadv.ApplyFloatSynthesis,
-             nodes_vadv.FloatAudioPreprocessAndFeatureExtract, nodes_vadv.FloatApplyAudioProjection)
+             nodes_vadv.FloatAudioPreprocessAndFeatureExtract, nodes_vadv.FloatApplyAudioProjection,
+             nodes_vadv_loader.LoadEmotionRecognitionModel, nodes_vadv.FloatExtractEmotionWithCustomModel,
+             nodes_vadv.FloatExtractEmotionWithCustomModelDyn)
 NODE_CLASS_MAPPINGS = {c.UNIQUE_NAME: c for c in _NODES + _VA_NODES}
 NODE_DISPLAY_NAME_MAPPINGS = {c.UNIQUE_NAME: c.DISPLAY_NAME for c in _NODES}
 NODE_DISPLAY_NAME_MAPPINGS.update({c.UNIQUE_NAME: c.DISPLAY_NAME + " " + nodes_vadv.SUFFIX for c in _VA_NODES})

@@ -6,8 +6,8 @@ import os
 import torch
 
 from ... import host_models, weights
-from ...audio import AudioEncoderHIP
-from ...config import AudioConfig, FmtConfig, small_audio_config
+from ...audio import Audio2EmotionHIP, AudioEncoderHIP
+from ...config import AudioConfig, FmtConfig, emotion_audio_config, small_audio_config, small_emotion_config
 from ...encoder import EncoderHIP
 from ...fmt import draw_noise
 from ...pipeline import FloatHotPath
@@ -58,9 +58,11 @@ class InferenceAgent:
         aud_sd, aud_cfg = parts["audio_encoder"]
         self.audio_encoder = AudioEncoderHIP(aud_sd, aud_cfg, self.rank, dtype=os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16"),
                                              sampling_rate=opt.sampling_rate, fps=opt.fps)
+        # speech-to-emotion (emotion="none"): the wav2vec2-large variant of the same operator with its classification head
         ser = parts.get("emotion_encoder")
-        self.emotion_encoder = ser.to(self.rank) if ser is not None else None
-        # callable(a) -> (1,7) softmax scores; None disables emotion="none" (speech-to-emotion)
+        self.emotion_encoder = Audio2EmotionHIP(ser[0], ser[1], self.rank, dtype=os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16")) \
+            if ser is not None else None
+        # callable(a) -> (1,7) softmax scores; None disables emotion="none"
         self.emotion_predictor = self.emotion_encoder.predict_emotion if ser is not None else parts.get("emotion_predictor")
 
     # ------------------------------------------------------------------ weights
@@ -77,34 +79,25 @@ class InferenceAgent:
         aud_sd.update({"audio_projection." + k: v for k, v in parts["proj"].items()})
         parts["audio_encoder"] = (aud_sd, AudioConfig(dim_w=opt.dim_w, only_last_features=opt.only_last_features))
         if parts["ser"]:
-            ser = host_models.EmotionHost()
-            miss = ser.load_state_dict(parts["ser"], strict=False)
-            if miss.missing_keys:
-                main_logger.warning("emotion encoder keys missing from checkpoint: %s", miss.missing_keys[:5])
-            parts["emotion_encoder"] = ser
+            parts["emotion_encoder"] = (parts["ser"], emotion_audio_config())
         return parts
 
     @staticmethod
     def synthetic_parts(opt, seed=0):
         """Seeded random weights in the checkpoint layout (no network / no checkpoint available)."""
-        from transformers import Wav2Vec2Config
         cfg = FmtConfig.from_options(opt)
-        torch.manual_seed(seed)
-        small = Wav2Vec2Config(hidden_size=64, num_hidden_layers=2, num_attention_heads=2, intermediate_size=128,
-                               conv_dim=(32, 32, 32, 32, 32, 32, 32), num_conv_pos_embeddings=16,
-                               num_conv_pos_embedding_groups=4)
         acfg = small_audio_config()
         acfg.dim_w = opt.dim_w
         return dict(enc=weights.synth_encoder_state(opt.input_size, seed=seed), dec=weights.synth_decoder_state(opt.input_size, seed=seed),
                     fmt=weights.synth_fmt_state(cfg, seed=seed),
                     audio_encoder=(weights.synth_audio_state(acfg, seed=seed), acfg),
-                    emotion_encoder=host_models.EmotionHost(small))
+                    emotion_encoder=(weights.synth_audio_state(small_emotion_config(), seed=seed), small_emotion_config()))
 
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
     def conditions(self, ref_img, ref_audio, emo=None):
-        """Once-per-clip stage: image -> (s_r, feats, r_s) and audio -> (wa, T) on the HIP operators; the
-        speech-emotion classifier (only for emotion='none') is the one host-side PyTorch model left."""
+        """Once-per-clip stage, all on HIP operators: image -> (s_r, feats, r_s), audio -> (wa, T), and for
+        emotion='none' the speech-emotion scores (FLOAT.py:196-198)."""
         o = self.opt
         s = host_models.preprocess_image(ref_img[0] if ref_img.dim() == 4 else ref_img, o.input_size).to(self.rank)
         a = host_models.preprocess_audio(ref_audio["waveform"][0], ref_audio["sample_rate"], o.sampling_rate).to(self.rank)
@@ -118,10 +111,7 @@ class InferenceAgent:
                 raise NotImplementedError(
                     "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198) but the checkpoint has "
                     "no `emotion_encoder.wav2vec2_for_emotion.` weights - pick an emotion or attach agent.emotion_predictor")
-            # deterministic MIOpen/rocBLAS algorithms so that a seed reproduces a clip bit for bit (the HIP operators
-            # are deterministic by construction)
-            with torch.backends.cudnn.flags(enabled=True, benchmark=False, deterministic=True):
-                we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
+            we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
         else:
             we = host_models.emotion_one_hot(emo, self.rank)
         return dict(s_r=s_r, feats=feats, r_s=r_s, wa=wa, we=we, T=T)

@@ -2,14 +2,14 @@
 Apply FLOAT Encoder, FLOAT Get Identity Reference, Sample Motion Sequence RD, Apply FLOAT Synthesis, plus the audio
 pair (feature extract + projection), which this build runs as ONE fused operator (float_aud_*).  Same class
 attributes, widget names/defaults and return tuples as the reference; tensors between nodes are CPU tensors like there.
-The emotion-recognition nodes (FloatExtractEmotion*) are not part of this build."""
+The emotion nodes run the speech-emotion operator (float_aud_classify)."""
 import math
 
 import torch
 
 from ... import host_models
 from ...fmt import draw_noise
-from . import TORCHDIFFEQ_FIXED_STEP_SOLVERS
+from . import EMOTIONS, TORCHDIFFEQ_FIXED_STEP_SOLVERS
 from . import main_logger as logger
 from .nodes_vadv_loader import BASE_CATEGORY, build_audio_encoder
 from .options.base_options import BaseOptions
@@ -258,3 +258,96 @@ class FloatApplyAudioProjection:
         enc = cache[key]
         enc.fps = wav2vec_features.fps
         return (enc.inference(wav2vec_features.audio, wav2vec_features.n_frames).cpu(),)
+
+
+class FloatExtractEmotionWithCustomModel:
+    UNIQUE_NAME = "FloatExtractEmotionWithCustomModel"
+    DISPLAY_NAME = "FLOAT Extract Emotion from Features"
+    DESCRIPTION = "Emotion conditioning we (B,1,num_labels): predicted from the normalised audio, or one-hot for a named emotion."
+    CATEGORY = BASE_CATEGORY
+
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {"required": {
+            "processed_audio_features": ("TORCH_TENSOR", {}),
+            "emotion_model_pipe": ("EMOTION_MODEL_PIPE", {}),
+            "emotion": (EMOTIONS, {"default": "none"}),
+        }}
+
+    RETURN_TYPES = ("TORCH_TENSOR", "EMOTION_MODEL_PIPE")
+    RETURN_NAMES = ("we_latent", "emotion_model_pipe_out")
+    FUNCTION = "extract_emotion_from_features"
+
+    def extract_emotion_from_features(self, processed_audio_features, emotion_model_pipe, emotion):
+        if not isinstance(emotion_model_pipe, tuple) or len(emotion_model_pipe) != 3:
+            raise TypeError("emotion_model_pipe is not in the expected format (model, feature_extractor_ref, config_dict).")
+        model, _, info = emotion_model_pipe
+        if not isinstance(processed_audio_features, torch.Tensor):
+            raise TypeError("Input 'processed_audio_features' must be a torch.Tensor.")
+        if processed_audio_features.ndim != 2:
+            raise ValueError("Input 'processed_audio_features' must be a 2D tensor (Batch, NumSamplesAfterPrep), got %dD with shape %s."
+                             % (processed_audio_features.ndim, tuple(processed_audio_features.shape)))
+        B, n = processed_audio_features.shape[0], info.get("num_labels")
+        if n is None:
+            raise ValueError("Number of labels (num_labels) not found in emotion model config from pipe.")
+        name = str(emotion).lower()
+        idx = (info.get("label2id") or {}).get(name) if name != "none" else None
+        if name != "none" and idx is None:  # nodes_vadv.py:265-271: unknown name -> predict from the audio
+            logger.warning("Specified emotion '%s' not found in the emotion model's label2id map. Predicting from audio instead.", name)
+        if idx is None:
+            we = model.predict_emotion(processed_audio_features).unsqueeze(1)
+        else:
+            we = torch.nn.functional.one_hot(torch.tensor(idx), num_classes=n).float()[None, None].repeat(B, 1, 1)
+        return (we.cpu(), emotion_model_pipe)
+
+
+class FloatExtractEmotionWithCustomModelDyn:
+    UNIQUE_NAME = "FloatExtractEmotionWithCustomModelDyn"
+    DISPLAY_NAME = "FLOAT Extract Emotion (Dynamic)"
+    DESCRIPTION = "Per-chunk speech-emotion scores, nearest-neighbour up-sampled to one vector per video frame (dynamic we)."
+    CATEGORY = BASE_CATEGORY
+
+    @classmethod
+    def INPUT_TYPES(cls):
+        return {"required": {
+            "audio": ("AUDIO", {}),
+            "emotion_model_pipe": ("EMOTION_MODEL_PIPE", {}),
+            "target_fps": ("FLOAT", {"default": 25.0, "min": 1.0, "max": 120.0, "step": 0.1}),
+            "chunk_duration_sec": ("FLOAT", {"default": 2.0, "min": 0.5, "max": 10.0, "step": 0.1}),
+        }}
+
+    RETURN_TYPES = ("TORCH_TENSOR", "EMOTION_MODEL_PIPE", "TORCH_TENSOR")
+    RETURN_NAMES = ("we_latent_dynamic", "emotion_model_pipe_out", "emotion_sequence")
+    FUNCTION = "extract_dynamic_emotion"
+
+    def extract_dynamic_emotion(self, audio, emotion_model_pipe, target_fps, chunk_duration_sec):
+        model, normalise, info = emotion_model_pipe
+        want = info.get("sampling_rate", 16000)
+        if not isinstance(audio, dict) or "waveform" not in audio or "sample_rate" not in audio:
+            raise TypeError("Input 'audio' must be a ComfyUI AUDIO dictionary.")
+        w, sr = audio["waveform"], audio["sample_rate"]
+        if sr != want:
+            raise ValueError("Input audio SR (%d) must match emotion model's expected SR (%d). Please resample upstream." % (sr, want))
+        if w.ndim == 2:
+            w = w.unsqueeze(1)
+        if w.shape[1] != 1:
+            raise ValueError("Input audio must be mono (1 channel).")
+        B, total = w.shape[0], w.shape[-1]
+        chunk = int(chunk_duration_sec * sr)
+        if chunk == 0:
+            raise ValueError("Chunk duration is too small for the sample rate.")
+        n_chunks = math.ceil(total / chunk)
+        seq = []
+        for b in range(B):  # nodes_vadv.py:812-826: every chunk is normalised on its own, then classified
+            for i in range(n_chunks):
+                piece = normalise(w[b, :, i * chunk:(i + 1) * chunk], sr, want)
+                if piece.shape[1] < 400:  # shorter than the feature extractor's receptive field: pad by replication
+                    piece = torch.nn.functional.pad(piece[:, None], (0, 400 - piece.shape[1]), mode="replicate")[:, 0]
+                seq.append(model.predict_emotion(piece))
+        seq = torch.cat(seq, dim=0).view(B, n_chunks, info["num_labels"]).cpu()
+        T = math.ceil(total / sr * target_fps)
+        if n_chunks > 1:  # nearest-neighbour up-sampling (nodes_vadv.py:835-838)
+            we = torch.nn.functional.interpolate(seq.transpose(1, 2), size=T, mode="nearest").transpose(1, 2)
+        else:
+            we = seq.repeat(1, T, 1)
+        return (we, emotion_model_pipe, seq)

@@ -2,15 +2,15 @@
 model is its own .safetensors under `models/float/...` (utils/downloader.py:20-42), its architecture is INFERRED
 from tensor shapes, and the loaded object is the MI355X HIP operator instead of an nn.Module.  Same class
 attributes, widget names/defaults and return tuples as the reference; the bodies build EncoderHIP / SynthesisHIP /
-FlowMatchingTransformerHIP / AudioEncoderHIP.  The emotion-recognition loader is not part of this build."""
+FlowMatchingTransformerHIP / AudioEncoderHIP / Audio2EmotionHIP."""
 import ast
 import os
 import re
 
 import torch
 
-from ...audio import AudioEncoderHIP
-from ...config import AudioConfig, FmtConfig
+from ...audio import Audio2EmotionHIP, AudioEncoderHIP
+from ...config import AudioConfig, FmtConfig, emotion_audio_config
 from ...decoder import SynthesisHIP
 from ...encoder import EncoderHIP
 from ...fmt import FlowMatchingTransformerHIP
@@ -325,6 +325,52 @@ class LoadAudioProjectionLayer:
         layer = {"state": {"audio_projection." + k: v for k, v in sd.items()}, "inferred_input_feature_dim": din, "dim_a": dim_a,
                  "target_device": torch.device(target_device)}
         return (layer, din, dim_a)
+
+
+class LoadEmotionRecognitionModel:
+    UNIQUE_NAME = "LoadEmotionRecognitionModel"
+    DISPLAY_NAME = "Load Emotion Recognition Model"
+    DESCRIPTION = "Loads a wav2vec2 speech-emotion folder (config.json + model.safetensors) as the HIP classification operator."
+    DEFAULT_FOLDER = "wav2vec-english-speech-emotion-recognition"
+    CATEGORY = FILE_CATEGORY
+
+    @classmethod
+    def INPUT_TYPES(cls):
+        device_options, default_device = _device_options()
+        return {"required": {
+            "model_folder": (look_for_models(WAV2VEC_DIR, cls.DEFAULT_FOLDER, dirs=True), {}),
+            "target_device": (device_options, {"default": default_device}),
+        }}
+
+    RETURN_TYPES = ("EMOTION_MODEL_PIPE", "INT")
+    RETURN_NAMES = ("emotion_model_pipe", "dim_e")
+    FUNCTION = "load_emotion_model"
+
+    def load_emotion_model(self, model_folder, target_device):
+        """(model, feature_extractor_ref, config_dict) like the reference (nodes_vadv_loader.py:287-340); the model is an
+        Audio2EmotionHIP, the feature-extractor slot holds the normaliser this build applies (zero mean / unit variance)."""
+        sub = os.path.join(WAV2VEC_DIR, model_folder)
+        folder = os.path.join(models_dir(), sub)
+        wpath = ensure_model_part_exists("emotion_ser", sub, "model.safetensors")
+        sd = _load_sd(wpath)
+        cfg_path = os.path.join(folder, "config.json")
+        id2label = dict(Audio2EmotionHIP.id2label)
+        if os.path.exists(cfg_path):
+            from transformers import Wav2Vec2Config
+            hf = Wav2Vec2Config.from_pretrained(folder)
+            if not getattr(hf, "num_labels", None):
+                raise ValueError("Missing `num_labels` in emotion recognition config")
+            cfg = AudioConfig.from_hf(hf, num_labels=hf.num_labels)
+            if getattr(hf, "id2label", None):
+                id2label = {int(k): str(v) for k, v in hf.id2label.items()}
+        else:
+            cfg = emotion_audio_config()
+        model = Audio2EmotionHIP(sd, cfg, target_device, dtype=os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16"))
+        model.target_device = torch.device(target_device)
+        info = {"num_labels": cfg.num_labels, "id2label": id2label, "label2id": {v: k for k, v in id2label.items()},
+                "sampling_rate": 16000, "model_path": folder}
+        from ... import host_models
+        return ((model, host_models.preprocess_audio, info), cfg.num_labels)
 
 
 def build_audio_encoder(wav2vec_pipe, projection_layer, only_last_features=None):

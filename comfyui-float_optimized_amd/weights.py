@@ -195,7 +195,9 @@ def synth_audio_state(cfg, seed=0):
     for i, (co, k) in enumerate(zip(cfg.conv_dim, cfg.conv_kernel)):
         q = p + "feature_extractor.conv_layers.%d." % i
         sd[q + "conv.weight"] = _randn(seed, q + "conv.weight", (co, cin, k), math.sqrt(2.0 / (cin * k)))
-        if i == 0:
+        if cfg.conv_bias:
+            sd[q + "conv.bias"] = _randn(seed, q + "conv.bias", (co,), 0.05)
+        if i == 0 or cfg.feat_extract_norm == "layer":
             sd[q + "layer_norm.weight"] = 1.0 + _randn(seed, q + "layer_norm.weight", (co,), 0.1)
             sd[q + "layer_norm.bias"] = _randn(seed, q + "layer_norm.bias", (co,), 0.1)
         cin = co
@@ -228,6 +230,10 @@ def synth_audio_state(cfg, seed=0):
         lin(q + "feed_forward.intermediate_dense", cfg.intermediate_size, D)
         lin(q + "feed_forward.output_dense", D, cfg.intermediate_size)
         ln(q + "final_layer_norm", D)
+    if cfg.num_labels:  # Wav2Vec2ClassificationHead (wav2vec2_ser.py:23-38)
+        lin("classifier.dense", D, D)
+        lin("classifier.out_proj", cfg.num_labels, D, 2.0 / math.sqrt(D))
+        return sd
     din = D if cfg.only_last_features else D * cfg.num_hidden_layers
     lin("audio_projection.0", cfg.dim_w, din)
     ln("audio_projection.1", cfg.dim_w)

@@ -204,6 +204,12 @@ typedef struct {
   int32_t only_last;           /* opt.only_last_features */
   int32_t dtype;               /* FLOAT_DT_* of activations / weights; statistics and the residual stream are fp32 */
   float ln_eps;                /* layer_norm_eps 1e-5 */
+  /* Architecture switches of the wav2vec2-large family used by the speech-emotion model
+   * (src/nodes/model_configs/emotion_ser/config.json): all 0 for wav2vec2-base. */
+  int32_t feat_norm_layer;     /* feat_extract_norm == "layer": LayerNorm over channels after every conv */
+  int32_t stable_ln;           /* do_stable_layer_norm: pre-LayerNorm encoder layers + one final LayerNorm */
+  int32_t conv_bias;           /* feature-extractor convs carry a bias */
+  int32_t num_labels;          /* > 0: classification head (float_aud_classify) instead of the audio projection */
 } float_aud_cfg_t;
 
 typedef struct float_aud float_aud_t;
@@ -218,6 +224,13 @@ void float_aud_destroy(float_aud_t* h);
  * longer than any seen before. */
 int float_aud_inference(float_aud_t* h, const float* a, int32_t n_samples, int32_t seq_len, float* wa,
                         void* stream);
+
+/* Speech-to-emotion (reference Audio2Emotion.predict_emotion, FLOAT.py:378-401, on
+ * Wav2Vec2ForSpeechClassification, src/nodes/models/wav2vec2_ser.py:41-118): wav2vec2 encoder on the un-interpolated
+ * feature sequence, mean over time, dense -> tanh -> out_proj, softmax.  Handle created with num_labels > 0 and the
+ * keys `wav2vec2.*`, `classifier.dense.*`, `classifier.out_proj.*` (prefix `emotion_encoder.wav2vec2_for_emotion.`
+ * stripped).  scores: (num_labels) fp32 device. */
+int float_aud_classify(float_aud_t* h, const float* a, int32_t n_samples, float* scores, void* stream);
 
 /* ---------------------------------------------------------------- misc ------------ */
 int float_hip_abi_version(void);

@@ -464,9 +464,14 @@ def wav2vec_features(sd, cfg, a, dtype=torch.float32):
     """feature_extractor(input_values) (wav2vec2.py:64-65): (B,N) -> (B,C,L)."""
     p = "wav2vec2.feature_extractor.conv_layers."
     h = a.to(dtype)[:, None]
+    layer_norm = getattr(cfg, "feat_extract_norm", "group") == "layer"
     for i, s in enumerate(cfg.conv_stride):
-        h = F.conv1d(h, sd[p + "%d.conv.weight" % i].to(dtype), stride=s)
-        if i == 0:  # GroupNorm(num_groups = C): per-channel statistics over time, eps 1e-5, affine
+        bias = sd[p + "%d.conv.bias" % i].to(dtype) if getattr(cfg, "conv_bias", False) else None
+        h = F.conv1d(h, sd[p + "%d.conv.weight" % i].to(dtype), bias, stride=s)
+        if layer_norm:  # Wav2Vec2LayerNormConvLayer: LayerNorm over the channels of each time step (eps 1e-5, affine)
+            h = _ln_affine(h.transpose(1, 2), sd[p + "%d.layer_norm.weight" % i].to(dtype), sd[p + "%d.layer_norm.bias" % i].to(dtype),
+                           1e-5).transpose(1, 2)
+        elif i == 0:  # GroupNorm(num_groups = C): per-channel statistics over time, eps 1e-5, affine
             mu = h.mean(dim=2, keepdim=True)
             var = ((h - mu) ** 2).mean(dim=2, keepdim=True)
             h = (h - mu) / torch.sqrt(var + 1e-5) * sd[p + "0.layer_norm.weight"].to(dtype)[None, :, None] \
@@ -511,7 +516,9 @@ def wav2vec_encoder(sd, cfg, h, dtype=torch.float32):
     if K % 2 == 0:
         pos = pos[:, :, :-1]  # Wav2Vec2SamePadLayer
     h = h + _gelu(pos).transpose(1, 2)
-    h = _ln_affine(h, g("layer_norm.weight"), g("layer_norm.bias"), cfg.layer_norm_eps)
+    stable = getattr(cfg, "do_stable_layer_norm", False)  # Wav2Vec2EncoderStableLayerNorm: pre-LN layers, one LN at the end
+    if not stable:
+        h = _ln_affine(h, g("layer_norm.weight"), g("layer_norm.bias"), cfg.layer_norm_eps)
     H = cfg.num_attention_heads
     hd = cfg.hidden_size // H
     outs = []
@@ -519,15 +526,24 @@ def wav2vec_encoder(sd, cfg, h, dtype=torch.float32):
         q = "layers.%d." % l
         lin = lambda x, n: x @ g(q + n + ".weight").T + g(q + n + ".bias")  # noqa: E731
         B, T, D = h.shape
-        qh = lin(h, "attention.q_proj").view(B, T, H, hd).transpose(1, 2)
-        kh = lin(h, "attention.k_proj").view(B, T, H, hd).transpose(1, 2)
-        vh = lin(h, "attention.v_proj").view(B, T, H, hd).transpose(1, 2)
+        ln1 = lambda x: _ln_affine(x, g(q + "layer_norm.weight"), g(q + "layer_norm.bias"), cfg.layer_norm_eps)  # noqa: E731
+        ln2 = lambda x: _ln_affine(x, g(q + "final_layer_norm.weight"), g(q + "final_layer_norm.bias"), cfg.layer_norm_eps)  # noqa: E731
+        x = ln1(h) if stable else h
+        qh = lin(x, "attention.q_proj").view(B, T, H, hd).transpose(1, 2)
+        kh = lin(x, "attention.k_proj").view(B, T, H, hd).transpose(1, 2)
+        vh = lin(x, "attention.v_proj").view(B, T, H, hd).transpose(1, 2)
         att = torch.softmax(qh @ kh.transpose(-1, -2) * hd ** -0.5, dim=-1) @ vh
         att = lin(att.transpose(1, 2).reshape(B, T, D), "attention.out_proj")
-        h = _ln_affine(h + att, g(q + "layer_norm.weight"), g(q + "layer_norm.bias"), cfg.layer_norm_eps)
-        ff = lin(_gelu(lin(h, "feed_forward.intermediate_dense")), "feed_forward.output_dense")
-        h = _ln_affine(h + ff, g(q + "final_layer_norm.weight"), g(q + "final_layer_norm.bias"), cfg.layer_norm_eps)
+        ffn = lambda x: lin(_gelu(lin(x, "feed_forward.intermediate_dense")), "feed_forward.output_dense")  # noqa: E731
+        if stable:  # Wav2Vec2EncoderLayerStableLayerNorm
+            h = h + att
+            h = h + ffn(ln2(h))
+        else:       # Wav2Vec2EncoderLayer
+            h = ln1(h + att)
+            h = ln2(h + ffn(h))
         outs.append(h)
+    if stable:
+        outs[-1] = _ln_affine(outs[-1], g("layer_norm.weight"), g("layer_norm.bias"), cfg.layer_norm_eps)
     return outs
 
 
@@ -549,3 +565,17 @@ def audio_encoder_inference(sd, cfg, a, seq_len, sampling_rate=16000, fps=25.0, 
     y = x @ sd["audio_projection.0.weight"].T + sd["audio_projection.0.bias"]
     y = _ln_affine(y, sd["audio_projection.1.weight"], sd["audio_projection.1.bias"], 1e-5)
     return y * torch.sigmoid(y)
+
+
+def audio2emotion_predict(sd, cfg, a, dtype=torch.float32):
+    """Audio2Emotion.predict_emotion (FLOAT.py:396-401) on Wav2Vec2ForSpeechClassification.forward
+    (wav2vec2_ser.py:78-96): wav2vec2 on the un-interpolated features, mean over time (merged_strategy 'mean', :58-75),
+    dense -> tanh -> out_proj (:31-38; dropout inert), softmax.  a (B,N) -> (B, num_labels)."""
+    sd = {k: v.to(dtype) for k, v in sd.items()}
+    f = wav2vec_features(sd, cfg, a, dtype).transpose(1, 2)
+    f = _ln_affine(f, sd["wav2vec2.feature_projection.layer_norm.weight"], sd["wav2vec2.feature_projection.layer_norm.bias"],
+                   cfg.layer_norm_eps)
+    h = f @ sd["wav2vec2.feature_projection.projection.weight"].T + sd["wav2vec2.feature_projection.projection.bias"]
+    h = wav2vec_encoder(sd, cfg, h, dtype)[-1].mean(dim=1)
+    x = torch.tanh(h @ sd["classifier.dense.weight"].T + sd["classifier.dense.bias"])
+    return torch.softmax(x @ sd["classifier.out_proj.weight"].T + sd["classifier.out_proj.bias"], dim=1)

@@ -70,3 +70,35 @@ def test_audio_weight_norm_key_variants_and_errors():
     bad.hidden_size, bad.num_attention_heads = 320, 5  # LayerNorm width not a multiple of 256
     with pytest.raises(ValueError):
         pkg.audio.AudioEncoderHIP(sd, bad, "cuda:0")
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("tag", ["small", "xlsr"])
+def test_speech_emotion_golden(tag, dtype):
+    """float_aud_classify (wav2vec2-large variant + classification head) vs the golden assembled from transformers'
+    Wav2Vec2Model and the reference's Wav2Vec2ClassificationHead.  Scores are probabilities: max |d| <= 1e-3 fp16, 1e-2 bf16 (measured 2.8e-4 / 3.0e-3 on the xlsr shape)."""
+    g = golden("emo_" + tag)
+    cfg = C.small_emotion_config() if tag == "small" else C.emotion_audio_config()
+    sd = W.synth_audio_state(cfg, seed=g["seed"])
+    ser = pkg.audio.Audio2EmotionHIP(sd, cfg, "cuda:0", dtype)
+    a = W.synth_waveform(g["seconds"], seed=g["seed"] + 1)
+    scores = ser.predict_emotion(a).cpu()
+    d = float((scores - g["scores"]).abs().max())
+    print(tag, dtype, "scores max|d| %.3e" % d, [round(float(v), 4) for v in scores[0]])
+    assert scores.shape == g["scores"].shape and d < (1e-3 if dtype == "fp16" else 1e-2)
+    assert abs(float(scores.sum()) - 1.0) < 1e-5 and int(scores.argmax()) == int(g["scores"].argmax())
+    assert torch.equal(ser.predict_emotion(a).cpu(), scores)
+    with pytest.raises(TypeError):
+        ser.inference(a, 25)
+
+
+def test_speech_emotion_live_oracle_ragged():
+    cfg = C.small_emotion_config()
+    sd = W.synth_audio_state(cfg, seed=41)
+    ser = pkg.audio.Audio2EmotionHIP(sd, cfg, "cuda:0", "fp16")
+    for seconds in (0.3, 2.7, 1.0):
+        a = W.synth_waveform(seconds, seed=int(seconds * 10))
+        assert float((ser.predict_emotion(a).cpu() - O.audio2emotion_predict(sd, cfg, a)).abs().max()) < 2e-3
+    # prev_a is concatenated in front (FLOAT.py:397-398)
+    a, p = W.synth_waveform(1.0, seed=2), W.synth_waveform(0.4, seed=3)
+    assert torch.equal(ser.predict_emotion(a, p), ser.predict_emotion(torch.cat([p, a], dim=1)))

@@ -40,7 +40,16 @@ def models(tmp_path_factory):
     os.makedirs(root / "float" / "audio_projections")
     save_file(cont({k[len("audio_projection."):]: v for k, v in sds["aud"].items() if k.startswith("audio_projection.")}),
               str(root / "float" / "audio_projections" / "projection.safetensors"))
-    return dict(root=root, sds=sds, fcfg=fcfg, acfg=acfg)
+    ecfg = C.small_emotion_config()
+    sds["emo"] = W.synth_audio_state(ecfg, seed=31)
+    edir = root / "audio" / "wav2vec-english-speech-emotion-recognition"
+    os.makedirs(edir)
+    save_file(cont(sds["emo"]), str(edir / "model.safetensors"))
+    hf = ecfg.to_hf()
+    hf.id2label = {i: n for i, n in enumerate(["angry", "disgust", "fear", "happy", "neutral", "sad", "surprise"])}
+    hf.label2id = {n: i for i, n in hf.id2label.items()}
+    hf.save_pretrained(str(edir))
+    return dict(root=root, sds=sds, fcfg=fcfg, acfg=acfg, ecfg=ecfg)
 
 
 def test_va_graph(models):
@@ -103,3 +112,27 @@ def test_va_errors(models):
         n["LoadFMTModel"]().load_fmt_model("fmt.safetensors", "cuda:0", False, 600, 8, 2, 10, 25.0, 2.0)  # dim_a <= 0
     with pytest.raises(FileNotFoundError):
         n["LoadAudioProjectionLayer"]().load_projection_layer("nope.safetensors", "cuda:0")
+
+
+def test_va_emotion_nodes(models):
+    n = pkg.NODE_CLASS_MAPPINGS
+    pipe, dim_e = n["LoadEmotionRecognitionModel"]().load_emotion_model("wav2vec-english-speech-emotion-recognition", "cuda:0")
+    assert dim_e == 7 and pipe[2]["label2id"]["happy"] == 3
+    a = torch.cat([W.synth_waveform(1.0, seed=12), W.synth_waveform(1.0, seed=13)])
+    E = n["FloatExtractEmotionWithCustomModel"]()
+    we, _ = E.extract_emotion_from_features(a, pipe, "none")
+    assert we.shape == (2, 1, 7)
+    assert float((we[:, 0] - O.audio2emotion_predict(models["sds"]["emo"], models["ecfg"], a)).abs().max()) < 2e-3
+    we, _ = E.extract_emotion_from_features(a, pipe, "happy")
+    assert torch.equal(we, torch.nn.functional.one_hot(torch.tensor(3), 7).float()[None, None].repeat(2, 1, 1))
+    with pytest.raises(ValueError):
+        E.extract_emotion_from_features(a[0], pipe, "none")
+    # dynamic: 4.5 s in 2 s chunks -> 3 score vectors, nearest-upsampled to ceil(4.5 * 25) = 113 frames
+    wav = torch.from_numpy(np.random.RandomState(3).standard_normal((1, 1, 72000)).astype(np.float32)) * 0.1
+    we_dyn, _, seq = n["FloatExtractEmotionWithCustomModelDyn"]().extract_dynamic_emotion({"waveform": wav, "sample_rate": 16000}, pipe, 25.0, 2.0)
+    assert seq.shape == (1, 3, 7) and we_dyn.shape == (1, 113, 7)
+    assert torch.equal(we_dyn[0, 0], seq[0, 0]) and torch.equal(we_dyn[0, 112], seq[0, 2])
+    chunk0 = pkg.host_models.preprocess_audio(wav[0, :, :32000], 16000, 16000)
+    assert float((seq[0, 0] - O.audio2emotion_predict(models["sds"]["emo"], models["ecfg"], chunk0)[0]).abs().max()) < 2e-3
+    with pytest.raises(ValueError):
+        n["FloatExtractEmotionWithCustomModelDyn"]().extract_dynamic_emotion({"waveform": wav, "sample_rate": 8000}, pipe, 25.0, 2.0)

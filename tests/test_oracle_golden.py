@@ -147,3 +147,17 @@ def test_audio_encoder(tag):
     ap = a if a.shape[1] % need == 0 else torch.nn.functional.pad(a[:, None], (0, need - a.shape[1]), mode="replicate")[:, 0]
     f = O.linear_interpolation(O.wav2vec_features(sd, cfg, ap).transpose(1, 2), int(g["T"]))
     assert rel_l2(f[:, :, ::8], g["feat_interp"]) < TOL_REL
+
+
+@pytest.mark.parametrize("tag", ["small", "xlsr"])
+def test_speech_emotion(tag):
+    """Audio2Emotion.predict_emotion (FLOAT.py:396-401; wav2vec2_ser.py:23-96): layer-norm feature extractor with conv
+    bias, pre-LayerNorm encoder, mean pooling, classification head, softmax."""
+    g = golden("emo_" + tag)
+    if tag == "xlsr" and not __import__("os").environ.get("FLOAT_SLOW_TESTS"):
+        pytest.skip("316 M parameters: ~40 s of CPU; set FLOAT_SLOW_TESTS=1 (the GPU suite covers this shape)")
+    cfg = C.small_emotion_config() if tag == "small" else C.emotion_audio_config()
+    sd = W.synth_audio_state(cfg, seed=g["seed"])
+    scores = O.audio2emotion_predict(sd, cfg, W.synth_waveform(g["seconds"], seed=g["seed"] + 1))
+    assert scores.shape == g["scores"].shape and max_abs(scores, g["scores"]) < 1e-5
+    assert abs(float(scores.sum()) - 1.0) < 1e-5

@@ -335,6 +335,32 @@ def gen_audio(ns, tag, cfg, seed, seconds, T):
     save("aud_%s" % tag, seed=seed, seconds=seconds, T=T, wa=wa, feat_interp=feat[:, :, ::8])
 
 
+def gen_emotion(ns, tag, cfg, seed, seconds):
+    """Audio2Emotion.predict_emotion (FLOAT.py:396-401).  The reference's Wav2Vec2ForSpeechClassification cannot be
+    instantiated on transformers 5.x (its init_weights() call breaks), so the golden is assembled from the
+    same parts it is made of: transformers' Wav2Vec2Model, the reference's own Wav2Vec2ClassificationHead class and the
+    'mean' pooling of merged_strategy (wav2vec2_ser.py:23-38,58-75,94-96), then softmax."""
+    import importlib
+    from transformers import Wav2Vec2Model
+    print("[speech emotion %s]" % tag)
+    ser = importlib.import_module("floatref.src.nodes.models.wav2vec2_ser")
+    sd = weights.synth_audio_state(cfg, seed=seed)
+    hf = cfg.to_hf()
+    hf.final_dropout = 0.0
+    m, head = Wav2Vec2Model(hf), ser.Wav2Vec2ClassificationHead(hf)
+    m.load_state_dict({k[len("wav2vec2."):]: v for k, v in sd.items() if k.startswith("wav2vec2.")}, strict=True)
+    head.load_state_dict({k[len("classifier."):]: v for k, v in sd.items() if k.startswith("classifier.")}, strict=True)
+    m.eval()
+    head.eval()
+    a = weights.synth_waveform(seconds, seed=seed + 1)
+    with torch.no_grad():
+        hs = m(a).last_hidden_state
+        scores = torch.softmax(head(hs.mean(dim=1)), dim=1)
+    o = O.audio2emotion_predict(sd, cfg, a)
+    print("  oracle-ref max|d| %.3e ; scores %s" % (maxdiff(o, scores)[0], [round(float(v), 4) for v in scores[0]]))
+    save("emo_%s" % tag, seed=seed, seconds=seconds, scores=scores, pooled=hs.mean(dim=1))
+
+
 def gen_node_surface(ns):
     """Widget/return contracts of the three north-star nodes and the batch/seed schedule of
     FloatProcess.floatprocess (nodes.py:189-222), captured from the reference classes themselves."""
@@ -424,6 +450,10 @@ def main():
     if os.environ.get("GOLDENS_ONLY") == "va":
         gen_node_surface_va(ns)
         return
+    if os.environ.get("GOLDENS_ONLY") == "emo":
+        gen_emotion(ns, "small", config.small_emotion_config(), seed=1400, seconds=1.3)
+        gen_emotion(ns, "xlsr", config.emotion_audio_config(), seed=1500, seconds=1.0)
+        return
     if os.environ.get("GOLDENS_ONLY") == "aud":
         gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
         gen_audio(ns, "base", config.AudioConfig(), seed=1300, seconds=2.0, T=50)
@@ -453,6 +483,8 @@ def main():
     gen_encoder(ns, 512, seed=1100, sparse=True)
     gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
     gen_audio(ns, "base", config.AudioConfig(), seed=1300, seconds=2.0, T=50)
+    gen_emotion(ns, "small", config.small_emotion_config(), seed=1400, seconds=1.3)
+    gen_emotion(ns, "xlsr", config.emotion_audio_config(), seed=1500, seconds=1.0)
 
 
 if __name__ == "__main__":
