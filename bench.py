@@ -208,8 +208,22 @@ def main():
                 aud.inference(wav, seq_len=T)
             extra["stage_ms"]["appearance_encoder_hip"] = timed(enc_stage)
             extra["stage_ms"]["audio_encoder_hip"] = timed(aud_stage)
+
+            # SURVEY.md 8(d) wall-clock definition, reported beside `value` (never as it): (image, waveform) in HBM ->
+            # frames in pinned host memory through every operator of the path, one clip
+            host = torch.empty(T, args.size, args.size, 3, dtype=torch.float32, pin_memory=True)
+
+            def end_to_end():
+                s_r, _, _, r_s = enc.encode_image_into_latent(img, want_feats=False)
+                enc.hand_feats_to(hp.dec)
+                wa = aud.inference(wav, seq_len=T)
+                r_d2 = hp.sample(r_s, wa, cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+                host.copy_(hp.decode(s_r, None, r_d2, (0, T)))
+            e2e_ms = timed(end_to_end)
+            extra["end_to_end"] = {"ms_per_clip": e2e_ms, "frames_per_s": round(T / (e2e_ms * 1e-3), 1),
+                                   "includes": "appearance encoder + audio encoder + FMT sampling + decode + D2H of the frames (pinned)"}
             hp.dec.set_feats(feats)  # restore the bench's synthetic features
-            del aud, enc
+            del aud, enc, host
         except Exception as e:  # conditioning is plumbing; never fail the bench for it
             extra["stage_ms"]["conditioning"] = "n/a (%s: %s)" % (type(e).__name__, e)
         if args.d2h:
