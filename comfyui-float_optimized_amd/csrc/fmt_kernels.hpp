@@ -20,7 +20,10 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   constexpr int BN = NT * 16;
   constexpr int ROWS = MTW * 16;
   constexpr int NTHR = NW * 64;
-  constexpr int PF = (MTW + NT <= 5) ? 4 : ((MTW + NT <= 8) ? 3 : 2);  // k-steps of operands in flight per wave
+  // k-steps of operands in flight per wave.  With 4 k-blocks per wave (K = 1024 over 8 waves) PF = 4 puts the whole
+  // K slice in flight at once: one memory round trip instead of two for the 48x64 tilings (7 fragments per k-step,
+  // 112 operand registers + 48 accumulators still fit two waves per SIMD)
+  constexpr int PF = (MTW + NT <= 7) ? 4 : ((MTW + NT <= 8) ? 3 : 2);
   extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][BN]
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
