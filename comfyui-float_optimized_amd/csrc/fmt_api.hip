@@ -318,12 +318,14 @@ int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
 template <class T>
 int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s, PendingRed* pend = nullptr) {
   const int nv = h->D / 256;
-  dim3 grid((M + 3) / 4);
+  // one row (wave) per workgroup: 180 single-wave workgroups spread over 180 CUs (4 rows per workgroup: +0.4 %)
+  static const int rpw = getenv("FLOAT_FMT_LN_ROWS") ? std::max(1, std::min(4, atoi(getenv("FLOAT_FMT_LN_ROWS")))) : 1;
+  dim3 grid((M + rpw - 1) / rpw), block(64 * rpw);
   const int ks = pend ? pend->ks : 0;
   LnRed red{};
   if (ks) red = pend->red;
 #define LN_LAUNCH(NV, KS) \
-  hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS>), grid, dim3(256), 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red)
+  hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red)
 #define LN_CASE(NV)                     \
   case NV:                              \
     if (ks == 0) LN_LAUNCH(NV, 0);      \
@@ -397,8 +399,22 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
       g.ldo16 = 3 * D;
       if ((rc = run_gemm<T, EPI_T16>(g, s))) return rc;
     }
-    hipLaunchKernelGGL((fmt_attn_kernel<T>), dim3(bc * c.heads), dim3(512), 0, s, h->qkv16, 3 * D, h->att16, ntok,
-                       c.heads, D, c.attn_window);
+    {
+      // queries per workgroup / lanes per query (FLOAT_FMT_ATTN="qpw,lpq"): single-wave workgroups by default
+      static int qpw = 8, lpq = 8;
+      static const bool parsed = [] {
+        if (const char* v = getenv("FLOAT_FMT_ATTN")) sscanf(v, "%d,%d", &qpw, &lpq);
+        if (lpq != 16) lpq = 8;
+        qpw = std::max(1, std::min(512 / lpq, qpw));
+        return true;
+      }();
+      (void)parsed;
+      dim3 grid(bc * c.heads, (ntok + qpw - 1) / qpw), block(qpw * lpq);
+      if (lpq == 16)
+        hipLaunchKernelGGL((fmt_attn_kernel<T, 16>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, c.heads, D, c.attn_window);
+      else
+        hipLaunchKernelGGL((fmt_attn_kernel<T, 8>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, c.heads, D, c.attn_window);
+    }
     if (split_ok(g_fmt_proj_split, B.proj)) {
       if ((rc = run_gemm_partial<T>(h, base_args(h->att16, B.proj, M), g_fmt_proj_split, s))) return rc;
       pend.ks = g_fmt_proj_split;

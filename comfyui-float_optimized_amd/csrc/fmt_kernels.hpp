@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
                                                         LnRed red) {
   constexpr int D = NV * 256;
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= M) return;
   float* xr = x + (size_t)row * D;
   const float* sh = shift + (size_t)row * ldm;
@@ -441,96 +441,96 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 }
 
 // Banded attention (FMT.py:71-88 with the mask of FMT.py:15-19): query i sees keys |i-j| <= window.
-// One workgroup per (cfg row b, head h); 8 lanes per query, 16 of the 128 head dims each.  With at
-// most 2*window+1 keys per query this is 0.3 % of the evaluation's flops - MFMA/LDS tiling would only
-// add latency - so q/k/v come straight from L2 in 32-byte pieces.  For window <= 2 every load of the
-// query's band is issued before the first use (one memory round trip); wider windows loop.
-// Output is written in the packed A-operand order of the proj GEMM (K = D).
-template <class T>
+// LPQ lanes per query, 128/LPQ head dims each; a workgroup is a run of blockDim.x/LPQ queries of one (cfg row, head)
+// (blockIdx.y = run), so the 24 (row, head) pairs spread over many CUs - with one 512-thread workgroup per pair only 24 CUs
+// pulled q/k/v and the kernel took 5.2 us; single-wave workgroups of 8 queries take 4.1 us.  With at most 2*window+1 keys
+// per query this is 0.3 % of the evaluation's flops - MFMA/LDS tiling would only add latency - so q/k/v come straight from
+// L2.  For window <= 2 every load of the query's band is issued before the first use (one memory round trip); wider
+// windows loop.  Output is written in the packed A-operand order of the proj GEMM (K = D).
+template <class T, int LPQ>
 __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ntok,
                                                        int heads, int D, int window) {
-  constexpr int HD = 128, PD = 16, LPQ = 8;
+  constexpr int HD = 128, PD = HD / LPQ, NU = PD / 8;
   const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const int qi = threadIdx.x / LPQ, part = threadIdx.x % LPQ;
-  if (qi >= ntok) return;  // whole 8-lane groups leave together
+  const int qi = blockIdx.y * (blockDim.x / LPQ) + threadIdx.x / LPQ, part = threadIdx.x % LPQ;
+  if (qi >= ntok) return;  // whole LPQ-lane groups leave together
   const int d0 = h * HD + part * PD;
   const float scale = rsqrtf((float)HD);
   const u16* base = qkv + (size_t)(b * ntok) * ld + d0;
   float qf[PD], o[PD];
-  {
-    const uint4 u0 = *reinterpret_cast<const uint4*>(base + (size_t)qi * ld);
-    const uint4 u1 = *reinterpret_cast<const uint4*>(base + (size_t)qi * ld + 8);
-    const u16* e0 = reinterpret_cast<const u16*>(&u0);
-    const u16* e1 = reinterpret_cast<const u16*>(&u1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      qf[j] = T::to_float(e0[j]) * scale;
-      qf[8 + j] = T::to_float(e1[j]) * scale;
-    }
+  for (int u = 0; u < NU; ++u) {
+    const uint4 uu = *reinterpret_cast<const uint4*>(base + (size_t)qi * ld + u * 8);
+    const u16* e = reinterpret_cast<const u16*>(&uu);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[u * 8 + j] = T::to_float(e[j]) * scale;
   }
 #pragma unroll
   for (int i = 0; i < PD; ++i) o[i] = 0.f;
   float m = -INFINITY, l = 0.f;
-  auto fold = [&](const uint4& k0, const uint4& k1, const uint4& v0, const uint4& v1, bool valid) {
-    const u16* ka = reinterpret_cast<const u16*>(&k0);
-    const u16* kb = reinterpret_cast<const u16*>(&k1);
+  auto fold = [&](const uint4* k, const uint4* v, bool valid) {
     float dot = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dot += qf[j] * T::to_float(ka[j]) + qf[8 + j] * T::to_float(kb[j]);
-    dot += __shfl_xor(dot, 1, 64);
-    dot += __shfl_xor(dot, 2, 64);
-    dot += __shfl_xor(dot, 4, 64);
+    for (int u = 0; u < NU; ++u) {
+      const u16* ke = reinterpret_cast<const u16*>(&k[u]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot += qf[u * 8 + j] * T::to_float(ke[j]);
+    }
+#pragma unroll
+    for (int d = 1; d < LPQ; d <<= 1) dot += __shfl_xor(dot, d, 64);
     if (!valid) return;
     const float mn = fmaxf(m, dot);
     const float alpha = __expf(m - mn), p = __expf(dot - mn);
     l = l * alpha + p;
     m = mn;
-    const u16* va = reinterpret_cast<const u16*>(&v0);
-    const u16* vb = reinterpret_cast<const u16*>(&v1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      o[j] = o[j] * alpha + p * T::to_float(va[j]);
-      o[8 + j] = o[8 + j] * alpha + p * T::to_float(vb[j]);
+    for (int u = 0; u < NU; ++u) {
+      const u16* ve = reinterpret_cast<const u16*>(&v[u]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[u * 8 + j] = o[u * 8 + j] * alpha + p * T::to_float(ve[j]);
     }
   };
   if (window <= 2) {
-    uint4 kk[5][2], vv[5][2];
+    uint4 kk[5][NU], vv[5][NU];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int kj = min(max(qi + t - 2, 0), ntok - 1);
       const u16* kp = base + (size_t)kj * ld + D;
-      kk[t][0] = *reinterpret_cast<const uint4*>(kp);
-      kk[t][1] = *reinterpret_cast<const uint4*>(kp + 8);
-      vv[t][0] = *reinterpret_cast<const uint4*>(kp + D);
-      vv[t][1] = *reinterpret_cast<const uint4*>(kp + D + 8);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        kk[t][u] = *reinterpret_cast<const uint4*>(kp + u * 8);
+        vv[t][u] = *reinterpret_cast<const uint4*>(kp + D + u * 8);
+      }
     }
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int kj = qi + t - 2;
       const bool valid = kj >= 0 && kj < ntok && (t - 2 >= -window) && (t - 2 <= window);
-      fold(kk[t][0], kk[t][1], vv[t][0], vv[t][1], valid);
+      fold(kk[t], vv[t], valid);
     }
   } else {
     for (int kj = qi - window; kj <= qi + window; ++kj) {
       const int kc = min(max(kj, 0), ntok - 1);
       const u16* kp = base + (size_t)kc * ld + D;
-      const uint4 k0 = *reinterpret_cast<const uint4*>(kp), k1 = *reinterpret_cast<const uint4*>(kp + 8);
-      const uint4 v0 = *reinterpret_cast<const uint4*>(kp + D), v1 = *reinterpret_cast<const uint4*>(kp + D + 8);
-      fold(k0, k1, v0, v1, kj >= 0 && kj < ntok);
+      uint4 k[NU], v[NU];
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        k[u] = *reinterpret_cast<const uint4*>(kp + u * 8);
+        v[u] = *reinterpret_cast<const uint4*>(kp + D + u * 8);
+      }
+      fold(k, v, kj >= 0 && kj < ntok);
     }
   }
   const float inv = 1.f / l;
-  uint4 u0, u1;
-  u16* e0 = reinterpret_cast<u16*>(&u0);
-  u16* e1 = reinterpret_cast<u16*>(&u1);
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    e0[j] = T::from_float(o[j] * inv);
-    e1[j] = T::from_float(o[8 + j] * inv);
-  }
   const int row = b * ntok + qi;
-  *reinterpret_cast<uint4*>(out + fmt_pack_off(row, d0, D / 32)) = u0;
-  *reinterpret_cast<uint4*>(out + fmt_pack_off(row, d0 + 8, D / 32)) = u1;
+#pragma unroll
+  for (int u = 0; u < NU; ++u) {
+    uint4 uo;
+    u16* e = reinterpret_cast<u16*>(&uo);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = T::from_float(o[u * 8 + j] * inv);
+    *reinterpret_cast<uint4*>(out + fmt_pack_off(row, d0 + u * 8, D / 32)) = uo;
+  }
 }
 
 // Condition rows for c_embedder: [wr | wa | we | 0-pad] per (cfg row b, token i) with the CFG nulling
