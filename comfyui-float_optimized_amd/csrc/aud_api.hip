@@ -293,6 +293,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   const int Lfeat = feature_len(c, n_samples);
   FH_REQUIRE(Lfeat >= 1, "audio too short for the feature extractor (%d samples)", n_samples);
   if (Tn <= 0) Tn = Lfeat;
+  FH_REQUIRE(Tn <= 3900, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit 3900 frames per call)", Tn);
   if ((rc = ensure_workspace(h, n_samples, Tn, st))) return rc;
   // ---- feature extractor
   int L = (n_samples - c.conv_kernel[0]) / c.conv_stride[0] + 1;

@@ -34,7 +34,7 @@ def test_audio_live_oracle_lengths_and_determinism():
     cfg = C.small_audio_config()
     sd = W.synth_audio_state(cfg, seed=21)
     enc = pkg.audio.AudioEncoderHIP(sd, cfg, "cuda:0", "fp16")
-    for seconds, T in ((0.5, 13), (3.1, 78), (1.0, 25)):
+    for seconds, T in ((0.5, 13), (3.1, 78), (12.0, 300), (1.0, 25)):  # 300 frames: more than one row block per GEMM
         a = W.synth_waveform(seconds, seed=int(seconds * 10))
         got = enc.inference(a, T)
         want = O.audio_encoder_inference(sd, cfg, a, T)
