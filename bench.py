@@ -267,6 +267,12 @@ def main():
             conv_roof["traffic"] = pmc["dec_conv"]["hbm_bytes_per_launch"]
         except Exception:
             pass
+        try:  # MFMA pipe utilisation of the two classes from the committed SQ counter pass (tools/make_mfma_json.py)
+            mf = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))
+            gemm_roof["mfma_util_pmc"] = mf["fmt_gemm"]["mfma_util"]
+            conv_roof["mfma_util_pmc"] = mf["dec_conv"]["mfma_util"]
+        except Exception:
+            pass
         roof = (conv_roof, gemm_roof) if conv_total_ms >= gemm_total_ms else (gemm_roof, conv_roof)
         extra["kernel_class_ms"] = {"fmt_gemm": round(gemm_total_ms, 2), "dec_conv": round(conv_total_ms, 2)}
 

@@ -8,5 +8,10 @@ for w in fmt dec; do for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_${c}_$w -o p -- python3 tools/profile_hotpath.py --what $w > $O/pmc_${c}_$w.log 2>&1
   find $O/pmc_${c}_$w -name "*kernel_trace.csv" -delete
 done; done
+for w in fmt dec; do
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_sq_$w -o p -- python3 tools/profile_hotpath.py --what $w > $O/pmc_sq_$w.log 2>&1
+  find $O/pmc_sq_$w -name "*kernel_trace.csv" -delete
+done
+python tools/make_mfma_json.py $O/pmc_sq_fmt,$O/pmc_sq_dec $O/pmc_mfma.json
 python tools/make_traffic_json.py $O/pmc_FETCH_SIZE_fmt,$O/pmc_FETCH_SIZE_dec $O/pmc_WRITE_SIZE_fmt,$O/pmc_WRITE_SIZE_dec $O/pmc_traffic.json
 du -sh $O
