@@ -385,6 +385,23 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
       const int tile = tile0 + item / nchunks;
       const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
       const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+      // per-(frame, channel) epilogue operands once per tile, not once per pixel row (the stores to Y may alias them as
+      // far as the compiler knows, so it re-loaded all three for each of the 4 x NT fragments): v = lrelu(acc*d + b) * (sqrt2*s)
+      float4 ed[NT], eb[NT], es[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int co = n0 + j * 16 + q * 4;
+        ed[j] = g.demod ? *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + co) : float4{1.f, 1.f, 1.f, 1.f};
+        eb[j] = g.act ? *reinterpret_cast<const float4*>(g.bias + co) : float4{0.f, 0.f, 0.f, 0.f};
+        es[j] = g.snext ? *reinterpret_cast<const float4*>(g.snext + (size_t)f * g.lds + co) : float4{1.f, 1.f, 1.f, 1.f};
+        if (g.act) {
+          es[j].x *= 1.4142135623730951f;
+          es[j].y *= 1.4142135623730951f;
+          es[j].z *= 1.4142135623730951f;
+          es[j].w *= 1.4142135623730951f;
+        }
+      }
+      const bool act = g.act != 0;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int m = (w * 4 + mt) * 16 + r16;
@@ -394,33 +411,17 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int co = n0 + j * 16 + q * 4;
-          float v[4] = {acc[mt][j][0], acc[mt][j][1], acc[mt][j][2], acc[mt][j][3]};
-          if (g.demod) {
-            const float4 d = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + co);
-            v[0] *= d.x;
-            v[1] *= d.y;
-            v[2] *= d.z;
-            v[3] *= d.w;
-          }
-          if (g.act) {
-            const float4 bb = *reinterpret_cast<const float4*>(g.bias + co);
-            v[0] = fh_lrelu_s2(v[0] + bb.x);
-            v[1] = fh_lrelu_s2(v[1] + bb.y);
-            v[2] = fh_lrelu_s2(v[2] + bb.z);
-            v[3] = fh_lrelu_s2(v[3] + bb.w);
-          }
-          if (g.snext) {
-            const float4 sn = *reinterpret_cast<const float4*>(g.snext + (size_t)f * g.lds + co);
-            v[0] *= sn.x;
-            v[1] *= sn.y;
-            v[2] *= sn.z;
-            v[3] *= sn.w;
+          float v[4] = {acc[mt][j][0] * ed[j].x + eb[j].x, acc[mt][j][1] * ed[j].y + eb[j].y, acc[mt][j][2] * ed[j].z + eb[j].z,
+                        acc[mt][j][3] * ed[j].w + eb[j].w};
+          if (act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.2f * v[r]);  // leaky_relu(0.2); the sqrt(2) rides in es
           }
           ushort4 o;
-          o.x = T::from_float(v[0]);
-          o.y = T::from_float(v[1]);
-          o.z = T::from_float(v[2]);
-          o.w = T::from_float(v[3]);
+          o.x = T::from_float(v[0] * es[j].x);
+          o.y = T::from_float(v[1] * es[j].y);
+          o.z = T::from_float(v[2] * es[j].z);
+          o.w = T::from_float(v[3] * es[j].w);
           *reinterpret_cast<ushort4*>(yp + co) = o;
         }
       }
@@ -543,6 +544,9 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
     }
   }
   // epilogue: z[f][2m+pu][2n+pv][co] = acc * demod, for the positions that exist (u, v <= R = OH-1)
+  float4 ed[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) ed[j] = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + n0 + j * 16 + q * 4);
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int mpos = ty * 16 + w * 4 + mt, npos = tx * 16 + r16;
@@ -554,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = n0 + j * 16 + q * 4;
-        const float4 d = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + co);
+        const float4 d = ed[j];
         ushort4 o;
         o.x = T::from_float(acc[c][mt][j][0] * d.x);
         o.y = T::from_float(acc[c][mt][j][1] * d.y);
