@@ -339,7 +339,13 @@ int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, in
   const int fblocks = (F + nf - 1) / nf;
   const int npix = nf * g.hh * g.hw;
   FH_REQUIRE(npix * 4 <= 9 * 256, "conv halo tile too large (%d pixels)", npix);
-  const int bn = s.cout >= 64 ? 64 : 32;
+  // Output channels per workgroup.  32 (NT = 2) everywhere: twice the workgroups and 39 KB instead of 58 KB of LDS each beat the
+  // 64-channel tiles' better operand reuse (decode 35.2 -> 33.9 ms); FLOAT_DEC_CONV_BN=64 / FLOAT_DEC_CONV_BN_LO=64 restore them
+  // for the 16x16-tile kernel / the generic low-resolution kernel.
+  static const int bn_hi = getenv("FLOAT_DEC_CONV_BN") ? atoi(getenv("FLOAT_DEC_CONV_BN")) : 32;
+  static const int bn_lo = getenv("FLOAT_DEC_CONV_BN_LO") ? atoi(getenv("FLOAT_DEC_CONV_BN_LO")) : 32;
+  const bool tile16 = tdim == 16;
+  const int bn = (s.cout >= 64 && (tile16 ? bn_hi : bn_lo) == 64) ? 64 : 32;
   FH_REQUIRE(s.cout % bn == 0 && s.cin % 32 == 0, "conv channels (%d -> %d) not tileable", s.cin, s.cout);
   const int ty_taps = dymax - dymin + 1, tx_taps = dxmax - dxmin + 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
