@@ -353,7 +353,8 @@ int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, in
   if (tdim == 16 && ty_taps * tx_taps == ntaps) {
     // dense TY x TX window on 16x16 tiles: compile-time geometry, swizzled LDS, register prefetch
     const int total = g.tiles_x * g.tiles_y * F;
-    g.tpw = total >= 16384 ? 4 : (total >= 4096 ? 2 : 1);
+    static const int tpw_env = getenv("FLOAT_DEC_TPW") ? atoi(getenv("FLOAT_DEC_TPW")) : 0;  // tuning aid
+    g.tpw = tpw_env ? tpw_env : (total >= 16384 ? 4 : (total >= 4096 ? 2 : 1));
     const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64;
     dim3 grid((total + g.tpw - 1) / g.tpw, s.cout / bn);
 #define CONV16(NTv, TYv, TXv)                                                                                    \

@@ -13,6 +13,7 @@ struct Blk {
   Lin qkv, proj, fc1, fc2;
 };
 
+constexpr int kMaxTok = 80;      // tokens per window (n_prev + n_cur): 3-way CFG of 80 tokens = 240 rows, the tallest GEMM tiling
 constexpr int kMaxSteps = 1024;  // FloatAdvancedParameters.nfe max is 1000 (nodes_adv.py:184-190)
 
 }  // namespace
@@ -32,7 +33,7 @@ struct float_fmt {
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
   // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, scales)
   int method = 0;          // FLOAT_ODE_*
-  float* kbuf = nullptr;   // [4][64][dim_w] stage velocities of the Runge-Kutta solvers
+  float* kbuf = nullptr;   // [4][kMaxTok][dim_w] stage velocities of the Runge-Kutta solvers
   struct GraphKey {
     int nfe, bc, we_len, method;
     float a, r, e;
@@ -583,7 +584,7 @@ int run_window_steps_rk(float_fmt* h, const CfgMode& m, int nfe, const std::vect
                         hipStream_t s) {
   const Tableau& tb = tableau(h->method);
   const float_fmt_cfg_t& c = h->cfg;
-  const int kstride = 64 * c.dim_w, n = c.n_cur * c.dim_w;
+  const int kstride = kMaxTok * c.dim_w, n = c.n_cur * c.dim_w;
   const bool hoisted = n_evals(h->method, nfe) <= kScSteps;
   int rc;
   for (int i = 0; i < nfe - 1; ++i) {
@@ -700,6 +701,8 @@ int window_impl(float_fmt* h, const float* x0, const float* wa, const float* wr,
                 const float* prev_x, const float* prev_wa, const float* prev_we, int nfe, const std::vector<float>& ts,
                 float a, float r, float e, int include_r, hipStream_t s) {
   const CfgMode m = cfg_mode(a, r, e, include_r);
+  FH_REQUIRE(m.bc * h->ntok <= 240, "%d-way CFG of %d tokens is %d rows; the CFG epilogue GEMM holds at most 240 (15 row tiles)", m.bc,
+             h->ntok, m.bc * h->ntok);
   int rc = stage_window<T>(h, m, x0, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s);
   if (rc) return rc;
   const int nev = n_evals(h->method, nfe);
@@ -721,6 +724,8 @@ int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const floa
   int rc = prepare_time<T>(h, ts, s);
   if (rc) return rc;
   const CfgMode m = cfg_mode(a, r, e, include_r);
+  FH_REQUIRE(m.bc * h->ntok <= 240, "%d-way CFG of %d tokens is %d rows; the CFG epilogue GEMM holds at most 240 (15 row tiles)", m.bc,
+             h->ntok, m.bc * h->ntok);
   if ((rc = stage_window<T>(h, m, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s))) return rc;
   if ((rc = run_mod<T>(h, m.bc, 0, h->mod, s, false))) return rc;
   if ((rc = run_blocks<T>(h, m.bc, h->mod, false, 0.f, a, r, e, s))) return rc;
@@ -873,7 +878,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
              "dim_h=%d unsupported", cfg->dim_h);
   FH_REQUIRE(cfg->dim_h / cfg->heads == 128, "head_dim must be 128 (dim_h=%d heads=%d)", cfg->dim_h, cfg->heads);
   FH_REQUIRE(cfg->dim_w % 128 == 0 && cfg->mlp_hidden % 128 == 0, "dim_w / mlp_hidden must be multiples of 128");
-  FH_REQUIRE(cfg->n_prev + cfg->n_cur <= 64, "at most 64 tokens per window (got %d)", cfg->n_prev + cfg->n_cur);
+  FH_REQUIRE(cfg->n_prev + cfg->n_cur <= kMaxTok, "at most %d tokens per window (got %d)", kMaxTok, cfg->n_prev + cfg->n_cur);
   FH_REQUIRE(cfg->n_prev >= 0 && cfg->n_prev <= cfg->n_cur, "n_prev must be in [0, n_cur]");
   FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
   float_fmt* h = new float_fmt();
@@ -898,7 +903,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   auto A = [&](auto** p, size_t n) {
     if (!rc) rc = h->pool.alloc(p, n, true);
   };
-  A(&h->pos, (size_t)64 * D);
+  A(&h->pos, (size_t)kMaxTok * D);
   A(&h->freqs, 128);
   A(&h->cond16, (size_t)Mp * h->Kc);
   A(&h->sc16, (size_t)kScSteps * Mp * D);
@@ -906,19 +911,19 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->qkv16, (size_t)Mp * 3 * D);
   A(&h->att16, (size_t)Mp * D);
   A(&h->hid16, (size_t)Mp * cfg->mlp_hidden);
-  A(&h->xin16, (size_t)64 * h->Kx);
+  A(&h->xin16, (size_t)kMaxTok * h->Kx);
   A(&h->tsin16, (size_t)kMaxSteps * 256);
   A(&h->th16, (size_t)kMaxSteps * D);
   A(&h->ccond, (size_t)Mp * D);
   A(&h->mod, (size_t)Mp * h->Ntot);
   A(&h->mod2, (size_t)Mp * h->Ntot);
-  A(&h->kbuf, (size_t)4 * 64 * cfg->dim_w);
+  A(&h->kbuf, (size_t)4 * kMaxTok * cfg->dim_w);
   A(&h->xres, (size_t)Mp * D);
   A(&h->slab, (size_t)4 * Mp * D);
   A(&h->xcur, (size_t)cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
   A(&h->ts_dev, (size_t)kMaxSteps);
-  A(&h->vout, (size_t)64 * cfg->dim_w);
+  A(&h->vout, (size_t)kMaxTok * cfg->dim_w);
   A(&h->wa_c, (size_t)cfg->n_cur * cfg->dim_a);
   A(&h->we_c, (size_t)cfg->n_cur * cfg->dim_e);
   A(&h->x0_c, (size_t)cfg->n_cur * cfg->dim_w);

@@ -10,6 +10,7 @@ from tests.util import load_pkg, rel_l2
 pkg = load_pkg()
 pytestmark = pytest.mark.gpu
 CFG = pkg.config.FmtConfig()
+C, W = pkg.config, pkg.weights
 
 
 @pytest.fixture(scope="module")
@@ -92,3 +93,29 @@ def test_other_fixed_step_solvers(method):
     assert rel_l2(back, eul) < 4e-3
     with pytest.raises(ValueError):
         m.set_method("dopri5")
+
+
+@pytest.mark.parametrize("n_prev,n_cur,window", [(5, 40, 3), (10, 60, 2), (2, 50, 1)])
+def test_other_temporal_structures(n_prev, n_cur, window):
+    """LoadFMTModel lets fps / wav2vec_sec / num_prev_frames / attention_window reshape the model
+    (nodes_vadv_loader.py:791-840): windows of n_cur = int(wav2vec_sec * fps) frames with n_prev of context and a band
+    of +-window keys.  Up to 80 tokens per window (e.g. fps 30: 60 + 10); a 4-way CFG of more than 60 tokens exceeds the
+    240-row CFG epilogue tile and must be refused, not silently truncated."""
+    cfg = C.small_fmt_config()
+    cfg.num_prev_frames, cfg.num_frames_for_clip, cfg.attention_window = n_prev, n_cur, window
+    sd = W.synth_fmt_state(cfg, seed=61)
+    f = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", "fp16")
+    g = torch.Generator().manual_seed(3)
+    r = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    T = n_cur + 7
+    r_s, wa, we = r(1, cfg.dim_w) * 0.5, torch.nn.functional.silu(r(1, T, cfg.dim_a)), torch.softmax(r(1, 1, cfg.dim_e), -1)
+    noise = pkg.fmt.draw_noise(2, 1, cfg, 15)
+    got = f.sample(r_s, wa, we, noise, 4, 2.0, 1.0, 1.0).cpu()
+    want = O.sample_rd(sd, cfg, r_s, wa, we, noise, 4, 2.0, 1.0, 1.0)
+    assert got.shape == (1, T, cfg.dim_w) and rel_l2(got, want) < 4e-3
+    if 4 * (n_prev + n_cur) > 240:
+        with pytest.raises(ValueError):
+            f.sample(r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, include_r_cfg=True)
+    else:
+        got4 = f.sample(r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, include_r_cfg=True).cpu()
+        assert rel_l2(got4, O.sample_rd(sd, cfg, r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, True)) < 4e-3
