@@ -43,6 +43,19 @@ def test_argument_validation_needs_no_gpu():
     assert L.float_fmt_create(C.byref(cfg), arr, 0, C.byref(h)) == 1 and b"dim_h" in L.float_last_error()
     dcfg = N.DecCfg(100, 512, 0, 8)  # size not a power of two
     assert L.float_dec_create(C.byref(dcfg), arr, 0, C.byref(h)) == 1 and b"power of two" in L.float_last_error()
+    ecfg = N.EncCfg(100, 512, 20, 1)  # encoder size not a power of two
+    assert L.float_enc_create(C.byref(ecfg), arr, 0, C.byref(h)) == 1 and b"power of two" in L.float_last_error()
+    assert L.float_enc_forward(None, None, None, None, None, None, 0, None) == 1
+    acfg = N.AudCfg()
+    acfg.n_conv = 1  # a one-layer feature extractor is not a wav2vec2
+    assert L.float_aud_create(C.byref(acfg), arr, 0, C.byref(h)) == 1 and b"n_conv" in L.float_last_error()
+    acfg.n_conv = 7
+    for i in range(7):
+        acfg.conv_dim[i], acfg.conv_kernel[i], acfg.conv_stride[i] = 512, 3, 2
+    acfg.hidden, acfg.heads = 768, 8  # head dim 96
+    assert L.float_aud_create(C.byref(acfg), arr, 0, C.byref(h)) == 1 and b"head dim" in L.float_last_error()
+    assert L.float_aud_inference(None, None, 0, 0, None, None) == 1 and L.float_aud_classify(None, None, 0, None, None) == 1
+    assert L.float_dec_direction(None, None, None, None) == 1 and L.float_dec_set_feats16(None, None, 0, 0, None) == 1
     assert L.float_fmt_sample_next(None, None, None, None) == 1
     try:
         N.check(1)
