@@ -1,4 +1,5 @@
-"""CPU oracle for the FLOAT hot path (FMT Euler sampling loop + Synthesis decoder).
+"""CPU oracle for the FLOAT hot path (FMT Euler sampling loop + Synthesis decoder) and the rows it was widened into
+(appearance encoder, wav2vec2 audio conditioning, speech-emotion recogniser: SURVEY.md section 8f).
 
 TEST INFRASTRUCTURE ONLY.  Imported by tests/, __graft_entry__.smoke() and bench.py's
 `cpu_baseline` leg as the checker / baseline.  The product package never imports it and
@@ -17,6 +18,10 @@ Third-party arithmetic that is not in /root/reference:
     is unpinned (the package is absent); the stand-in used to make the goldens implements
     the same published rule.
   * timm>=1.0.9 Mlp = Linear -> GELU(tanh) -> Linear (FMT.py:160-162); unpinned likewise.
+  * transformers>=4 (requirements.txt:8; 5.15.0 where the goldens were made) - the wav2vec2 modules under the reference's
+    Wav2VecModel / Wav2Vec2ForSpeechClassification.  Restated from the package's module definitions and PINNED through
+    the reference's own AudioEncoder, which instantiates that package (aud_*.npz, 4e-6), and, for the speech-emotion
+    model, through transformers' Wav2Vec2Model + the reference's Wav2Vec2ClassificationHead (emo_*.npz, 1e-7).
 """
 import math
 
