@@ -269,7 +269,7 @@ int create_impl(float_dec* h, const TensorTable& tt) {
   if ((rc = h->pool.alloc(&h->hiA, FH * act_hi, true))) return rc;
   if ((rc = h->pool.alloc(&h->hiB, FH * act_hi, true))) return rc;
   if ((rc = h->pool.alloc(&h->hiZ, FH * act_hi, true))) return rc;
-  const size_t sk_lo = FL * 32 * 32 * 3, sk_hi = FH * (size_t)size * size * 3;
+  const size_t sk_lo = FL * 32 * 32 * 4, sk_hi = FH * (size_t)size * size * 4;  // flow / rgb pyramids: 4 floats per pixel
   for (int i = 0; i < 2; ++i) {
     if ((rc = h->pool.alloc(&h->loFlow[i], sk_lo, true))) return rc;
     if ((rc = h->pool.alloc(&h->loRgb[i], sk_lo, true))) return rc;
@@ -521,8 +521,8 @@ int run_high(float_dec* h, int n, int off, const float* styles, const float* dem
   if (l0 > 0) {
     const Level& P = h->levels[l0 - 1];
     x_in = h->loX + (size_t)off * P.R * P.R * P.C;
-    fp = h->loFlow[skip_idx] + (size_t)off * P.R * P.R * 3;
-    rp = h->loRgb[skip_idx] + (size_t)off * P.R * P.R * 3;
+    fp = h->loFlow[skip_idx] + (size_t)off * P.R * P.R * 4;
+    rp = h->loRgb[skip_idx] + (size_t)off * P.R * P.R * 4;
   } else {
     x_in = h->loX + (size_t)off * 16 * h->convs[0].cout;
   }

@@ -668,8 +668,8 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
 struct FlowArgs {
   const u16* x;        // [F][R][R][C] conv2 output (unscaled)
   const u16* feat;     // [R][R][C]
-  const float* pflow;  // [F][R/2][R/2][3] or nullptr
-  const float* prgb;   // [F][R/2][R/2][3] or nullptr
+  const float* pflow;  // [F][R/2][R/2][4] (3 channels + pad: one 16-byte load per tap) or nullptr
+  const float* prgb;   // [F][R/2][R/2][4] or nullptr
   const float* wflow;  // [3][C], already * 1/sqrt(C)
   const float* sflow;  // [F][ld_s] style of the ToFlow conv (offset applied)
   const float* bflow;  // [3]
@@ -678,8 +678,8 @@ struct FlowArgs {
   const float* b2;     // [3] ToRGB bias
   const float* snext;  // [F][ld_s] or nullptr
   u16* xnext;          // [F][R][R][C] or nullptr (last level)
-  float* flow_out;     // [F][R][R][3]
-  float* rgb_out;      // [F][R][R][3]
+  float* flow_out;     // [F][R][R][4]
+  float* rgb_out;      // [F][R][R][4]
   const float* lin;    // [R] identity grid: np.linspace(-1, 1, R) (float64) cast to float32
   float* final_out;    // last level: frames
   int final_mode;      // 0: none, 1: HWC clamp(-1,1)*0.5+0.5 (FLOAT.py:149-152), 2: raw CHW
@@ -688,27 +688,33 @@ struct FlowArgs {
   int nbands, band_pix;  // the image is cut into nbands runs of band_pix consecutive pixels (multiple of gpb*PIX)
 };
 
-__device__ __forceinline__ float up2_tap(const float* __restrict__ prev, int f, int Rp, int Y, int X, int j) {
+__device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, int Rp, int Y, int X, float out[3]) {
   // Upsample([1,3,3,1]) of a 3-channel map (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR
-  // gain 4 -> per axis: even 2m: .25*p[m-1] + .75*p[m];  odd 2m+1: .75*p[m] + .25*p[m+1]
+  // gain 4 -> per axis: even 2m: .25*p[m-1] + .75*p[m];  odd 2m+1: .75*p[m] + .25*p[m+1].
+  // The map is stored with 4 floats per pixel, so a tap is ONE 16-byte load for all three channels (the 4-byte-per-lane
+  // version issued 32 scattered load instructions per 4 pixels and cost 5 of the decoder's 34 ms).
   const int my = Y >> 1, mx = X >> 1;
   const int y0 = (Y & 1) ? my : my - 1, x0 = (X & 1) ? mx : mx - 1;
   const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
-  float acc = 0.f;
+  float4 t[4];
 #pragma unroll
-  for (int a = 0; a < 2; ++a) {
-    const int yy = y0 + a;
-    if (yy < 0 || yy >= Rp) continue;
-    const float wy = a ? (1.f - wy0) : wy0;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const int xx = x0 + b;
-      if (xx < 0 || xx >= Rp) continue;
-      const float wx = b ? (1.f - wx0) : wx0;
-      acc += wy * wx * prev[((size_t)(f * Rp + yy) * Rp + xx) * 3 + j];
+      const int yy = y0 + a, xx = x0 + b;
+      const bool in = yy >= 0 && yy < Rp && xx >= 0 && xx < Rp;
+      t[a * 2 + b] = in ? *reinterpret_cast<const float4*>(prev + ((size_t)(f * Rp + yy) * Rp + xx) * 4) : float4{0.f, 0.f, 0.f, 0.f};
     }
-  }
-  return acc;
+  out[0] = out[1] = out[2] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float wgt = (a ? 1.f - wy0 : wy0) * (b ? 1.f - wx0 : wx0);
+      out[0] += wgt * t[a * 2 + b].x;
+      out[1] += wgt * t[a * 2 + b].y;
+      out[2] += wgt * t[a * 2 + b].z;
+    }
 }
 
 __device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x}); saturates cleanly at +-1
@@ -754,10 +760,11 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     sw[6 * C + c] = g.snext ? g.snext[(size_t)f * g.ld_s + c] : 0.f;
   }
   __syncthreads();
-  // lane `sub` < 3 owns output channel `sub` of the 3-channel maps (bias, pyramid taps, stores)
-  const int jch = sub < 3 ? sub : 0;
-  const float bfl = sub < 3 ? g.bflow[jch] : 0.f;
-  const float b1 = g.b1[jch], b2 = g.b2[jch];
+  // lane `sub` < PIX owns PIXEL `sub` of the iteration's run for the 3-channel maps (bias, pyramid taps, stores); C >= 32
+  // means at least 4 lanes per pixel group, so every pixel of the run has an owner
+  const bool owner = sub < PIX;
+  const float bf0 = g.bflow[0], bf1 = g.bflow[1], bf2 = g.bflow[2];
+  const float b10 = g.b1[0], b11 = g.b1[1], b12 = g.b1[2], b20 = g.b2[0], b21 = g.b2[1], b22 = g.b2[2];
   const int R = g.R, npix = R * R, Rp = R >> 1;
   const float fR = (float)R;
   const int pend = min(npix, (band + 1) * g.band_pix);
@@ -767,9 +774,8 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     uint4 xu[PIX];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) xu[k] = *reinterpret_cast<const uint4*>(g.x + (po0 + k) * C + c0);
-    float upf[PIX];
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) upf[k] = (g.pflow && sub < 3) ? up2_tap(g.pflow, f, Rp, Y, X0 + k, jch) : 0.f;
+    float upf[3] = {0.f, 0.f, 0.f};  // up-sampled previous flow of THIS lane's pixel
+    if (g.pflow && owner) up2_tap3(g.pflow, f, Rp, Y, X0 + sub, upf);
     const float gy = g.lin[Y];
     float o[PIX][3];
 #pragma unroll
@@ -790,11 +796,11 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     }
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
-      // bias + up-sampled previous flow enter the sum once, in the lane that owns the channel
-      const float add = upf[k] + bfl;
-      o[k][0] += sub == 0 ? add : 0.f;
-      o[k][1] += sub == 1 ? add : 0.f;
-      o[k][2] += sub == 2 ? add : 0.f;
+      // bias + up-sampled previous flow enter the sum once, in the lane that owns the pixel
+      const bool mine = sub == k;
+      o[k][0] += mine ? upf[0] + bf0 : 0.f;
+      o[k][1] += mine ? upf[1] + bf1 : 0.f;
+      o[k][2] += mine ? upf[2] + bf2 : 0.f;
     }
     for (int d = 1; d < lpp; d <<= 1) {
 #pragma unroll
@@ -825,9 +831,8 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
           fu[k][a * 2 + b] = in ? *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * C + c0) : uint4{0u, 0u, 0u, 0u};
         }
     }
-    float upr[PIX];
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) upr[k] = (g.prgb && sub < 3) ? up2_tap(g.prgb, f, Rp, Y, X0 + k, jch) : 0.f;
+    float upr[3] = {0.f, 0.f, 0.f};
+    if (g.prgb && owner) up2_tap3(g.prgb, f, Rp, Y, X0 + sub, upr);
     float rgb[PIX][3];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
@@ -870,19 +875,36 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
         rgb[k][2] += __shfl_xor(rgb[k][2], d, 64);
       }
     }
-    if (sub < 3) {
+    if (owner) {
+      // this lane's pixel: select its sums out of the unrolled arrays
+      float r0 = rgb[0][0], r1 = rgb[0][1], r2 = rgb[0][2], f0 = o[0][0], f1 = o[0][1], f2 = o[0][2];
 #pragma unroll
-      for (int k = 0; k < PIX; ++k) {
-        const float rs = sub == 0 ? rgb[k][0] : (sub == 1 ? rgb[k][1] : rgb[k][2]);
-        const float os = sub == 0 ? o[k][0] : (sub == 1 ? o[k][1] : o[k][2]);
-        const float v = fh_lrelu_s2(rs + b1) + b2 + upr[k];
-        const size_t po = po0 + k;
-        if (g.write_pyr) {  // the pyramids are only read by the next level
-          g.flow_out[po * 3 + sub] = os;
-          g.rgb_out[po * 3 + sub] = v;
+      for (int k = 1; k < PIX; ++k)
+        if (sub == k) {
+          r0 = rgb[k][0];
+          r1 = rgb[k][1];
+          r2 = rgb[k][2];
+          f0 = o[k][0];
+          f1 = o[k][1];
+          f2 = o[k][2];
         }
-        if (g.final_mode == 1) g.final_out[po * 3 + sub] = fminf(fmaxf(v, -1.f), 1.f) * 0.5f + 0.5f;
-        else if (g.final_mode == 2) g.final_out[((size_t)f * 3 + sub) * npix + p0 + k] = v;
+      const float v0 = fh_lrelu_s2(r0 + b10) + b20 + upr[0], v1 = fh_lrelu_s2(r1 + b11) + b21 + upr[1],
+                  v2 = fh_lrelu_s2(r2 + b12) + b22 + upr[2];
+      const size_t po = po0 + sub;
+      if (g.write_pyr) {  // the pyramids are only read by the next level
+        *reinterpret_cast<float4*>(g.flow_out + po * 4) = float4{f0, f1, f2, 0.f};
+        *reinterpret_cast<float4*>(g.rgb_out + po * 4) = float4{v0, v1, v2, 0.f};
+      }
+      if (g.final_mode == 1) {
+        float* fo = g.final_out + po * 3;
+        fo[0] = fminf(fmaxf(v0, -1.f), 1.f) * 0.5f + 0.5f;
+        fo[1] = fminf(fmaxf(v1, -1.f), 1.f) * 0.5f + 0.5f;
+        fo[2] = fminf(fmaxf(v2, -1.f), 1.f) * 0.5f + 0.5f;
+      } else if (g.final_mode == 2) {
+        float* fo = g.final_out + (size_t)f * 3 * npix + p0 + sub;
+        fo[0] = v0;
+        fo[npix] = v1;
+        fo[2 * (size_t)npix] = v2;
       }
     }
   }
