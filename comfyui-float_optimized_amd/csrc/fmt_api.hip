@@ -321,7 +321,8 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   const int nv = h->D / 256;
   // one row (wave) per workgroup: 180 single-wave workgroups spread over 180 CUs (4 rows per workgroup: +0.4 %)
   static const int rpw = getenv("FLOAT_FMT_LN_ROWS") ? std::max(1, std::min(4, atoi(getenv("FLOAT_FMT_LN_ROWS")))) : 1;
-  dim3 grid((M + rpw - 1) / rpw), block(64 * rpw);
+  // rpw == 1: the kernel maps ids to rows in groups of 8 rows per XCD -> 64 row slots per group of 64 ids
+  dim3 grid(rpw == 1 ? ((M + 63) / 64) * 64 : (M + rpw - 1) / rpw), block(64 * rpw);
   const int ks = pend ? pend->ks : 0;
   LnRed red{};
   if (ks) red = pend->red;
