@@ -316,8 +316,49 @@ int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
   return launch_gemm<T, EPI_PARTIAL>(g, t.mtw, t.nt, t.nw, false, s);
 }
 
+// Touch descriptor for the weights of GEMM `L` as it will be launched for M rows (ksplit = 0: plain GEMM, else EPI_PARTIAL
+// with that many K slices), to be executed by `lanes` threads per XCD with at most `per_lane` lines each; W = nullptr when the
+// GEMM's block decode is not the XCD-affine one or the lanes cannot cover it.
+// FLOAT_FMT_TOUCH bit mask - who pulls whose weights: 1 LayerNorm -> qkv / fc1, 2 attention -> proj, 4 fc1 -> fc2, 8 qkv -> proj,
+// 16 proj -> fc1, 32 fc2 -> the next block's qkv.  Default 2 + 4 + 32 (r01, ms per 250 evaluations, same box: none 90.8,
+// 2+4 87.6, 4+32 86.0-86.7, 2+4+32 85.2; every way of touching fc1's weights - from LayerNorm, proj or qkv - made it slower).
+int g_fmt_touch = 38;
+TouchSpec make_touch(const Lin& L, int M, int ksplit, unsigned lanes, unsigned per_lane) {
+  TouchSpec t{};
+  Tiling tl = ksplit ? pick_tiling(M, L.N * ksplit, L.K / ksplit, false) : pick_tiling(M, L.N, L.K, false);
+  if (ksplit)
+    while (tl.nt > 1 && L.N % (tl.nt * 16)) tl.nt >>= 1;
+  const int ks = ksplit ? ksplit : 1;
+  if (L.N % (tl.nt * 16) || L.K % (32 * ks) || 8 % ks) return t;
+  const int nbn = L.N / (tl.nt * 16);
+  if ((nbn * ks) % 8) return t;
+  auto lg = [](unsigned v) {  // log2 of a power of two, else -1
+    int n = 0;
+    while ((1u << n) < v) ++n;
+    return (1u << n) == v ? n : -1;
+  };
+  const unsigned P = 8 / ks, run_lines = (unsigned)(L.K / 32 / ks) * 8u;
+  if (lg(run_lines) < 0 || lg((unsigned)tl.nt) < 0) return t;
+  t.run_shift = (unsigned)lg(run_lines);
+  t.nt_shift = (unsigned)lg((unsigned)tl.nt);
+  t.p_shift = (unsigned)lg(P);
+  t.tile_bytes = (unsigned)(L.K / 32) * 1024u;
+  t.total = ((unsigned)nbn / P) * (unsigned)tl.nt * run_lines;
+  if ((size_t)t.total > (size_t)lanes * per_lane) return t;
+  t.W = reinterpret_cast<const char*>(L.W);
+  return t;
+}
+
+// threads per XCD of the launch run_gemm makes for a plain (M, N, K) GEMM
+unsigned gemm_lanes_per_xcd(int M, int N, int K) {
+  const Tiling t = pick_tiling(M, N, K, false);
+  const int mblk = ((M + 15) / 16 + t.mtw - 1) / t.mtw;
+  return (unsigned)((N / (t.nt * 16)) * mblk / 8) * (unsigned)(t.nw * 64);
+}
+
 template <class T>
-int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s, PendingRed* pend = nullptr) {
+int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s, PendingRed* pend = nullptr,
+                 const Lin* next = nullptr) {
   const int nv = h->D / 256;
   // one row (wave) per workgroup: 180 single-wave workgroups spread over 180 CUs (4 rows per workgroup: +0.4 %)
   static const int rpw = getenv("FLOAT_FMT_LN_ROWS") ? std::max(1, std::min(4, atoi(getenv("FLOAT_FMT_LN_ROWS")))) : 1;
@@ -326,8 +367,13 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   const int ks = pend ? pend->ks : 0;
   LnRed red{};
   if (ks) red = pend->red;
-#define LN_LAUNCH(NV, KS) \
-  hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red)
+  TouchSpec pf{};
+  if (next && (g_fmt_touch & 1) && rpw == 1) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
+#define LN_LAUNCH(NV, KS)                                                                                                          \
+  do {                                                                                                                             \
+    if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red, pf); \
+    else hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red, pf);   \
+  } while (0)
 #define LN_CASE(NV)                     \
   case NV:                              \
     if (ks == 0) LN_LAUNCH(NV, 0);      \
@@ -394,11 +440,12 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
   for (int b = 0; b < c.depth; ++b) {
     const float* mod = modbuf + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, &B.qkv))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.qkv, M);
       g.out16 = h->qkv16;
       g.ldo16 = 3 * D;
+      if ((g_fmt_touch & 8) && !split_ok(g_fmt_proj_split, B.proj)) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       if ((rc = run_gemm<T, EPI_T16>(g, s))) return rc;
     }
     {
@@ -411,11 +458,19 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
         return true;
       }();
       (void)parsed;
-      dim3 grid(bc * c.heads, (ntok + qpw - 1) / qpw), block(qpw * lpq);
-      if (lpq == 16)
-        hipLaunchKernelGGL((fmt_attn_kernel<T, 16>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, c.heads, D, c.attn_window);
-      else
-        hipLaunchKernelGGL((fmt_attn_kernel<T, 8>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, c.heads, D, c.attn_window);
+      dim3 grid(c.heads, (M + qpw - 1) / qpw), block(qpw * lpq);
+      TouchSpec pf{};
+      if ((g_fmt_touch & 2) && !split_ok(g_fmt_proj_split, B.proj)) pf = make_touch(B.proj, M, 0, (grid.x * grid.y / 8) * block.x, 2);
+#define ATTN_LAUNCH(LPQ, TCH) \
+  hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf)
+      if (lpq == 16) {
+        if (pf.W) ATTN_LAUNCH(16, true);
+        else ATTN_LAUNCH(16, false);
+      } else {
+        if (pf.W) ATTN_LAUNCH(8, true);
+        else ATTN_LAUNCH(8, false);
+      }
+#undef ATTN_LAUNCH
     }
     if (split_ok(g_fmt_proj_split, B.proj)) {
       if ((rc = run_gemm_partial<T>(h, base_args(h->att16, B.proj, M), g_fmt_proj_split, s))) return rc;
@@ -427,17 +482,23 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
       g.ldo = D;
       g.gate = mod + 2 * D;
       g.ldg = h->Ntot;
+      if (g_fmt_touch & 16) g.touch = make_touch(B.fc1, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       if ((rc = run_gemm<T, EPI_GATE_RES>(g, s))) return rc;
     }
-    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, &B.fc1))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.fc1, M);
       g.out16 = h->hid16;
       g.ldo16 = B.fc2.K / 32;  // packed for fc2
+      if (g_fmt_touch & 4)
+        g.touch = make_touch(B.fc2, M, split_ok(g_fmt_fc2_split, B.fc2) ? g_fmt_fc2_split : 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       if ((rc = run_gemm<T, EPI_GELU_P16>(g, s))) return rc;
     }
     if (split_ok(g_fmt_fc2_split, B.fc2)) {
-      if ((rc = run_gemm_partial<T>(h, base_args(h->hid16, B.fc2, M), g_fmt_fc2_split, s))) return rc;
+      GemmArgs g = base_args(h->hid16, B.fc2, M);
+      if ((g_fmt_touch & 32) && b + 1 < c.depth)
+        g.touch = make_touch(h->blk[b + 1].qkv, M, 0, gemm_lanes_per_xcd(M, g.N * g_fmt_fc2_split, g.K / g_fmt_fc2_split), 2);
+      if ((rc = run_gemm_partial<T>(h, g, g_fmt_fc2_split, s))) return rc;
       pend.ks = g_fmt_fc2_split;
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.fc2.b, mod + 5 * D};
     } else {
@@ -891,6 +952,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   h->Kx = round_up(cfg->dim_w, 128);
   if (const char* wd = getenv("FLOAT_FMT_WIDE")) g_fmt_wide = atoi(wd) != 0;
   if (const char* v = getenv("FLOAT_FMT_FC2_SPLIT")) g_fmt_fc2_split = atoi(v);
+  if (const char* v = getenv("FLOAT_FMT_TOUCH")) g_fmt_touch = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_FULL_NW")) g_fmt_full_nw = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);

@@ -98,6 +98,12 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
       for (int i = 0; i < MTW; ++i) a[p][i] = *reinterpret_cast<const u32x4*>(Ap + i * tstride + (size_t)p * 512);
     }
   }
+  // only the epilogue kinds whose launches are given a TouchSpec carry the code (2 registers, a branch)
+  constexpr bool kTouch = (EPI == EPI_GELU_P16 || EPI == EPI_T16 || EPI == EPI_GATE_RES || EPI == EPI_PARTIAL);
+  unsigned touched[2] = {0u, 0u};
+  if constexpr (kTouch) {
+    if (g.touch.W) fmt_touch(g.touch, blockIdx.x & 7, (blockIdx.x >> 3) * NTHR + threadIdx.x, (gridDim.x >> 3) * NTHR, touched);
+  }
   for (int kb0 = 0; kb0 < KBw; kb0 += PF) {
 #pragma unroll
     for (int p = 0; p < PF; ++p) {
@@ -118,6 +124,9 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
     }
   }
 
+  if constexpr (kTouch) {
+    if (g.touch.W) fmt_touch_retire(touched);
+  }
   // C/D map of mfma_f32_16x16x32: col = lane & 15, row = (lane >> 4) * 4 + reg
   float* my = red + w * (ROWS * BN);
 #pragma unroll
@@ -371,13 +380,18 @@ struct LnRed {
   const float* gate;   // row stride ldm (a column block of the modulation matrix)
 };
 
-template <class T, int NV, int KS>
+constexpr int kLnTouch = 6;  // lines per lane: 192 single-wave workgroups cover 8 XCDs x 1 MB (fc1) with 6
+
+template <class T, int NV, int KS, bool TOUCH>
 __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, int M, const float* __restrict__ shift,
                                                         const float* __restrict__ scale, int ldm, u16* __restrict__ out,
-                                                        LnRed red) {
+                                                        LnRed red, TouchSpec pf) {
   constexpr int D = NV * 256;
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  unsigned touched[kLnTouch] = {};
+  const unsigned tfirst = (blockIdx.x >> 3) * 64 + lane, tstride = (gridDim.x >> 3) * 64;
+  const bool touch = TOUCH && blockDim.x == 64;
   if (blockDim.x == 64) {
     // One row per workgroup: a 128-byte line of the packed output holds the 16-byte pieces of 8 consecutive rows, so give
     // those 8 rows to workgroups of ONE XCD (ids congruent mod 8 share an XCD's L2, where the pieces merge into full lines
@@ -385,7 +399,13 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
     const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
     row = (((j >> 3) * 8 + x) << 3) + (j & 7);
   }
-  if (row >= M) return;
+  if (row >= M) {
+    if (touch) {
+      fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);
+      fmt_touch_retire(touched);
+    }
+    return;
+  }
   float* xr = x + (size_t)row * D;
   const float* sh = shift + (size_t)row * ldm;
   const float* sc = scale + (size_t)row * ldm;
@@ -398,6 +418,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
     a[i] = *reinterpret_cast<const float4*>(sh + c);
     b[i] = *reinterpret_cast<const float4*>(sc + c);
   }
+  if (touch) fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);  // behind the row's own loads
   if constexpr (KS > 0) {
     float4 p[KS][NV], gt[NV], bi[NV];
 #pragma unroll
@@ -445,6 +466,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
     o.w = T::from_float((v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w);
     *reinterpret_cast<ushort4*>(out + fmt_pack_off(row, c, D / 32)) = o;
   }
+  if (touch) fmt_touch_retire(touched);
 }
 
 // Banded attention (FMT.py:71-88 with the mask of FMT.py:15-19): query i sees keys |i-j| <= window.
@@ -454,13 +476,24 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 // per query this is 0.3 % of the evaluation's flops - MFMA/LDS tiling would only add latency - so q/k/v come straight from
 // L2.  For window <= 2 every load of the query's band is issued before the first use (one memory round trip); wider
 // windows loop.  Output is written in the packed A-operand order of the proj GEMM (K = D).
-template <class T, int LPQ>
+template <class T, int LPQ, bool TOUCH>
 __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ntok,
-                                                       int heads, int D, int window) {
+                                                       int M, int D, int window, TouchSpec pf) {
   constexpr int HD = 128, PD = HD / LPQ, NU = PD / 8;
-  const int b = blockIdx.x / heads, h = blockIdx.x % heads;
-  const int qi = blockIdx.y * (blockDim.x / LPQ) + threadIdx.x / LPQ, part = threadIdx.x % LPQ;
-  if (qi >= ntok) return;  // whole LPQ-lane groups leave together
+  // blockIdx.x = head, blockIdx.y = run of blockDim.x / LPQ consecutive ROWS of the (cfg rows x tokens) batch: with 8 rows per
+  // workgroup the run is one 8-row group of the packed output, whose 128-byte lines then come whole from a single wave
+  const int h = blockIdx.x;
+  const int row_ = blockIdx.y * (blockDim.x / LPQ) + threadIdx.x / LPQ, part = threadIdx.x % LPQ;
+  unsigned touched[2] = {0u, 0u};
+  if constexpr (TOUCH) {
+    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
+    fmt_touch(pf, lin & 7, (lin >> 3) * blockDim.x + threadIdx.x, (nwg >> 3) * blockDim.x, touched);
+  }
+  if (row_ >= M) {  // whole LPQ-lane groups leave together
+    if constexpr (TOUCH) fmt_touch_retire(touched);
+    return;
+  }
+  const int b = row_ / ntok, qi = row_ - b * ntok;
   const int d0 = h * HD + part * PD;
   const float scale = rsqrtf((float)HD);
   const u16* base = qkv + (size_t)(b * ntok) * ld + d0;
@@ -538,6 +571,7 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
     for (int j = 0; j < 8; ++j) e[j] = T::from_float(o[u * 8 + j] * inv);
     *reinterpret_cast<uint4*>(out + fmt_pack_off(row, d0 + u * 8, D / 32)) = uo;
   }
+  if constexpr (TOUCH) fmt_touch_retire(touched);
 }
 
 // Condition rows for c_embedder: [wr | wa | we | 0-pad] per (cfg row b, token i) with the CFG nulling

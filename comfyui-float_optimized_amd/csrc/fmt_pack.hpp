@@ -21,6 +21,43 @@ __host__ __device__ __forceinline__ size_t fmt_pack_off(int row, int k, int KB) 
   return ((size_t)((row >> 4) * KB + (k >> 5)) * 64 + (row & 15) + 16 * ((k >> 3) & 3)) * 8 + (k & 7);
 }
 
+// Weights of a LATER GEMM of the chain, touched one dword per 128-byte line by the workgroups of a kernel that runs
+// before it, so that the GEMM finds them in its XCD's L2 (clean L2 lines survive a kernel boundary; r01: LayerNorm touching
+// qkv / fc1 took the chain from 91.3 to 88.4 ms).  Mirrors fmt_gemm_kernel's block decode: column block bx (nt 16-column
+// tiles) of K slice ks runs on XCD (bx % P) + ks * P with P = 8 / ksplit; a tile's K slice is one contiguous run.
+struct TouchSpec {
+  const char* W;         // nullptr: nothing to touch
+  unsigned run_shift;    // log2 of the 128-byte lines of one run (one 16-column tile's K slice)
+  unsigned nt_shift;     // log2 of the 16-column tiles per column block
+  unsigned p_shift;      // log2 of P
+  unsigned tile_bytes;   // bytes of one 16-column tile over all of K
+  unsigned total;        // lines per XCD = column blocks per XCD * tiles * run lines
+};
+
+// line l (of t.total) of XCD xcd's share; every size is a power of two, so this is shifts and masks
+__device__ __forceinline__ unsigned fmt_touch_line(const TouchSpec& t, unsigned xcd, unsigned l) {
+  if (l >= t.total) return 0u;
+  const unsigned r = l >> t.run_shift, off = l & ((1u << t.run_shift) - 1u);
+  const unsigned cb = r >> t.nt_shift, jn = r & ((1u << t.nt_shift) - 1u);
+  const unsigned ks = xcd >> t.p_shift, bx = (cb << t.p_shift) + (xcd & ((1u << t.p_shift) - 1u));
+  return *reinterpret_cast<const unsigned*>(t.W + (size_t)((bx << t.nt_shift) + jn) * t.tile_bytes +
+                                            ((size_t)((ks << t.run_shift) + off) << 7));
+}
+// `n` lines per lane, lanes of the XCD's workgroups interleaved; the dwords must stay live until fmt_touch_retire
+template <int N>
+__device__ __forceinline__ void fmt_touch(const TouchSpec& t, unsigned xcd, unsigned first, unsigned stride, unsigned (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = fmt_touch_line(t, xcd, first + (unsigned)i * stride);
+}
+// keeps the touched dwords' registers reserved until the loads have landed, at no other cost
+template <int N>
+__device__ __forceinline__ void fmt_touch_retire(const unsigned (&v)[N]) {
+  unsigned o = 0u;
+#pragma unroll
+  for (int i = 0; i < N; ++i) o |= v[i];
+  asm volatile("" ::"v"(o));
+}
+
 struct GemmArgs {
   const u16* A;   // packed [row tiles][KB][64][8]; pad rows/columns are zero
   const u16* W;   // packed [N/16][KB][64][8]
@@ -44,5 +81,6 @@ struct GemmArgs {
   // EPI_PARTIAL: K is cut into ksplit slices, one per workgroup; slice ks writes out_f32 + ks * slab_stride
   int ksplit;
   size_t slab_stride;
+  TouchSpec touch;  // weights of a later GEMM to pull into L2 (W == nullptr: none)
 };
 
