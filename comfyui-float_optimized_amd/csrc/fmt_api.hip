@@ -27,7 +27,7 @@ struct float_fmt {
   float* pos = nullptr;
   float* freqs = nullptr;
   // workspace
-  u16 *cond16, *sc16, *h16, *qkv16, *att16, *hid16, *xin16, *tsin16, *th16;
+  u16 *cond16, *sc16, *h16, *hfin16, *qkv16, *att16, *hid16, *xin16, *tsin16, *th16;
   float *ccond, *mod, *xres, *xcur, *temb, *ts_dev, *vout;
   float* slab = nullptr;  // [4][Mpad][D] split-K partial sums (EPI_PARTIAL)
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
@@ -323,9 +323,10 @@ int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
 // 16 proj -> fc1, 32 fc2 -> the next block's qkv.  Default 2 + 4 + 32 (r01, ms per 250 evaluations, same box: none 90.8,
 // 2+4 87.6, 4+32 86.0-86.7, 2+4+32 85.2; every way of touching fc1's weights - from LayerNorm, proj or qkv - made it slower).
 int g_fmt_touch = 38;
-TouchSpec make_touch(const Lin& L, int M, int ksplit, unsigned lanes, unsigned per_lane) {
+TouchSpec make_touch(const Lin& L, int M, int ksplit, unsigned lanes, unsigned per_lane, int force_nt = 0) {
   TouchSpec t{};
   Tiling tl = ksplit ? pick_tiling(M, L.N * ksplit, L.K / ksplit, false) : pick_tiling(M, L.N, L.K, false);
+  if (force_nt) tl.nt = force_nt;
   if (ksplit)
     while (tl.nt > 1 && L.N % (tl.nt * 16)) tl.nt >>= 1;
   const int ks = ksplit ? ksplit : 1;
@@ -358,7 +359,7 @@ unsigned gemm_lanes_per_xcd(int M, int N, int K) {
 
 template <class T>
 int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s, PendingRed* pend = nullptr,
-                 const Lin* next = nullptr) {
+                 const Lin* next = nullptr, u16* out = nullptr, int perm = 0) {
   const int nv = h->D / 256;
   // one row (wave) per workgroup: 180 single-wave workgroups spread over 180 CUs (4 rows per workgroup: +0.4 %)
   static const int rpw = getenv("FLOAT_FMT_LN_ROWS") ? std::max(1, std::min(4, atoi(getenv("FLOAT_FMT_LN_ROWS")))) : 1;
@@ -371,8 +372,8 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   if (next && (g_fmt_touch & 1) && rpw == 1) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
 #define LN_LAUNCH(NV, KS)                                                                                                          \
   do {                                                                                                                             \
-    if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red, pf); \
-    else hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, h->h16, red, pf);   \
+    if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
+    else hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm);   \
   } while (0)
 #define LN_CASE(NV)                     \
   case NV:                              \
@@ -496,8 +497,11 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
     }
     if (split_ok(g_fmt_fc2_split, B.fc2)) {
       GemmArgs g = base_args(h->hid16, B.fc2, M);
-      if ((g_fmt_touch & 32) && b + 1 < c.depth)
-        g.touch = make_touch(h->blk[b + 1].qkv, M, 0, gemm_lanes_per_xcd(M, g.N * g_fmt_fc2_split, g.K / g_fmt_fc2_split), 2);
+      if (g_fmt_touch & 32) {
+        const unsigned lanes = gemm_lanes_per_xcd(M, g.N * g_fmt_fc2_split, g.K / g_fmt_fc2_split);
+        if (b + 1 < c.depth) g.touch = make_touch(h->blk[b + 1].qkv, M, 0, lanes, 2);
+        else g.touch = make_touch(h->final_lin, M, 0, lanes, 2, 1);  // the head GEMM runs 16-column workgroups
+      }
       if ((rc = run_gemm_partial<T>(h, g, g_fmt_fc2_split, s))) return rc;
       pend.ks = g_fmt_fc2_split;
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.fc2.b, mod + 5 * D};
@@ -512,8 +516,14 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
   }
   {
     const float* mod = modbuf + (size_t)c.depth * 6 * D;  // shift, scale (FMT.py:196)
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend))) return rc;
-    GemmArgs g = base_args(h->h16, h->final_lin, M);
+    // head: token-blocked rows (every CFG row of 16 tokens in one workgroup: 4 x 32 workgroups of bc row tiles) unless the
+    // CFG batch is not one of the combine's shapes; then all rows per workgroup (32 workgroups)
+    static const bool tokblk_on = !getenv("FLOAT_FMT_NO_TOKBLK");
+    const bool tokblk = tokblk_on && (bc == 1 || bc == 3 || bc == 4) && h->final_lin.K % 256 == 0;
+    const int nblk = (ntok + 15) / 16;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, nullptr, tokblk ? h->hfin16 : nullptr, tokblk ? bc * 16 : 0))) return rc;
+    GemmArgs g = base_args(tokblk ? h->hfin16 : h->h16, h->final_lin, tokblk ? nblk * bc * 16 : M);
+    g.tokblk = tokblk ? 1 : 0;
     g.bc = bc;
     g.ntok = ntok;
     g.n_prev = c.n_prev;
@@ -528,7 +538,9 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
     } else {
       g.vout = vout_to ? vout_to : h->vout;
     }
-    if ((rc = run_gemm<T, EPI_CFG>(g, s, true))) return rc;
+    if (tokblk) rc = launch_gemm<T, EPI_CFG>(g, bc, 1, 8, false, s);
+    else rc = run_gemm<T, EPI_CFG>(g, s, true);
+    if (rc) return rc;
   }
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
@@ -947,7 +959,9 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   h->cfg = *cfg;
   h->D = cfg->dim_h;
   h->ntok = cfg->n_prev + cfg->n_cur;
-  h->Mpad = 16 * ((4 * h->ntok + 15) / 16);
+  // rows of every activation buffer: the 4-way CFG batch plus the row tiles a row-blocked tiling reads past it (row blocks
+  // are 3-6 tiles; their operand loads are not guarded, the rows are zero and their results are dropped)
+  h->Mpad = 16 * ((4 * h->ntok + 15) / 16 + 6);
   h->Kc = round_up(cfg->dim_w + cfg->dim_a + cfg->dim_e, 128);
   h->Kx = round_up(cfg->dim_w, 128);
   if (const char* wd = getenv("FLOAT_FMT_WIDE")) g_fmt_wide = atoi(wd) != 0;
@@ -971,6 +985,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->cond16, (size_t)Mp * h->Kc);
   A(&h->sc16, (size_t)kScSteps * Mp * D);
   A(&h->h16, (size_t)Mp * D);
+  A(&h->hfin16, (size_t)64 * ((kMaxTok + 15) / 16) * D);  // token-blocked rows of the head GEMM, 4 CFG rows x 16 tokens per block
   A(&h->qkv16, (size_t)Mp * 3 * D);
   A(&h->att16, (size_t)Mp * D);
   A(&h->hid16, (size_t)Mp * cfg->mlp_hidden);

@@ -146,15 +146,18 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
     return a;
   };
   if constexpr (EPI == EPI_CFG) {
-    // rows of the tile: b * ntok + i.  Combine the CFG rows of token i, then (optionally) Euler.
-    for (int idx = threadIdx.x; idx < g.ntok * BN; idx += NTHR) {
-      const int i = idx / BN, c = idx % BN, n = n0 + c;
+    // rows of the tile: b * ntok + i, or b * 16 + i % 16 of token block `by` (g.tokblk).  Combine the CFG rows of token i,
+    // then (optionally) Euler.
+    const int ni = g.tokblk ? 16 : g.ntok, i0 = g.tokblk ? by * 16 : 0, rstride = g.tokblk ? 16 : g.ntok;
+    for (int idx = threadIdx.x; idx < ni * BN; idx += NTHR) {
+      const int il = idx / BN, i = i0 + il, c = idx % BN, n = n0 + c;
+      if (i >= g.ntok) break;
       const float bias = g.bias[n];
       float v[4];
 #pragma unroll
       for (int b2 = 0; b2 < 4; ++b2) {
         if (b2 < g.bc) {
-          const int o = (b2 * g.ntok + i) * BN + c;
+          const int o = (b2 * rstride + il) * BN + c;
           v[b2] = slab_sum(o) + bias;
         } else {
           v[b2] = 0.f;
@@ -385,7 +388,7 @@ constexpr int kLnTouch = 6;  // lines per lane: 192 single-wave workgroups cover
 template <class T, int NV, int KS, bool TOUCH>
 __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, int M, const float* __restrict__ shift,
                                                         const float* __restrict__ scale, int ldm, u16* __restrict__ out,
-                                                        LnRed red, TouchSpec pf) {
+                                                        LnRed red, TouchSpec pf, int ntok, int perm) {
   constexpr int D = NV * 256;
   const int lane = threadIdx.x & 63;
   int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -456,6 +459,12 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
     s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
   }
   const float rstd = rsqrtf(wave_sum(s2) * (1.f / D) + 1e-6f);
+  // perm = bc * 16: token-blocked output rows for the CFG head GEMM (GemmArgs::tokblk)
+  int orow = row;
+  if (perm) {
+    const int b = row / ntok, i = row - b * ntok;
+    orow = (i >> 4) * perm + b * 16 + (i & 15);
+  }
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
@@ -464,7 +473,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
     o.y = T::from_float((v[i].y - mu) * rstd * (1.f + b[i].y) + a[i].y);
     o.z = T::from_float((v[i].z - mu) * rstd * (1.f + b[i].z) + a[i].z);
     o.w = T::from_float((v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w);
-    *reinterpret_cast<ushort4*>(out + fmt_pack_off(row, c, D / 32)) = o;
+    *reinterpret_cast<ushort4*>(out + fmt_pack_off(orow, c, D / 32)) = o;
   }
   if (touch) fmt_touch_retire(touched);
 }

@@ -82,5 +82,8 @@ struct GemmArgs {
   int ksplit;
   size_t slab_stride;
   TouchSpec touch;  // weights of a later GEMM to pull into L2 (W == nullptr: none)
+  // EPI_CFG: rows are token-blocked, row = (i / 16) * (bc * 16) + b * 16 + i % 16 for token i, CFG row b, so a workgroup
+  // with bc row tiles holds every CFG row of its 16 tokens (else: row = b * ntok + i and the workgroup holds all rows)
+  int tokblk;
 };
 
