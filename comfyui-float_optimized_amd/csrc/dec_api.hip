@@ -284,6 +284,7 @@ int create_impl(float_dec* h, const TensorTable& tt) {
   (void)hipGetLastError();
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zblur_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
   return FLOAT_OK;
 }
 
@@ -396,6 +397,33 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   // transposed conv (stride 2) into z (R+1 x R+1), demodulated: all four parity classes in one launch when
   // the (m, n) grid is at least one 16x16 block, else class by class through the generic kernel
   static const bool fuse_z = !getenv("FLOAT_DEC_NO_ZFUSE");
+  // from this resolution up the blur runs inside the transposed conv's launch (z never leaves the CU)
+  static const int zblur_min = getenv("FLOAT_DEC_ZBLUR_MIN") ? atoi(getenv("FLOAT_DEC_ZBLUR_MIN")) : 64;
+  if (R >= zblur_min && up.cout % 32 == 0 && up.cin % 32 == 0) {
+    U = Zb;  // x_in may alias U (the callers reuse one buffer); the z buffer is free in this path and large enough
+    ConvArgs z;
+    memset(&z, 0, sizeof(z));
+    z.X = x_in;
+    z.Wt = up.W;
+    z.Y = U;
+    z.demod = demod + up.demod_off;
+    z.bias = up.abias;
+    z.snext = styles + c2.style_off;
+    z.lds = h->Stot;
+    z.F = n;
+    z.Hi = z.Wi = Ri;
+    z.Cin = up.cin;
+    z.Cout = up.cout;
+    z.OH = z.OW = R;
+    z.ldd = h->Dtot;
+    z.tiles_x = z.tiles_y = (R + 27) / 28;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    const bool prof = fh_prof_pair(1, &e0, &e1);
+    dim3 grid(z.tiles_x * z.tiles_y * n, up.cout / 32);
+    const size_t smem = 32 * 32 * 64;
+    if (prof) hipExtLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, e0, e1, 0, z);
+    else hipLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, z);
+  } else {
   if (Ri + 1 > 8 && up.cout % 32 == 0 && fuse_z) {
     ConvArgs z;
     memset(&z, 0, sizeof(z));
@@ -433,6 +461,7 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
     hipLaunchKernelGGL((dec_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Zb, U, n, R, up.cout, up.abias,
                        styles + c2.style_off, h->Stot);
   }
+  }  // unfused path
   // conv2 (plain 3x3); its unscaled output feeds ToFlow
   if ((rc = launch_conv<T>(U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
                            c2.abias, 1, nullptr, 0, st)))

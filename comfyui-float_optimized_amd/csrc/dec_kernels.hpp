@@ -279,26 +279,24 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
 
-  // per-lane swizzled LDS byte offsets of the A fragments, two 16-bit offsets per register
-  constexpr int NTP = (NTAPS + 1) / 2;
-  unsigned aaddr[4][NTP];
+  // A wave's 4 m-tiles are image rows w*4 .. w*4+3 of the tile (x = r16), so tap (ty, tx) of m-tile mt reads halo row
+  // w*4 + mt + ty at column shift tx: only (3 + TY) * TX distinct fragments, each feeding every (mt, ty) with mt + ty = its
+  // row (3x3: 18 ds_read_b128 per chunk instead of 36; the kernel was LDS-read bound: 54 reads per 72 MFMAs).
+  // Per-lane swizzled LDS byte offsets of those fragments, two 16-bit offsets per register.
+  constexpr int HR = 3 + TY, NFR = HR * TX, NTP = (NFR + 1) / 2;
+  unsigned aaddr[NTP];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = (w * 4 + mt) * 16 + r16;
-    const int y = m >> 4, x = m & 15;
+  for (int tp = 0; tp < NTP; ++tp) {
+    unsigned packed = 0;
 #pragma unroll
-    for (int tp = 0; tp < NTP; ++tp) {
-      unsigned packed = 0;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int t = tp * 2 + h;
-        if (t < NTAPS) {
-          const int P = (y + t / TX) * HW + x + t % TX;
-          packed |= (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4)) << (16 * h);
-        }
+    for (int h = 0; h < 2; ++h) {
+      const int idx = tp * 2 + h;
+      if (idx < NFR) {
+        const int P = (w * 4 + idx / TX) * HW + r16 + idx % TX;
+        packed |= (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4)) << (16 * h);
       }
-      aaddr[mt][tp] = packed;
     }
+    aaddr[tp] = packed;
   }
   const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);  // rows t*BN + j*16 + r16: same swizzle term
 
@@ -369,17 +367,25 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
         for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int t = 0; t < NTAPS; ++t) {
-      u32x4 a[4], b[NT];
+    for (int tx = 0; tx < TX; ++tx) {
+      u32x4 b[TY][NT];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-        a[mt] = *reinterpret_cast<const u32x4*>(sA + ((t & 1) ? (aaddr[mt][t >> 1] >> 16) : (aaddr[mt][t >> 1] & 0xffffu)));
+      for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + baddr + (t * BN + j * 16) * 64);
+        for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const u32x4*>(sB + baddr + ((ty * TX + tx) * BN + j * 16) * 64);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
+      for (int hr = 0; hr < HR; ++hr) {
+        const int idx = hr * TX + tx;
+        const u32x4 a = *reinterpret_cast<const u32x4*>(sA + ((idx & 1) ? (aaddr[idx >> 1] >> 16) : (aaddr[idx >> 1] & 0xffffu)));
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[j], a[mt], acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+        for (int mt = 0; mt < 4; ++mt) {
+          const int ty = hr - mt;
+          if (ty >= 0 && ty < TY) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[ty][j], a, acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+          }
+        }
+      }
     }
     if (chunk == nchunks - 1) {
       const int tile = tile0 + item / nchunks;
@@ -565,6 +571,199 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
         o.z = T::from_float(acc[c][mt][j][2] * d.z);
         o.w = T::from_float(acc[c][mt][j][3] * d.w);
         *reinterpret_cast<ushort4*>(yp + co) = o;
+      }
+    }
+  }
+}
+
+// Transposed conv AND its FIR blur in one launch, for the levels whose z tensor is HBM traffic (r01: at 512x512 the separate
+// kernels ran at 3.4 TB/s - z is written once and read once, 2 x 16.8 MB per frame, for nothing).  A workgroup computes the
+// z values of a 16x16 block of (m, n) positions like dec_zconv4_kernel - 32x32 z pixels x 32 channels - parks them in LDS
+// (fp16, the rounding the z tensor had), and filters the 28x28 output pixels whose 4x4 support lies inside: block origin
+// (14 ty - 1, 14 tx - 1), output tile origin (28 ty, 28 tx), out[Y][X] = sum_ab k[a] k[b] z[Y - 1 + a][X - 1 + b].  Positions
+// outside the image read zero inputs, so their z (the blur's zero padding) comes out as exact zeros by itself.  (16/14)^2 =
+// 1.31x the MFMA work of the unfused kernel buys 59 -> 25 MB of traffic per frame at 512x512.
+template <class T>
+__global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
+  constexpr int NT = 2, BN = 32, HW = 17, NPIX = HW * HW, NTAPS = 9;
+  constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* sA = smem;              // [17*17][64 B], chunk-swizzled
+  unsigned char* sB = smem + NPIX * 64;  // [9][BN][64 B], chunk-swizzled
+  unsigned char* sZ = smem;              // after the K loop: [32][32][64 B] z tile, chunk c of pixel (zr, zc) at c ^ ((zc >> 2) & 3)
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r16 = lane & 15, q = lane >> 4;
+  unsigned aaddr[4][2];
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int mrow = (w * 4 + mt), x = r16;
+#pragma unroll
+    for (int sh = 0; sh < 4; ++sh) {
+      const int P = (mrow + (sh >> 1)) * HW + x + (sh & 1);  // halo origin is (m-1, n-1)
+      const unsigned off = (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4));
+      if (sh & 1) aaddr[mt][sh >> 1] |= off << 16;
+      else aaddr[mt][sh >> 1] = off;
+    }
+  }
+  const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);
+  const int tiles_pf = g.tiles_x * g.tiles_y;
+  const int tile = blockIdx.x;
+  const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
+  const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
+  const int n0 = blockIdx.y * BN;
+  const int nchunks = g.Cin >> 5;
+  const int iy0 = ty * 14 - 2, ix0 = tx * 14 - 2;
+
+  f32x4 acc[4][4][NT];  // [class][m-tile][n-tile]
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  u32x4 ra[NA], rb[NB];
+  auto issue = [&](int chunk) {
+    const int c0 = chunk << 5;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
+      ra[i] = u32x4{0u, 0u, 0u, 0u};
+      if (p < NPIX) {
+        const int hy = p / HW, hx = p - hy * HW;
+        const int iy = iy0 + hy, ix = ix0 + hx;
+        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
+          ra[i] = *reinterpret_cast<const u32x4*>(g.X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + i * 256;
+      if (e < NBC) {
+        const int row = e >> 2, ch = e & 3;
+        const int tap = row / BN, n = row - tap * BN;
+        rb[i] = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+      }
+    }
+  };
+  issue(0);
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
+      if (p < NPIX) *reinterpret_cast<u32x4*>(sA + p * 64 + ((ch ^ ((p >> 1) & 3)) << 4)) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = tid + i * 256;
+      if (e < NBC) {
+        const int row = e >> 2, ch = e & 3;
+        *reinterpret_cast<u32x4*>(sB + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = rb[i];
+      }
+    }
+    __syncthreads();
+    if (chunk + 1 < nchunks) issue(chunk + 1);
+    constexpr int kNum[4] = {1, 2, 2, 4};  // see dec_zconv4_kernel
+    constexpr int kTap[4][4] = {{0, 0, 0, 0}, {1, 4, 0, 0}, {2, 6, 0, 0}, {3, 5, 7, 8}};
+    constexpr int kCls[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 1, 2, 3}};
+#pragma unroll
+    for (int sh = 0; sh < 4; ++sh) {
+      u32x4 a[4];
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        a[mt] = *reinterpret_cast<const u32x4*>(sA + ((sh & 1) ? (aaddr[mt][sh >> 1] >> 16) : (aaddr[mt][sh >> 1] & 0xffffu)));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (u < kNum[sh]) {
+          const int t = kTap[sh][u], c = kCls[sh][u];
+          u32x4 b[NT];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + baddr + (t * BN + j * 16) * 64);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[c][mt][j] = T::mfma(b[j], a[mt], acc[c][mt][j]);
+        }
+      }
+    }
+  }
+  // z tile -> LDS: lane (r16, q) holds channels j*16 + q*4 .. +3 of z pixel (2*(w*4+mt) + pu, 2*r16 + pv)
+  __syncthreads();  // every wave is done with the operand tiles
+  {
+    float4 ed[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) ed[j] = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + n0 + j * 16 + q * 4);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int zr = 2 * (w * 4 + mt) + (c >> 1), zc = 2 * r16 + (c & 1);
+        unsigned char* zp = sZ + (zr * 32 + zc) * 64;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float4 d = ed[j];
+          ushort4 o;
+          o.x = T::from_float(acc[c][mt][j][0] * d.x);
+          o.y = T::from_float(acc[c][mt][j][1] * d.y);
+          o.z = T::from_float(acc[c][mt][j][2] * d.z);
+          o.w = T::from_float(acc[c][mt][j][3] * d.w);
+          const int chunk = (j * 2 + (q >> 1)) ^ ((zc >> 2) & 3);
+          *reinterpret_cast<ushort4*>(zp + chunk * 16 + (q & 1) * 8) = o;
+        }
+      }
+  }
+  __syncthreads();
+  // FIR + bias + lrelu*sqrt2 + next style: thread = (8-channel group cg, output column X, half of the 28 rows); the 64 lanes
+  // of a wave read 16 consecutive pixels x 64 B per LDS row (conflict-free), each z row is filtered horizontally once and
+  // feeds the four output rows it belongs to through a 3-row history
+  {
+    const int cg = tid & 3, X = (tid & 127) >> 2, half = tid >> 7;
+    const int gx = tx * 28 + X;
+    if (X < 28 && gx < g.OW) {
+      const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+      float bs[8], sn[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        bs[i] = g.bias[n0 + cg * 8 + i];
+        sn[i] = g.snext[(size_t)f * g.lds + n0 + cg * 8 + i];
+      }
+      float h0[8], h1[8], h2[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) h0[i] = h1[i] = h2[i] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 17; ++r) {
+        const int zr = half * 14 + 1 + r;  // z rows Yl + 1 .. Yl + 4 of output row Yl
+        float h[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = 0.f;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int zc = X + 1 + b;
+          const uint4 u = *reinterpret_cast<const uint4*>(sZ + (zr * 32 + zc) * 64 + ((cg ^ ((zc >> 2) & 3)) << 4));
+          const u16* e = reinterpret_cast<const u16*>(&u);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) h[i] += k1[b] * T::to_float(e[i]);
+        }
+        if (r >= 3) {
+          const int gy = ty * 28 + half * 14 + (r - 3);
+          if (gy < g.OH) {
+            uint4 o;
+            u16* oe = reinterpret_cast<u16*>(&o);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float v = k1[0] * h0[i] + k1[1] * h1[i] + k1[2] * h2[i] + k1[3] * h[i];
+              oe[i] = T::from_float(fh_lrelu_s2(v + bs[i]) * sn[i]);
+            }
+            *reinterpret_cast<uint4*>(g.Y + ((size_t)(f * g.OH + gy) * g.OW + gx) * g.Cout + n0 + cg * 8) = o;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          h0[i] = h1[i];
+          h1[i] = h2[i];
+          h2[i] = h[i];
+        }
       }
     }
   }
