@@ -721,29 +721,33 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
     const int cg = tid & 3, X = (tid & 127) >> 2, half = tid >> 7;
     const int gx = tx * 28 + X;
     if (X < 28 && gx < g.OW) {
+      // two channels per packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32): the filter is VALU-bound
+      typedef float v2f __attribute__((ext_vector_type(2)));
       const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-      float bs[8], sn[8];
+      v2f bs[4], sn[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        bs[i] = g.bias[n0 + cg * 8 + i];
-        sn[i] = g.snext[(size_t)f * g.lds + n0 + cg * 8 + i];
+      for (int i = 0; i < 4; ++i) {
+        const float2 b2 = *reinterpret_cast<const float2*>(g.bias + n0 + cg * 8 + i * 2);
+        const float2 s2 = *reinterpret_cast<const float2*>(g.snext + (size_t)f * g.lds + n0 + cg * 8 + i * 2);
+        bs[i] = v2f{b2.x, b2.y};
+        sn[i] = v2f{s2.x * 1.4142135623730951f, s2.y * 1.4142135623730951f};  // leaky_relu's sqrt(2) rides in the style
       }
-      float h0[8], h1[8], h2[8];
+      v2f h0[4], h1[4], h2[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) h0[i] = h1[i] = h2[i] = 0.f;
+      for (int i = 0; i < 4; ++i) h0[i] = h1[i] = h2[i] = v2f{0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 17; ++r) {
         const int zr = half * 14 + 1 + r;  // z rows Yl + 1 .. Yl + 4 of output row Yl
-        float h[8];
+        v2f h[4];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) h[i] = 0.f;
+        for (int i = 0; i < 4; ++i) h[i] = v2f{0.f, 0.f};
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int zc = X + 1 + b;
           const uint4 u = *reinterpret_cast<const uint4*>(sZ + (zr * 32 + zc) * 64 + ((cg ^ ((zc >> 2) & 3)) << 4));
           const u16* e = reinterpret_cast<const u16*>(&u);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) h[i] += k1[b] * T::to_float(e[i]);
+          for (int i = 0; i < 4; ++i) h[i] += k1[b] * v2f{T::to_float(e[2 * i]), T::to_float(e[2 * i + 1])};
         }
         if (r >= 3) {
           const int gy = ty * 28 + half * 14 + (r - 3);
@@ -751,15 +755,18 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
             uint4 o;
             u16* oe = reinterpret_cast<u16*>(&o);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float v = k1[0] * h0[i] + k1[1] * h1[i] + k1[2] * h2[i] + k1[3] * h[i];
-              oe[i] = T::from_float(fh_lrelu_s2(v + bs[i]) * sn[i]);
+            for (int i = 0; i < 4; ++i) {
+              v2f v = k1[0] * h0[i] + k1[1] * h1[i] + k1[2] * h2[i] + k1[3] * h[i] + bs[i];
+              const v2f lo = 0.2f * v;
+              v = v2f{fmaxf(v.x, lo.x), fmaxf(v.y, lo.y)} * sn[i];  // leaky_relu(0.2)
+              oe[2 * i] = T::from_float(v.x);
+              oe[2 * i + 1] = T::from_float(v.y);
             }
             *reinterpret_cast<uint4*>(g.Y + ((size_t)(f * g.OH + gy) * g.OW + gx) * g.Cout + n0 + cg * 8) = o;
           }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 4; ++i) {
           h0[i] = h1[i];
           h1[i] = h2[i];
           h2[i] = h[i];
