@@ -23,3 +23,8 @@ else:
     print("mean err by row block of 28:", [round(float(d[0, i:i+28].mean()), 5) for i in range(0, 140, 28)])
     print("err at rows 0..6:", [round(float(d[0, i].mean()), 5) for i in range(7)])
     print("err at rows 26..30:", [round(float(d[0, i].mean()), 5) for i in range(26, 31)])
+if not os.environ.get("SAVE"):
+    big = (d > 1e-3)
+    print("count > 1e-3:", int(big.sum()), "of", d.numel(), " > 1e-4:", int((d > 1e-4).sum()), " psnr vs ref: %.1f dB" % float(-10 * torch.log10(((out - ref) ** 2).mean())))
+    idx = torch.nonzero(big)[:12]
+    print("where:", idx.tolist())
