@@ -59,7 +59,7 @@ typedef struct {
   int32_t dim_w, dim_a, dim_e, dim_h;
   int32_t depth, heads;
   int32_t mlp_hidden;      /* int(dim_h * mlp_ratio) */
-  int32_t n_prev, n_cur;   /* num_prev_frames, int(wav2vec_sec*fps); n_prev + n_cur <= 80, and (CFG rows) x tokens <= 240 */
+  int32_t n_prev, n_cur;   /* num_prev_frames, int(wav2vec_sec*fps); n_prev + n_cur <= 80 */
   int32_t attn_window;     /* |i-j| <= window is visible (FMT.py:15-19) */
   int32_t dtype;           /* FLOAT_DT_* */
   int32_t use_graph;       /* 0: eager launches; 1: replay each window's chain from a cached hipGraph with

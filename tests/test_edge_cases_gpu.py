@@ -95,12 +95,11 @@ def test_other_fixed_step_solvers(method):
         m.set_method("dopri5")
 
 
-@pytest.mark.parametrize("n_prev,n_cur,window", [(5, 40, 3), (10, 60, 2), (2, 50, 1)])
+@pytest.mark.parametrize("n_prev,n_cur,window", [(5, 40, 3), (10, 60, 2), (2, 50, 1), (10, 70, 2)])
 def test_other_temporal_structures(n_prev, n_cur, window):
     """LoadFMTModel lets fps / wav2vec_sec / num_prev_frames / attention_window reshape the model
     (nodes_vadv_loader.py:791-840): windows of n_cur = int(wav2vec_sec * fps) frames with n_prev of context and a band
-    of +-window keys.  Up to 80 tokens per window (e.g. fps 30: 60 + 10); a 4-way CFG of more than 60 tokens exceeds the
-    240-row CFG epilogue tile and must be refused, not silently truncated."""
+    of +-window keys.  Up to 80 tokens per window (e.g. fps 30: 60 + 10), 3- and 4-way CFG."""
     cfg = C.small_fmt_config()
     cfg.num_prev_frames, cfg.num_frames_for_clip, cfg.attention_window = n_prev, n_cur, window
     sd = W.synth_fmt_state(cfg, seed=61)
@@ -113,9 +112,5 @@ def test_other_temporal_structures(n_prev, n_cur, window):
     got = f.sample(r_s, wa, we, noise, 4, 2.0, 1.0, 1.0).cpu()
     want = O.sample_rd(sd, cfg, r_s, wa, we, noise, 4, 2.0, 1.0, 1.0)
     assert got.shape == (1, T, cfg.dim_w) and rel_l2(got, want) < 4e-3
-    if 4 * (n_prev + n_cur) > 240:
-        with pytest.raises(ValueError):
-            f.sample(r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, include_r_cfg=True)
-    else:
-        got4 = f.sample(r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, include_r_cfg=True).cpu()
-        assert rel_l2(got4, O.sample_rd(sd, cfg, r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, True)) < 4e-3
+    got4 = f.sample(r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, include_r_cfg=True).cpu()  # up to 4 x 70 = 280 rows
+    assert rel_l2(got4, O.sample_rd(sd, cfg, r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, True)) < 4e-3
