@@ -979,7 +979,7 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     const size_t po0 = (size_t)f * npix + p0;
     uint4 xu[PIX];
 #pragma unroll
-    for (int k = 0; k < PIX; ++k) xu[k] = *reinterpret_cast<const uint4*>(g.x + (po0 + k) * C + c0);
+    for (int k = 0; k < PIX; ++k) xu[k] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(g.x + (po0 + k) * C + c0)));  // read once: leave L2 to the features
     float upf[3] = {0.f, 0.f, 0.f};  // up-sampled previous flow of THIS lane's pixel
     if (g.pflow && owner) up2_tap3(g.pflow, f, Rp, Y, X0 + sub, upf);
     const float gy = g.lin[Y];
