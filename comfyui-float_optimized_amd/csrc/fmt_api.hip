@@ -993,7 +993,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->qkv16, (size_t)Mp * 3 * D);
   A(&h->att16, (size_t)Mp * D);
   A(&h->hid16, (size_t)Mp * cfg->mlp_hidden);
-  A(&h->xin16, (size_t)kMaxTok * h->Kx);
+  A(&h->xin16, (size_t)(kMaxTok + 6 * 16) * h->Kx);  // + the row tiles a row-blocked tiling reads past the last token (zero)
   A(&h->tsin16, (size_t)kMaxSteps * 256);
   A(&h->th16, (size_t)kMaxSteps * D);
   A(&h->ccond, (size_t)Mp * D);
