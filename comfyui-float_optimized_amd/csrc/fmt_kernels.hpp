@@ -494,11 +494,16 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
   const int h = blockIdx.x;
   const int row_ = blockIdx.y * (blockDim.x / LPQ) + threadIdx.x / LPQ, part = threadIdx.x % LPQ;
   unsigned touched[2] = {0u, 0u};
-  if constexpr (TOUCH) {
-    const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
-    fmt_touch(pf, lin & 7, (lin >> 3) * blockDim.x + threadIdx.x, (nwg >> 3) * blockDim.x, touched);
-  }
+  // issued BEHIND the wave's own q / k / v loads (memory operations retire in order: in front of them, the wave would wait
+  // for the touched HBM lines before it could use operands that come from the Infinity Cache)
+  auto touch = [&]() {
+    if constexpr (TOUCH) {
+      const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
+      fmt_touch(pf, lin & 7, (lin >> 3) * blockDim.x + threadIdx.x, (nwg >> 3) * blockDim.x, touched);
+    }
+  };
   if (row_ >= M) {  // whole LPQ-lane groups leave together
+    touch();
     if constexpr (TOUCH) fmt_touch_retire(touched);
     return;
   }
@@ -551,6 +556,7 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
         vv[t][u] = *reinterpret_cast<const uint4*>(kp + D + u * 8);
       }
     }
+    touch();
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int kj = qi + t - 2;
@@ -558,6 +564,7 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
       fold(kk[t], vv[t], valid);
     }
   } else {
+    touch();
     for (int kj = qi - window; kj <= qi + window; ++kj) {
       const int kc = min(max(kj, 0), ntok - 1);
       const u16* kp = base + (size_t)kc * ld + D;
