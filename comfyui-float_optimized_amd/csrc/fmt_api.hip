@@ -319,10 +319,11 @@ int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
 // Touch descriptor for the weights of GEMM `L` as it will be launched for M rows (ksplit = 0: plain GEMM, else EPI_PARTIAL
 // with that many K slices), to be executed by `lanes` threads per XCD with at most `per_lane` lines each; W = nullptr when the
 // GEMM's block decode is not the XCD-affine one or the lanes cannot cover it.
-// FLOAT_FMT_TOUCH bit mask - who pulls whose weights: 1 LayerNorm -> qkv / fc1, 2 attention -> proj, 4 fc1 -> fc2, 8 qkv -> proj,
-// 16 proj -> fc1, 32 fc2 -> the next block's qkv.  Default 2 + 4 + 32 (r01, ms per 250 evaluations, same box: none 90.8,
-// 2+4 87.6, 4+32 86.0-86.7, 2+4+32 85.2; every way of touching fc1's weights - from LayerNorm, proj or qkv - made it slower).
-int g_fmt_touch = 38;
+// FLOAT_FMT_TOUCH bit mask - who pulls whose weights: 1 LayerNorm -> qkv and fc1 (64: only LN2 -> fc1, 128: only LN1 -> qkv),
+// 2 attention -> proj, 4 fc1 -> fc2, 8 qkv -> proj, 16 proj -> fc1, 32 fc2 -> the next block's qkv / the head.
+// Default 2 + 4 + 32 + 128 (r01, ms per 250 evaluations, same box: none 90.8, 2+4 87.6, 4+32 86.0-86.7, 2+4+32 83.2-83.5 after the
+// head change, + LN1 -> qkv 82.5; touching fc1's weights - from LayerNorm, proj or qkv - never paid).
+int g_fmt_touch = 166;
 TouchSpec make_touch(const Lin& L, int M, int ksplit, unsigned lanes, unsigned per_lane, int force_nt = 0) {
   TouchSpec t{};
   Tiling tl = ksplit ? pick_tiling(M, L.N * ksplit, L.K / ksplit, false) : pick_tiling(M, L.N, L.K, false);
@@ -359,7 +360,7 @@ unsigned gemm_lanes_per_xcd(int M, int N, int K) {
 
 template <class T>
 int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s, PendingRed* pend = nullptr,
-                 const Lin* next = nullptr, u16* out = nullptr, int perm = 0) {
+                 const Lin* next = nullptr, u16* out = nullptr, int perm = 0, int touch_bit = 1) {
   const int nv = h->D / 256;
   // one row (wave) per workgroup: 180 single-wave workgroups spread over 180 CUs (4 rows per workgroup: +0.4 %)
   static const int rpw = getenv("FLOAT_FMT_LN_ROWS") ? std::max(1, std::min(4, atoi(getenv("FLOAT_FMT_LN_ROWS")))) : 1;
@@ -369,7 +370,7 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   LnRed red{};
   if (ks) red = pend->red;
   TouchSpec pf{};
-  if (next && (g_fmt_touch & 1) && rpw == 1) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
+  if (next && (g_fmt_touch & (1 | touch_bit)) && rpw == 1) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
 #define LN_LAUNCH(NV, KS)                                                                                                          \
   do {                                                                                                                             \
     if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
@@ -441,7 +442,7 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
   for (int b = 0; b < c.depth; ++b) {
     const float* mod = modbuf + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, &B.qkv))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, &B.qkv, nullptr, 0, 128))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.qkv, M);
       g.out16 = h->qkv16;
@@ -486,7 +487,7 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
       if (g_fmt_touch & 16) g.touch = make_touch(B.fc1, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       if ((rc = run_gemm<T, EPI_GATE_RES>(g, s))) return rc;
     }
-    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, &B.fc1))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, &B.fc1, nullptr, 0, 64))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.fc1, M);
       g.out16 = h->hid16;

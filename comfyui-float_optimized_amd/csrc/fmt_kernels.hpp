@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
     a[i] = *reinterpret_cast<const float4*>(sh + c);
     b[i] = *reinterpret_cast<const float4*>(sc + c);
   }
-  if (touch) fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);  // behind the row's own loads
+  if (KS == 0 && touch) fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);  // behind the row's own loads (in-order retirement)
   if constexpr (KS > 0) {
     float4 p[KS][NV], gt[NV], bi[NV];
 #pragma unroll
@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
       gt[i] = *reinterpret_cast<const float4*>(red.gate + (size_t)row * ldm + c);
       bi[i] = *reinterpret_cast<const float4*>(red.bias + c);
     }
+    if (touch) fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       float4 t = p[0][i];

@@ -53,7 +53,7 @@ def run_child(tmp_path, what, tag, env):
 def test_fmt_touch_and_token_blocked_head_are_bitwise_neutral(tmp_path):
     base = run_child(tmp_path, "fmt", "plain", {"FLOAT_FMT_TOUCH": "0", "FLOAT_FMT_NO_TOKBLK": "1"})
     tuned = run_child(tmp_path, "fmt", "tuned", {})
-    every = run_child(tmp_path, "fmt", "every", {"FLOAT_FMT_TOUCH": "63"})
+    every = run_child(tmp_path, "fmt", "every", {"FLOAT_FMT_TOUCH": "255"})
     for k in ("r3", "r4"):
         assert torch.isfinite(base[k]).all()
         assert torch.equal(base[k], tuned[k]), k
