@@ -28,23 +28,29 @@ struct float_fmt {
   float* freqs = nullptr;
   // workspace
   u16 *cond16, *sc16, *h16, *hfin16, *qkv16, *att16, *hid16, *xin16, *tsin16, *th16;
-  float *ccond, *mod, *xres, *xcur, *temb, *ts_dev, *vout;
+  float *ccond, *xres, *xcur, *temb, *vout;
   float* slab = nullptr;  // [4][Mpad][D] split-K partial sums (EPI_PARTIAL)
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
-  // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, scales)
   int method = 0;          // FLOAT_ODE_*
   float* kbuf = nullptr;   // [4][kMaxTok][dim_w] stage velocities of the Runge-Kutta solvers
+  // Modulations of up to kScSteps evaluations of a window, [step][Mmod][Ntot] fp32: c = t_emb + c_embedder(wr, wa, we) does not
+  // depend on x (FMT.py:333-335, 163-166), so every adaLN projection of those evaluations is ONE GEMM per window.
+  float* modall = nullptr;
+  int Mmod = 0;
+  // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, method, scales); least recently used entry evicted
   struct GraphKey {
     int nfe, bc, we_len, method;
     float a, r, e;
-    bool operator<(const GraphKey& o) const {
-      return memcmp(this, &o, sizeof(GraphKey)) < 0;
-    }
+    bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
   };
-  std::map<GraphKey, hipGraphExec_t> graphs;
-  hipStream_t cap_stream = nullptr, side_stream = nullptr;
-  std::vector<hipEvent_t> events;
-  float* mod2 = nullptr;
+  struct GraphEntry {
+    GraphKey key;
+    hipGraphExec_t exec;
+    uint64_t used;
+  };
+  std::vector<GraphEntry> graphs;
+  uint64_t graph_clock = 0;
+  hipStream_t cap_stream = nullptr;
   // state of an incremental sample (float_fmt_sample_begin / _next)
   struct {
     const float *wr, *wa, *we, *noise;
@@ -116,9 +122,10 @@ int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   }
   const int mt_total = (g.M + 15) / 16;
   g.mblk = (mt_total + MTW - 1) / MTW;
+  const dim3 grid((g.N / 128) * g.mblk * (g.zcount > 1 ? g.zcount : 1));
   hipEvent_t e0, e1;
-  if (fh_prof_pair(0, &e0, &e1)) hipExtLaunchKernelGGL(kern, dim3((g.N / 128) * g.mblk), dim3(256), smem, s, e0, e1, 0, g);
-  else hipLaunchKernelGGL(kern, dim3((g.N / 128) * g.mblk), dim3(256), smem, s, g);
+  if (fh_prof_pair(2, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, s, e0, e1, 0, g);
+  else hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -396,27 +403,72 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   return FLOAT_OK;
 }
 
-// Modulation half of an evaluation: depends only on t and the window's conditions, NOT on x, so
-// inside a captured window it runs on a side branch one step ahead of the block chain.
-//   sc = silu(t_emb + c_cond)  ->  mod[M][depth*6D + 2D] = every adaLN projection in one
-//   weight-streaming GEMM (105 MB of the 313 MB an evaluation reads).
-constexpr int kScSteps = 64;  // SiLU(c) of up to this many Euler steps is produced once per window
+// Banded attention over the M rows of qkv16 -> att16 (packed operand of attn.proj); `pull`: the GEMM whose weights the
+// workgroups touch meanwhile (TouchSpec), or nullptr.
+template <class T>
+void launch_attn(float_fmt* h, int M, const Lin* pull, hipStream_t s) {
+  const float_fmt_cfg_t& c = h->cfg;
+  const int D = h->D, ntok = h->ntok;
+  // queries per workgroup / lanes per query (FLOAT_FMT_ATTN="qpw,lpq"): one 8-row output group per workgroup by default
+  static int qpw = 8, lpq = 16;  // r01: 16 lanes per query (8 dims each) 81.5-81.9 ms per 250 evaluations, 8 lanes 82.3-82.9
+  static const bool parsed = [] {
+    if (const char* v = getenv("FLOAT_FMT_ATTN")) sscanf(v, "%d,%d", &qpw, &lpq);
+    if (lpq != 16) lpq = 8;
+    qpw = std::max(1, std::min(512 / lpq, qpw));
+    return true;
+  }();
+  (void)parsed;
+  dim3 grid(c.heads, (M + qpw - 1) / qpw), block(qpw * lpq);
+  TouchSpec pf{};
+  if (pull) pf = make_touch(*pull, M, 0, (grid.x * grid.y / 8) * block.x, 2);
+#define ATTN_LAUNCH(LPQ, TCH) \
+  hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf)
+  if (lpq == 16) {
+    if (pf.W) ATTN_LAUNCH(16, true);
+    else ATTN_LAUNCH(16, false);
+  } else {
+    if (pf.W) ATTN_LAUNCH(8, true);
+    else ATTN_LAUNCH(8, false);
+  }
+#undef ATTN_LAUNCH
+}
+
+// Modulation half of the evaluations [e0, e0 + n) of a window: depends only on t and the window's conditions, NOT on x
+// (c = t_emb + c_embedder([wr, wa, we]), FMT.py:333-335; adaLN_modulation = Linear(SiLU(c)), FMT.py:163-166, 187-190), so it is
+// taken out of the Euler step:
+//   sc[z]     = silu(t_emb[e0 + z] + c_cond)                          one launch, blockIdx.y = z
+//   modall[z] = sc[z] @ W_adaLN_all^T + b   (Mmod x Ntot fp32 per z)  ONE GEMM launch of n row batches against the 105 MB of
+//                                                                     weights (every block's adaLN projection + the head's)
+// The step chain then reads its 37 MB slab and no longer streams those weights, which leaves the 208 MB of block weights
+// alone in the 256 MB Infinity Cache.  FLOAT_FMT_HOIST=0 launches the same kernel once per evaluation (n = 1) instead
+// (bitwise the same numbers; the A/B switch of the measurement).
+constexpr int kScSteps = 64;  // evaluations per modulation batch; longer grids run in batches of this many
+int g_fmt_hoist = 1;
+int g_fmt_zgroup = 4;  // FLOAT_FMT_ZGROUP: column blocks of an XCD that share activation tiles through L2 (fmt_gemm_wide_kernel)
 
 template <class T>
-int run_mod(float_fmt* h, int bc, int step, float* modbuf, hipStream_t s, bool hoisted) {
+int run_mod_all(float_fmt* h, int bc, int e0, int n, hipStream_t s) {
   const int D = h->D, M = bc * h->ntok;
-  const u16* A = h->sc16;
-  if (hoisted) {
-    A = h->sc16 + (size_t)step * h->Mpad * D;
-  } else {
-    hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256, 1), dim3(256), 0, s, h->sc16,
-                       h->temb + (size_t)step * D, h->ccond, M, D, (size_t)0);
-  }
-  GemmArgs g = base_args(A, h->adaln_all, M);
-  g.out_f32 = modbuf;
+  FH_REQUIRE(n >= 1 && n <= kScSteps, "modulation batch of %d evaluations (max %d)", n, kScSteps);
+  hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256, n), dim3(256), 0, s, h->sc16, h->temb + (size_t)e0 * D,
+                     h->ccond, M, D, (size_t)h->Mpad * D);
+  GemmArgs g = base_args(h->sc16, h->adaln_all, M);
+  g.out_f32 = h->modall;
   g.ldo = h->Ntot;
+  g.zcount = n;
+  g.zgroup = g_fmt_zgroup;
+  g.a_zstride = (size_t)h->Mpad * D;
+  g.o_zstride = (size_t)h->Mmod * h->Ntot;
   if (g_fmt_wide && g.N % 128 == 0 && g.K % 128 == 0) return launch_wide<T>(g, false, s);
-  return run_gemm<T, EPI_F32>(g, s);
+  for (int z = 0; z < n; ++z) {  // shapes the wide kernel does not tile: the generic GEMM, one batch at a time
+    GemmArgs gz = g;
+    gz.A = g.A + (size_t)z * g.a_zstride;
+    gz.out_f32 = g.out_f32 + (size_t)z * g.o_zstride;
+    gz.zcount = 0;
+    int rc = run_gemm<T, EPI_F32>(gz, s);
+    if (rc) return rc;
+  }
+  return FLOAT_OK;
 }
 
 // Block chain of an evaluation on the rows staged in the workspace, using the modulations in modbuf.
@@ -450,30 +502,7 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
       if ((g_fmt_touch & 8) && !split_ok(g_fmt_proj_split, B.proj)) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       if ((rc = run_gemm<T, EPI_T16>(g, s))) return rc;
     }
-    {
-      // queries per workgroup / lanes per query (FLOAT_FMT_ATTN="qpw,lpq"): one 8-row output group per workgroup by default
-      static int qpw = 8, lpq = 16;  // r01: 16 lanes per query (8 dims each) 81.5-81.9 ms per 250 evaluations, 8 lanes 82.3-82.9
-      static const bool parsed = [] {
-        if (const char* v = getenv("FLOAT_FMT_ATTN")) sscanf(v, "%d,%d", &qpw, &lpq);
-        if (lpq != 16) lpq = 8;
-        qpw = std::max(1, std::min(512 / lpq, qpw));
-        return true;
-      }();
-      (void)parsed;
-      dim3 grid(c.heads, (M + qpw - 1) / qpw), block(qpw * lpq);
-      TouchSpec pf{};
-      if ((g_fmt_touch & 2) && !split_ok(g_fmt_proj_split, B.proj)) pf = make_touch(B.proj, M, 0, (grid.x * grid.y / 8) * block.x, 2);
-#define ATTN_LAUNCH(LPQ, TCH) \
-  hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf)
-      if (lpq == 16) {
-        if (pf.W) ATTN_LAUNCH(16, true);
-        else ATTN_LAUNCH(16, false);
-      } else {
-        if (pf.W) ATTN_LAUNCH(8, true);
-        else ATTN_LAUNCH(8, false);
-      }
-#undef ATTN_LAUNCH
-    }
+    launch_attn<T>(h, M, (g_fmt_touch & 2) && !split_ok(g_fmt_proj_split, B.proj) ? &B.proj : nullptr, s);
     if (split_ok(g_fmt_proj_split, B.proj)) {
       if ((rc = run_gemm_partial<T>(h, base_args(h->att16, B.proj, M), g_fmt_proj_split, s))) return rc;
       pend.ks = g_fmt_proj_split;
@@ -559,13 +588,18 @@ void linspace01(int n, std::vector<float>* ts) {
   for (int i = 0; i < n; ++i) (*ts)[i] = (i < half) ? (0.f + step * (float)i) : (1.0f - step * (float)(n - 1 - i));
 }
 
-// t-embedding MLP for all steps of the grid (FMT.py:128-131), rows = steps.
+// t-embedding MLP (FMT.py:128-131) for every evaluation time of a window, rows = evaluations.  The times are formed on the
+// device (fmt_tsin_kernel) from (nfe, stage offsets), so no host buffer is read by the stream: the call can be captured.
+struct TimeSpec {
+  float t;        // nfe == 0: the one explicit time of float_fmt_eval
+  int nfe, stages;
+  float c[4];     // stage offsets of the Runge-Kutta scheme (Euler: {0})
+};
 template <class T>
-int prepare_time(float_fmt* h, const std::vector<float>& ts, hipStream_t s) {
-  const int n = (int)ts.size();
+int prepare_time(float_fmt* h, const TimeSpec& ts, int n, hipStream_t s) {
   int rc;
-  FH_CHECK_HIP(hipMemcpyAsync(h->ts_dev, ts.data(), n * sizeof(float), hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL((fmt_tsin_kernel<T>), dim3(n), dim3(256), 0, s, h->tsin16, h->ts_dev, h->freqs, n);
+  hipLaunchKernelGGL((fmt_tsin_kernel<T>), dim3(n), dim3(256), 0, s, h->tsin16, h->freqs, n, ts.t, ts.nfe, ts.stages, ts.c[0],
+                     ts.c[1], ts.c[2], ts.c[3]);
   GemmArgs g = base_args(h->tsin16, h->t0, n);
   g.out16 = h->th16;
   g.ldo16 = h->t2.K / 32;
@@ -639,103 +673,59 @@ const Tableau& tableau(int method) {
 }
 
 // evaluation times of a window: Euler -> the grid itself; RK -> t_i + c_j (t_{i+1} - t_i), step-major
-void eval_times(int method, const std::vector<float>& grid, std::vector<float>* out) {
-  if (method == FLOAT_ODE_EULER) {
-    *out = grid;
-    return;
-  }
+TimeSpec time_spec(int method, int nfe) {
   const Tableau& tb = tableau(method);
-  out->clear();
-  for (size_t i = 0; i + 1 < grid.size(); ++i) {
-    const float dt = grid[i + 1] - grid[i];
-    for (int j = 0; j < tb.s; ++j) out->push_back(grid[i] + dt * tb.c[j]);
-  }
-  if (out->empty()) out->push_back(0.f);
+  TimeSpec ts{};
+  ts.nfe = nfe;
+  ts.stages = tb.s;
+  for (int j = 0; j < 4; ++j) ts.c[j] = tb.c[j];
+  return ts;
 }
 int n_evals(int method, int nfe) { return (nfe - 1) * tableau(method).s; }
 
+// The evaluations of one window, eager and single-stream (this is also what gets captured into the window's hipGraph and
+// the profiling path).  Modulations come in batches of up to kScSteps evaluations (run_mod_all); FLOAT_FMT_HOIST=0 makes the
+// batch one evaluation long.
 template <class T>
-int run_window_steps_rk(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
-                        hipStream_t s) {
+int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
+                     hipStream_t s) {
   const Tableau& tb = tableau(h->method);
   const float_fmt_cfg_t& c = h->cfg;
   const int kstride = kMaxTok * c.dim_w, n = c.n_cur * c.dim_w;
-  const bool hoisted = n_evals(h->method, nfe) <= kScSteps;
+  const int nev = n_evals(h->method, nfe), batch = g_fmt_hoist ? kScSteps : 1;
+  const size_t zs = (size_t)h->Mmod * h->Ntot;
+  const bool euler = h->method == FLOAT_ODE_EULER;
   int rc;
-  for (int i = 0; i < nfe - 1; ++i) {
+  for (int ev = 0; ev < nev; ++ev) {
+    const int i = ev / tb.s, j = ev - i * tb.s, z = ev % batch;
     const float dt = ts[i + 1] - ts[i];
-    for (int j = 0; j < tb.s; ++j) {
-      if (j > 0) {
-        hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, j,
-                           dt * tb.a[j][0], dt * tb.a[j][1], dt * tb.a[j][2], 0.f, 0, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
-                           c.dim_w);
-      }
-      if ((rc = run_mod<T>(h, m.bc, i * tb.s + j, h->mod, s, hoisted))) return rc;
-      if ((rc = run_blocks<T>(h, m.bc, h->mod, false, 0.f, a, r, e, s, h->kbuf + (size_t)j * kstride))) return rc;
+    if (z == 0 && (rc = run_mod_all<T>(h, m.bc, ev, std::min(batch, nev - ev), s))) return rc;
+    const float* mod = h->modall + (size_t)z * zs;
+    if (euler) {
+      if ((rc = run_blocks<T>(h, m.bc, mod, true, dt, a, r, e, s))) return rc;
+      continue;
     }
-    hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, tb.s,
-                       dt * tb.b[0], dt * tb.b[1], dt * tb.b[2], dt * tb.b[3], 1, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
-                       c.dim_w);
+    // fixed-grid explicit Runge-Kutta: stage j evaluates at y0 + dt sum_m a[j][m] k_m, the update is dt sum_j b_j k_j
+    if (j > 0) {
+      hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, j,
+                         dt * tb.a[j][0], dt * tb.a[j][1], dt * tb.a[j][2], 0.f, 0, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
+                         c.dim_w);
+    }
+    if ((rc = run_blocks<T>(h, m.bc, mod, false, 0.f, a, r, e, s, h->kbuf + (size_t)j * kstride))) return rc;
+    if (j == tb.s - 1) {
+      hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, tb.s,
+                         dt * tb.b[0], dt * tb.b[1], dt * tb.b[2], dt * tb.b[3], 1, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
+                         c.dim_w);
+    }
   }
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
 
-// The Euler chain of one window, eager and single-stream (also the profiling path).
-template <class T>
-int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
-                     hipStream_t s) {
-  if (h->method != FLOAT_ODE_EULER) return run_window_steps_rk<T>(h, m, nfe, ts, a, r, e, s);
-  for (int i = 0; i < nfe - 1; ++i) {
-    const float dt = ts[i + 1] - ts[i];
-    int rc = run_mod<T>(h, m.bc, i, h->mod, s, nfe - 1 <= kScSteps);
-    if (rc) return rc;
-    if ((rc = run_blocks<T>(h, m.bc, h->mod, true, dt, a, r, e, s))) return rc;
-  }
-  return FLOAT_OK;
-}
-
-// The same chain as it is captured into the hipGraph: the modulation GEMM of step i+1 (HBM-bound,
-// independent of x) runs on a side stream while the latency-bound block chain of step i runs on the
-// main stream; mod is double-buffered.  Every output element is still produced by the same kernel
-// with the same operands, so results are bitwise identical to the eager chain.
-template <class T>
-int capture_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<float>& ts, float a, float r, float e,
-                         hipStream_t s, hipStream_t side) {
-  const int S = nfe - 1;
-  if (S <= 0) return FLOAT_OK;
-  int rc;
-  float* modb[2] = {h->mod, h->mod2};
-  std::vector<hipEvent_t>& ev = h->events;
-  while ((int)ev.size() < 2 * S + 2) {
-    hipEvent_t e2;
-    FH_CHECK_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-    ev.push_back(e2);
-  }
-  hipEvent_t* ev_mod = ev.data();         // ev_mod[i]: modulations of step i ready
-  hipEvent_t* ev_done = ev.data() + S + 1;  // ev_done[i]: block chain of step i finished
-  FH_CHECK_HIP(hipEventRecord(ev_done[S], s));  // fork point
-  FH_CHECK_HIP(hipStreamWaitEvent(side, ev_done[S], 0));
-  const bool hoisted = S <= kScSteps;
-  if ((rc = run_mod<T>(h, m.bc, 0, modb[0], side, hoisted))) return rc;
-  FH_CHECK_HIP(hipEventRecord(ev_mod[0], side));
-  for (int i = 0; i < S; ++i) {
-    if (i + 1 < S) {
-      // buffer (i+1)%2 was last read by step i-1
-      if (i >= 1) FH_CHECK_HIP(hipStreamWaitEvent(side, ev_done[i - 1], 0));
-      if ((rc = run_mod<T>(h, m.bc, i + 1, modb[(i + 1) & 1], side, hoisted))) return rc;
-      FH_CHECK_HIP(hipEventRecord(ev_mod[i + 1], side));
-    }
-    FH_CHECK_HIP(hipStreamWaitEvent(s, ev_mod[i], 0));
-    if ((rc = run_blocks<T>(h, m.bc, modb[i & 1], true, ts[i + 1] - ts[i], a, r, e, s))) return rc;
-    FH_CHECK_HIP(hipEventRecord(ev_done[i], s));
-  }
-  // join: the side stream's last work (ev_mod[S-1]) was already waited on by the main stream
-  return FLOAT_OK;
-}
-
-// Same chain, replayed from a cached hipGraph (all pointers are workspace-internal, so the graph is
-// reusable across windows and clips for a given (nfe, cfg mode, scales)).
+// Same chain, replayed from a cached hipGraph (all pointers are workspace-internal, so the graph is reusable across windows
+// and clips for a given (nfe, method, cfg mode, scales)).  The cache holds kMaxGraphs executables; the least recently used
+// one is destroyed when a new key arrives (a caller sweeping a CFG scale would otherwise keep a ~3000-node graph per value).
+constexpr size_t kMaxGraphs = 8;
 template <class T>
 int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, const std::vector<float>& ts, float a,
                            float r, float e, hipStream_t s) {
@@ -748,14 +738,14 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
   key.a = a;
   key.r = r;
   key.e = e;
-  auto it = h->graphs.find(key);
-  if (it == h->graphs.end()) {
+  float_fmt::GraphEntry* hit = nullptr;
+  for (auto& g : h->graphs)
+    if (g.key == key) hit = &g;
+  if (!hit) {
     if (!h->cap_stream) FH_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
-    if (!h->side_stream) FH_CHECK_HIP(hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
     FH_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
-    int rc = (h->cfg.use_graph == 2 || h->method != FLOAT_ODE_EULER) ? run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream)
-                                   : capture_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream, h->side_stream);
+    int rc = run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream);
     hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);
     if (rc) {
       if (graph) (void)hipGraphDestroy(graph);
@@ -765,9 +755,20 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
     hipGraphExec_t exec = nullptr;
     FH_CHECK_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     (void)hipGraphDestroy(graph);
-    it = h->graphs.emplace(key, exec).first;
+    if (h->graphs.size() >= kMaxGraphs) {
+      size_t lru = 0;
+      for (size_t i = 1; i < h->graphs.size(); ++i)
+        if (h->graphs[i].used < h->graphs[lru].used) lru = i;
+      // an executable that is still queued on a stream must not be destroyed under it
+      FH_CHECK_HIP(hipStreamSynchronize(s));
+      (void)hipGraphExecDestroy(h->graphs[lru].exec);
+      h->graphs.erase(h->graphs.begin() + lru);
+    }
+    h->graphs.push_back({key, exec, 0});
+    hit = &h->graphs.back();
   }
-  FH_CHECK_HIP(hipGraphLaunch(it->second, s));
+  hit->used = ++h->graph_clock;
+  FH_CHECK_HIP(hipGraphLaunch(hit->exec, s));
   return FLOAT_OK;
 }
 
@@ -782,14 +783,16 @@ int window_impl(float_fmt* h, const float* x0, const float* wa, const float* wr,
              m.bc * h->ntok);
   int rc = stage_window<T>(h, m, x0, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s);
   if (rc) return rc;
-  const int nev = n_evals(h->method, nfe);
-  if (nev >= 1 && nev <= kScSteps) {
-    const int M = m.bc * h->ntok;
-    hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * h->D / 8 + 255) / 256, nev), dim3(256), 0, s, h->sc16, h->temb,
-                       h->ccond, M, h->D, (size_t)h->Mpad * h->D);
-  }
   if (nfe <= 1) return FLOAT_OK;  // a one-point grid has no evaluation: the sample is x0 (FLOAT.py:188,247-248)
-  if (h->cfg.use_graph && !g_fh_profiling) return run_window_steps_graph<T>(h, m, we_len, nfe, ts, a, r, e, s);
+  // A caller that is itself capturing `s` gets the chain launched straight into its capture (a graph cannot be launched or
+  // captured from inside another capture); so does the profiling pass, whose events need eager launches.
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess) {
+    (void)hipGetLastError();
+    cs = hipStreamCaptureStatusNone;
+  }
+  if (h->cfg.use_graph && !g_fh_profiling && cs == hipStreamCaptureStatusNone)
+    return run_window_steps_graph<T>(h, m, we_len, nfe, ts, a, r, e, s);
   return run_window_steps<T>(h, m, nfe, ts, a, r, e, s);
 }
 
@@ -797,8 +800,9 @@ template <class T>
 int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const float* wr, const float* we, int we_len,
               const float* prev_x, const float* prev_wa, const float* prev_we, float a, float r, float e, int include_r,
               float* out, hipStream_t s) {
-  std::vector<float> ts(1, t);
-  int rc = prepare_time<T>(h, ts, s);
+  TimeSpec tsp{};
+  tsp.t = t;
+  int rc = prepare_time<T>(h, tsp, 1, s);
   if (rc) return rc;
   const CfgMode m = cfg_mode(a, r, e, include_r);
   // only the all-rows-per-workgroup head (FLOAT_FMT_NO_TOKBLK, a debugging aid) is limited to 15 row tiles
@@ -806,8 +810,8 @@ int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const floa
              "%d-way CFG of %d tokens is %d rows; the all-rows CFG epilogue GEMM holds at most 240 (15 row tiles)", m.bc, h->ntok,
              m.bc * h->ntok);
   if ((rc = stage_window<T>(h, m, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s))) return rc;
-  if ((rc = run_mod<T>(h, m.bc, 0, h->mod, s, false))) return rc;
-  if ((rc = run_blocks<T>(h, m.bc, h->mod, false, 0.f, a, r, e, s))) return rc;
+  if ((rc = run_mod_all<T>(h, m.bc, 0, 1, s))) return rc;
+  if ((rc = run_blocks<T>(h, m.bc, h->modall, false, 0.f, a, r, e, s))) return rc;
   FH_CHECK_HIP(hipMemcpyAsync(out, h->vout, (size_t)h->ntok * h->cfg.dim_w * sizeof(float), hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
 }
@@ -821,9 +825,7 @@ int sample_window(float_fmt* h, int k, hipStream_t s) {
   const bool dynamic = J.we_len > 1;
   int rc;
   if (k == 0) {
-    std::vector<float> ets;
-    eval_times(h->method, J.ts, &ets);
-    if ((rc = prepare_time<T>(h, ets, s))) return rc;
+    if ((rc = prepare_time<T>(h, time_spec(h->method, J.nfe), std::max(1, n_evals(h->method, J.nfe)), s))) return rc;
     // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
     FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)P * c.dim_w * sizeof(float), s));
     FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)P * c.dim_a * sizeof(float), s));
@@ -949,6 +951,22 @@ int fmt_gemm_run(int dtype, int epi, GemmArgs g, hipStream_t s) {
   return dtype == FLOAT_DT_BF16 ? gemm_run_t<BF16>(epi, g, s) : gemm_run_t<FP16>(epi, g, s);
 }
 
+template <class T>
+static int debug_impl(float_fmt* h, int what, const float* in, float* out, hipStream_t s) {
+  const int D = h->D, ntok = h->ntok;
+  if (what == 0) {
+    FH_CHECK_HIP(hipMemcpyAsync(out, h->pos, (size_t)ntok * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return FLOAT_OK;
+  }
+  FH_REQUIRE(what == 1 && in != nullptr, "float_fmt_debug: unknown request %d (or null input)", what);
+  const int n = ntok * 3 * D;
+  hipLaunchKernelGGL((fmt_dbg_to16_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->qkv16, in, n);
+  launch_attn<T>(h, ntok, nullptr, s);
+  hipLaunchKernelGGL((fmt_dbg_unpack_kernel<T>), dim3((ntok * D + 255) / 256), dim3(256), 0, s, out, h->att16, ntok, D);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
 extern "C" {
 
 int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors, float_fmt_t** out) {
@@ -975,6 +993,8 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (const char* v = getenv("FLOAT_FMT_FULL_NW")) g_fmt_full_nw = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
+  if (const char* v = getenv("FLOAT_FMT_HOIST")) g_fmt_hoist = atoi(v) != 0;
+  if (const char* v = getenv("FLOAT_FMT_ZGROUP")) g_fmt_zgroup = std::max(1, atoi(v));
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
     sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],
            &g_fmt_plan_override[3], &g_fmt_plan_override[4], &g_fmt_plan_override[5]);
@@ -998,14 +1018,15 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->tsin16, (size_t)kMaxSteps * 256);
   A(&h->th16, (size_t)kMaxSteps * D);
   A(&h->ccond, (size_t)Mp * D);
-  A(&h->mod, (size_t)Mp * h->Ntot);
-  A(&h->mod2, (size_t)Mp * h->Ntot);
+  // modulations of a batch of evaluations (run_mod_all): never zero-filled or read before written, up to 3.1 GB at the
+  // default shape (64 x 240 x 51 200 fp32) of the 288 GB
+  h->Mmod = 16 * ((4 * h->ntok + 15) / 16);
+  if (!rc) rc = h->pool.alloc(&h->modall, (size_t)kScSteps * h->Mmod * h->Ntot, false);
   A(&h->kbuf, (size_t)4 * kMaxTok * cfg->dim_w);
   A(&h->xres, (size_t)Mp * D);
   A(&h->slab, (size_t)4 * Mp * D);
   A(&h->xcur, (size_t)cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
-  A(&h->ts_dev, (size_t)kMaxSteps);
   A(&h->vout, (size_t)kMaxTok * cfg->dim_w);
   A(&h->wa_c, (size_t)cfg->n_cur * cfg->dim_a);
   A(&h->we_c, (size_t)cfg->n_cur * cfg->dim_e);
@@ -1045,10 +1066,8 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
 
 void float_fmt_destroy(float_fmt_t* h) {
   if (!h) return;
-  for (auto& kv : h->graphs) (void)hipGraphExecDestroy(kv.second);
+  for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
-  if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
-  for (hipEvent_t e2 : h->events) (void)hipEventDestroy(e2);
   h->pool.release();
   delete h;
 }
@@ -1087,18 +1106,24 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
   }
   const float* we_p = we_len > 1 ? h->we_c : we;
   const float* pwe_p = we_len > 1 ? h->prev_we : nullptr;
-  std::vector<float> ets;
-  eval_times(h->method, ts, &ets);
+  const TimeSpec tsp = time_spec(h->method, nfe);
+  const int nev = std::max(1, n_evals(h->method, nfe));
   if (c.dtype == FLOAT_DT_BF16) {
-    if ((rc = prepare_time<BF16>(h, ets, s))) return rc;
+    if ((rc = prepare_time<BF16>(h, tsp, nev, s))) return rc;
     rc = window_impl<BF16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
   } else {
-    if ((rc = prepare_time<FP16>(h, ets, s))) return rc;
+    if ((rc = prepare_time<FP16>(h, tsp, nev, s))) return rc;
     rc = window_impl<FP16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
   }
   if (rc) return rc;
   FH_CHECK_HIP(hipMemcpyAsync(out, h->xcur, (size_t)c.n_cur * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
+}
+
+int float_fmt_debug(float_fmt_t* h, int32_t what, const float* in, float* out, void* stream) {
+  FH_REQUIRE(h != nullptr && out != nullptr, "null argument to float_fmt_debug");
+  return h->cfg.dtype == FLOAT_DT_BF16 ? debug_impl<BF16>(h, what, in, out, (hipStream_t)stream)
+                                       : debug_impl<FP16>(h, what, in, out, (hipStream_t)stream);
 }
 
 int float_fmt_set_method(float_fmt_t* h, int32_t method) {

@@ -274,16 +274,38 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int nbx = g.N >> 7;
-  int bx, by;
+  int bx, by, bz = 0;
   {
     const int id = blockIdx.x;
-    if ((nbx & 7) == 0) {
-      const int slot = id >> 3;
-      by = slot % g.mblk;
-      bx = (slot / g.mblk) * 8 + (id & 7);
+    const int nz = g.zcount > 1 ? g.zcount : 1;
+    if (nz > 1 && (nbx & 7) == 0 && g.zgroup > 1) {
+      // Batched over the Euler steps of a window (the hoisted adaLN projection): ids congruent mod 8 share an XCD's L2.
+      // An XCD walks groups of `zgroup` column blocks; inside a group the step runs slowest and the column blocks fastest, so
+      // the ~32 workgroups in flight on the XCD are (32 / zgroup) steps x zgroup column blocks: the group's weight slabs
+      // (262 KB each) stay in L2 for the whole group and every activation tile (393 KB) is fetched from the Infinity Cache
+      // once per group instead of once per column block.  The last group of an XCD may be narrower.
+      const int slot = id >> 3, G = g.zgroup, ncx = nbx >> 3, rows = g.mblk * nz;
+      const int full = ncx / G, per_grp = G * rows;
+      int grp = slot / per_grp, rem = slot - grp * per_grp, gw = G;
+      if (grp >= full) {
+        grp = full;
+        rem = slot - full * per_grp;
+        gw = ncx - full * G;
+      }
+      const int zy = rem / gw;
+      bz = zy / g.mblk;
+      by = zy - bz * g.mblk;
+      bx = (grp * G + (rem - zy * gw)) * 8 + (id & 7);
+    } else if ((nbx & 7) == 0) {
+      const int slot = id >> 3, zy = slot % (g.mblk * nz);
+      bz = zy / g.mblk;
+      by = zy - bz * g.mblk;
+      bx = (slot / (g.mblk * nz)) * 8 + (id & 7);
     } else {
       bx = id % nbx;
-      by = id / nbx;
+      const int zy = id / nbx;
+      bz = zy / g.mblk;
+      by = zy - bz * g.mblk;
     }
   }
   const int mt0 = by * MTW;
@@ -292,7 +314,8 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
   const int nchunk = KB / KCH;
   const size_t tstride = (size_t)KB * 512;
   const u16* Wp = g.W + (size_t)nb0 * tstride + lane * 8;
-  const u16* Ag = g.A + (size_t)mt0 * tstride + lane * 8;
+  const u16* Ag = g.A + (size_t)bz * g.a_zstride + (size_t)mt0 * tstride + lane * 8;
+  float* const outz = g.out_f32 + (size_t)bz * g.o_zstride;
 
   f32x4 acc[MTW][2];
 #pragma unroll
@@ -364,7 +387,7 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
       o.y = acc[i][j][1] + bb.y;
       o.z = acc[i][j][2] + bb.z;
       o.w = acc[i][j][3] + bb.w;
-      *reinterpret_cast<float4*>(g.out_f32 + (size_t)row * g.ldo + n) = o;
+      *reinterpret_cast<float4*>(outz + (size_t)row * g.ldo + n) = o;
     }
   }
 }
@@ -623,14 +646,34 @@ __global__ void fmt_build_cond_kernel(u16* __restrict__ out, int ld, int bc, int
   }
 }
 
-// Sinusoidal timestep features [cos(t f_k) | sin(t f_k)], k < 128 (FMT.py:118-123).
+// Sinusoidal timestep features [cos(t f_k) | sin(t f_k)], k < 128 (FMT.py:118-123), one row per evaluation of a window.
+// The evaluation times are formed here: grid point i of torch.linspace(0, 1, nfe) in fp32 (symmetric around the midpoint:
+// i * step below it, 1 - (nfe-1-i) * step above), and for a Runge-Kutta scheme with `stages` stages per step
+// t = g_i + c_j (g_{i+1} - g_i) for evaluation s = i * stages + j.  nfe == 0: the single explicit time t0 (float_fmt_eval).
+// Separately rounded multiplies and adds (no fma contraction): the times must equal the host's / torch's bit for bit.
+__device__ __forceinline__ float fmt_linspace01(int i, int n) {
+  if (n <= 1) return 0.f;
+  const float step = __fdiv_rn(1.0f, (float)(n - 1));
+  return (i < n / 2) ? __fmul_rn(step, (float)i) : __fsub_rn(1.0f, __fmul_rn(step, (float)(n - 1 - i)));
+}
 template <class T>
-__global__ void fmt_tsin_kernel(u16* __restrict__ out, const float* __restrict__ ts, const float* __restrict__ freqs,
-                                int n_steps) {
+__global__ void fmt_tsin_kernel(u16* __restrict__ out, const float* __restrict__ freqs, int n_steps, float t0, int nfe,
+                                int stages, float c0, float c1, float c2, float c3) {
   const int s = blockIdx.x;
   if (s >= n_steps) return;
+  float t = t0;
+  if (nfe > 0) {
+    const int i = s / stages, j = s - i * stages;
+    const float gi = fmt_linspace01(i, nfe);
+    t = gi;
+    if (j > 0) {
+      const float cj = j == 1 ? c1 : (j == 2 ? c2 : c3);
+      t = __fadd_rn(gi, __fmul_rn(__fsub_rn(fmt_linspace01(i + 1, nfe), gi), cj));
+    }
+  }
+  (void)c0;
   const int k = threadIdx.x;  // 0..255
-  const float arg = ts[s] * freqs[k & 127];
+  const float arg = t * freqs[k & 127];
   out[fmt_pack_off(s, k, 8)] = T::from_float(k < 128 ? cosf(arg) : sinf(arg));
 }
 
@@ -701,4 +744,18 @@ __global__ void fmt_slice_pad_kernel(float* __restrict__ dst, const float* __res
   const int i = idx / dim, c = idx % dim;
   const int t = min(t0 + i, T - 1);
   dst[idx] = src[(size_t)t * dim + c];
+}
+
+// Test hook (float_fmt_debug): fp32 rows -> the row-major 16-bit q|k|v operand of fmt_attn_kernel, and its packed output back.
+template <class T>
+__global__ void fmt_dbg_to16_kernel(u16* __restrict__ dst, const float* __restrict__ src, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = T::from_float(src[i]);
+}
+template <class T>
+__global__ void fmt_dbg_unpack_kernel(float* __restrict__ dst, const u16* __restrict__ src, int rows, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * D) return;
+  const int r = i / D, c = i - r * D;
+  dst[i] = T::to_float(src[fmt_pack_off(r, c, D / 32)]);
 }

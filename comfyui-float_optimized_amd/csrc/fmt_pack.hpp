@@ -82,6 +82,10 @@ struct GemmArgs {
   int ksplit;
   size_t slab_stride;
   TouchSpec touch;  // weights of a later GEMM to pull into L2 (W == nullptr: none)
+  // fmt_gemm_wide_kernel only: `zcount` independent row batches (the Euler steps of a window) against the same weights in one
+  // launch; batch z reads A + z * a_zstride (elements) and writes out_f32 + z * o_zstride (elements).  0 / 1 = a single batch.
+  int zcount, zgroup;  // zgroup: column blocks of an XCD that share their activation tiles through L2 (block decode)
+  size_t a_zstride, o_zstride;
   // EPI_CFG: rows are token-blocked, row = (i / 16) * (bc * 16) + b * 16 + i % 16 for token i, CFG row b, so a workgroup
   // with bc row tiles holds every CFG row of its 16 tokens (else: row = b * ntok + i and the workgroup holds all rows)
   int tokblk;

@@ -39,6 +39,27 @@ class FlowMatchingTransformerHIP:
         native.check(native.lib().float_fmt_set_method(self._h, native.ODE_METHODS[name]))
         self.method = name
 
+    # ------------------------------------------------------------------ test hooks (float_fmt_debug)
+    @torch.no_grad()
+    def pos_embed_in_use(self):
+        """(n_tokens, dim_h): the positional table the operator adds (checkpoint's or regenerated, FMT.py:22-40,249-250)."""
+        out = torch.empty(self.cfg.n_tokens, self.cfg.dim_h, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_fmt_debug(self._h, 0, None, native.dev_ptr(out), native.stream_ptr(self.device)))
+        return out
+
+    @torch.no_grad()
+    def attention_probe(self, qkv):
+        """qkv (n_tokens, 3*dim_h) = [q | k | v] -> (n_tokens, dim_h): the chain's banded attention kernel on caller data."""
+        qkv = self._f(qkv)
+        if qkv.shape != (self.cfg.n_tokens, 3 * self.cfg.dim_h):
+            raise ValueError("qkv must be (%d,%d)" % (self.cfg.n_tokens, 3 * self.cfg.dim_h))
+        out = torch.empty(self.cfg.n_tokens, self.cfg.dim_h, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_fmt_debug(self._h, 1, native.dev_ptr(qkv), native.dev_ptr(out),
+                                                      native.stream_ptr(self.device)))
+        return out
+
     def close(self):
         if getattr(self, "_h", None) and native is not None:  # `native` is None during interpreter shutdown
             native.lib().float_fmt_destroy(self._h)

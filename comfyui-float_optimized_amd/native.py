@@ -53,6 +53,7 @@ _SIGNATURES = {
     "float_fmt_create": (C.c_int, [C.POINTER(FmtCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_fmt_destroy": (None, [C.c_void_p]),
     "float_fmt_set_method": (C.c_int, [C.c_void_p, C.c_int32]),
+    "float_fmt_debug": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "float_fmt_eval": (C.c_int, [C.c_void_p, C.c_float] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 +
                        [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "float_fmt_sample_chunk": (C.c_int, [C.c_void_p] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 +

@@ -29,15 +29,16 @@ def _randn(seed, name, shape, std=1.0):
 
 def sinusoid_table(n_pos, d_hid):
     """pos_embed[p, j] = sin/cos(p / 10000^(2*(j//2)/d)), even j sin, odd j cos
-    (reference FMT.py:22-40).  Evaluated in float64 then cast, like the reference's
-    python-float list -> torch.Tensor path."""
+    (reference FMT.py:22-40).  The angle is evaluated in float64 then cast, like the reference's
+    python-float list -> torch.Tensor path, and sin / cos are torch's fp32 ones: bit-identical to the
+    reference's table (tests/golden/fmt_tables.npz)."""
     p = np.arange(n_pos, dtype=np.float64)[:, None]
     j = np.arange(d_hid, dtype=np.float64)[None, :]
-    ang = (p / np.power(10000.0, 2.0 * np.floor(j / 2.0) / d_hid)).astype(np.float32)
-    tab = np.empty_like(ang)
-    tab[:, 0::2] = np.sin(ang[:, 0::2])
-    tab[:, 1::2] = np.cos(ang[:, 1::2])
-    return torch.from_numpy(tab)
+    ang = torch.from_numpy((p / np.power(10000.0, 2.0 * np.floor(j / 2.0) / d_hid)).astype(np.float32))
+    tab = ang.clone()
+    tab[:, 0::2] = torch.sin(ang[:, 0::2])
+    tab[:, 1::2] = torch.cos(ang[:, 1::2])
+    return tab
 
 
 def band_mask(n, window):

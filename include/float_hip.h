@@ -62,8 +62,9 @@ typedef struct {
   int32_t n_prev, n_cur;   /* num_prev_frames, int(wav2vec_sec*fps); n_prev + n_cur <= 80 */
   int32_t attn_window;     /* |i-j| <= window is visible (FMT.py:15-19) */
   int32_t dtype;           /* FLOAT_DT_* */
-  int32_t use_graph;       /* 0: eager launches; 1: replay each window's chain from a cached hipGraph with
-                              the adaLN GEMM of step i+1 on a parallel branch; 2: graph, single branch */
+  int32_t use_graph;       /* 0: eager launches; != 0: replay each window's chain from a cached hipGraph (at most 8
+                              graphs per handle, least recently used evicted).  1 and 2 are the same (1 used to put the
+                              adaLN GEMM on a parallel branch; that GEMM now runs once per window, not per step). */
 } float_fmt_cfg_t;
 
 typedef struct float_fmt float_fmt_t;
@@ -112,6 +113,19 @@ int float_fmt_sample_begin(float_fmt_t* h, const float* wr, const float* wa, int
                            int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg,
                            float e_cfg, int32_t include_r_cfg, float* r_d);
 int float_fmt_sample_next(float_fmt_t* h, void* stream, int32_t* window_done, int32_t* windows_left);
+
+/* Stream capture: every float_fmt_* run-time call may be issued while `stream` is being captured by the caller
+ * (hipStreamBeginCapture); the chain is then launched straight into that capture instead of replaying the handle's own
+ * graph, and no host memory is read by the stream (evaluation times are formed on the device).
+ *
+ * Test hook for the two tables the model builds instead of loading (FMT.py:15-40, 234-236, 249-250):
+ *   what = 0: out (n_prev + n_cur, dim_h) = the positional table the handle adds in x_embedder (the checkpoint's
+ *             `pos_embed` when given, else regenerated: nodes_vadv_loader.py:822-840), `in` unused;
+ *   what = 1: the attention kernel of the chain on caller data: in (n_prev + n_cur, 3 * dim_h) = [q | k | v] rows of one
+ *             CFG row, out (n_prev + n_cur, dim_h) = softmax(q k^T / sqrt(128) + band mask) v per head; with q = k = 0 and
+ *             one-hot v rows the output shows which keys each query may see (enc_dec_mask, FMT.py:15-19).
+ * in / out are fp32 device pointers. */
+int float_fmt_debug(float_fmt_t* h, int32_t what, const float* in, float* out, void* stream);
 
 /* ---------------------------------------------------------------- decoder --------- */
 typedef struct {
@@ -236,8 +250,8 @@ int float_aud_classify(float_aud_t* h, const float* a, int32_t n_samples, float*
 int float_hip_abi_version(void);
 const char* float_last_error(void);
 /* Average device time (ms) of the kernels launched by the last timed call, by class, measured
- * with hipEvents on the caller's stream when profiling is on.  which: 0 = FMT GEMMs,
- * 1 = decoder convs.  Returns <0 when profiling is off. */
+ * with hipEvents on the caller's stream when profiling is on.  which: 0 = FMT GEMMs of the step chain,
+ * 1 = decoder convs, 2 = the once-per-window adaLN modulation GEMM of the FMT.  Returns <0 when profiling is off. */
 /* A HIP stream restricted to CUs [cu_begin, cu_end) (hipExtStreamCreateWithCUMask).  Used to run the FMT
  * chain and the decoder concurrently on disjoint CU sets (pipeline.generate(overlap="cu")). */
 int float_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream_out);

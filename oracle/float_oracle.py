@@ -74,12 +74,31 @@ def _layernorm(x, eps=1e-6):
     return (x - mu) / torch.sqrt(var + eps)
 
 
+def alignment_mask(n, window):
+    """enc_dec_mask(n, n, 1, expansion=window) (FMT.py:15-19, registered at 234-236): True = blocked.  Row i leaves
+    columns max(0, i - window) .. i + window open, i.e. blocks |i - j| > window.  Pinned by fmt_tables.npz."""
+    i = torch.arange(n)
+    return (i[:, None] - i[None, :]).abs() > window
+
+
+def sinusoid_table(n_position, d_hid):
+    """get_sinusoid_encoding_table (FMT.py:22-40, copied into pos_embed at 249-250): angle(p, j) = p / 10000^(2 (j//2) / d)
+    evaluated in python floats (float64), cast to fp32 by torch.Tensor(...), then sin on even / cos on odd columns in fp32.
+    Pinned bit for bit by fmt_tables.npz."""
+    p = torch.arange(n_position, dtype=torch.float64)[:, None]
+    j = torch.arange(d_hid, dtype=torch.float64)[None, :]
+    ang = (p / torch.pow(torch.tensor(10000.0, dtype=torch.float64), 2.0 * torch.floor(j / 2.0) / d_hid)).float()
+    tab = ang.clone()
+    tab[:, 0::2] = torch.sin(ang[:, 0::2])
+    tab[:, 1::2] = torch.cos(ang[:, 1::2])
+    return tab
+
+
 def band_attention(q, k, v, window):
     """softmax(q k^T / sqrt(d) + mask) v with mask = -inf where |i-j| > window
     (FMT.py:15-19, 75-80).  q,k,v: (B, H, N, d)."""
     n = q.shape[-2]
-    i = torch.arange(n)
-    blocked = (i[:, None] - i[None, :]).abs() > window
+    blocked = alignment_mask(n, window)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(q.shape[-1])
     s = s.masked_fill(blocked, float("-inf"))
     return torch.softmax(s, dim=-1) @ v
@@ -109,7 +128,10 @@ def fmt_forward(sd, cfg, t, x, wa, wr, we, prev_x, prev_wa, prev_we=None, dtype=
                              "audio latent `wa` time dimension (%d)." % (we.shape[1], n))
     else:
         we = we.expand(-1, n, -1)
-    h = _linear(x, sd, "x_embedder.proj") + cv(sd["pos_embed"])
+    # pos_embed: the checkpoint's when it carries one (the unified file does), else regenerated like the VA loader does
+    # (nodes_vadv_loader.py:822-840 -> FMT.py:249-250)
+    pos = sd["pos_embed"] if "pos_embed" in sd else sinusoid_table(n, sd["x_embedder.proj.weight"].shape[0])[None]
+    h = _linear(x, sd, "x_embedder.proj") + cv(pos)
     c = torch.cat([wr[:, None, :].expand(-1, n, -1), wa, we], dim=-1)
     c = te + _linear(c, sd, "c_embedder")
     sc = _silu(c)

@@ -39,7 +39,7 @@ def test_eval_golden(tag, dtype):
 def test_sample_golden(tag):
     g = golden("fmt_sample_" + tag)
     cfg = C.FmtConfig() if tag.startswith("full") else C.small_fmt_config()
-    for use_graph in (0, 2, 1):  # eager, single-branch graph, graph with the adaLN GEMM on a parallel branch
+    for use_graph in (0, 2, 1):  # eager, hipGraph replay (1 and 2 are the same since the adaLN GEMM left the step)
         sd, fmt = _fmt(cfg, g["seed"], "bf16", use_graph)
         r_d = fmt.sample(g["r_s"], g["wa"], g["we"], g["noise"], g["nfe"], g["a"], 1.0, g["e"]).cpu()
         assert r_d.shape == g["r_d"].shape

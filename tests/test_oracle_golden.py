@@ -39,6 +39,22 @@ def test_fmt_sample(tag):
     assert rel_l2(r_d, g["r_d"]) < TOL_REL
 
 
+@pytest.mark.parametrize("tag,windows", [("config2", 1), ("config5", 2)])
+def test_fmt_sample_full_length_prefix(tag, windows):
+    """The full-length reference runs (250 / 750 frames at 50 evaluations per window) are 25 / 75 s of oracle time; the AR
+    chain is causal, so the oracle is held to their first window(s) - config5's second window covers the dynamic-emotion
+    prev_we hand-off at the headline grid - and the HIP path to the whole clips (tests/test_configs_gpu.py)."""
+    from tests.util import sample_inputs
+    g = golden("fmt_sample_" + tag)
+    cfg = C.FmtConfig()
+    inp = sample_inputs(cfg, g["seed"], g["T"], bool(g["dynamic"]), g["noise_seed"])
+    n = windows * cfg.num_frames_for_clip
+    we = inp["we"][:, :n] if g["dynamic"] else inp["we"]
+    sd = W.synth_fmt_state(cfg, g["seed"])
+    r_d = O.sample_rd(sd, cfg, inp["r_s"], inp["wa"][:, :n], we, inp["noise"][:windows], g["nfe"], g["a"], 1.0, g["e"])
+    assert rel_l2(r_d, g["r_d"][:, :n]) < TOL_REL
+
+
 def test_dynamic_we_requires_prev_we():
     cfg = C.small_fmt_config()
     sd = W.synth_fmt_state(cfg, 1)

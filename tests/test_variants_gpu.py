@@ -1,7 +1,7 @@
 """The tuned launch variants against the plain ones: the tuning switches are read once per process (static), so each variant runs
 in its own child process and the results are compared here.
-  * FMT: weight touch (FLOAT_FMT_TOUCH) and the token-blocked head GEMM (FLOAT_FMT_NO_TOKBLK) only change WHERE and WHEN work is
-    done - every output element is produced by the same arithmetic in the same order, so r_d must be bitwise identical.
+  * FMT: weight touch (FLOAT_FMT_TOUCH), the token-blocked head GEMM (FLOAT_FMT_NO_TOKBLK) and the hoisting of the adaLN
+    projection out of the Euler step (FLOAT_FMT_HOIST, FLOAT_FMT_ZGROUP) only change WHERE and WHEN work is done - every output element is produced by the same arithmetic in the same order, so r_d must be bitwise identical.
   * decoder: the fused transposed-conv + blur kernel (FLOAT_DEC_ZBLUR_MIN) filters the same fp16-rounded z values as the separate
     kernels; the fp32 filter sums are contracted differently (packed fma), so frames agree to ~80 dB, not bitwise."""
 import os
@@ -54,10 +54,16 @@ def test_fmt_touch_and_token_blocked_head_are_bitwise_neutral(tmp_path):
     base = run_child(tmp_path, "fmt", "plain", {"FLOAT_FMT_TOUCH": "0", "FLOAT_FMT_NO_TOKBLK": "1"})
     tuned = run_child(tmp_path, "fmt", "tuned", {})
     every = run_child(tmp_path, "fmt", "every", {"FLOAT_FMT_TOUCH": "255"})
+    # the adaLN projection per evaluation (one launch per step) instead of once per window (one batched launch): the same
+    # kernel on the same operands; and other XCD groupings of the batched launch
+    per_step = run_child(tmp_path, "fmt", "perstep", {"FLOAT_FMT_HOIST": "0"})
+    grouped = run_child(tmp_path, "fmt", "zgroup", {"FLOAT_FMT_ZGROUP": "3"})
     for k in ("r3", "r4"):
         assert torch.isfinite(base[k]).all()
         assert torch.equal(base[k], tuned[k]), k
         assert torch.equal(base[k], every[k]), k
+        assert torch.equal(base[k], per_step[k]), k
+        assert torch.equal(base[k], grouped[k]), k
 
 
 def test_fused_upsample_matches_separate_kernels(tmp_path):

@@ -63,9 +63,29 @@ def ref_fmt(ns, cfg, seed):
     opt.rank = "cpu"
     m = ns.FMT.FlowMatchingTransformer(opt)
     sd = weights.synth_fmt_state(cfg, seed)
-    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    # pos_embed and alignment_mask stay the REFERENCE's own (FMT.py:15-40, built at 234-236 / 249-250): the goldens
+    # must not be produced with this repo's tables injected into the reference
+    own = {k: v for k, v in sd.items() if k not in ("pos_embed", "alignment_mask")}
+    res = m.load_state_dict(own, strict=False)
+    assert sorted(res.missing_keys) == ["alignment_mask", "pos_embed"] and not res.unexpected_keys, res
     m.eval()
     return m, sd, opt
+
+
+def gen_fmt_tables(ns):
+    """enc_dec_mask (FMT.py:15-19) and get_sinusoid_encoding_table (FMT.py:22-40) of the reference itself for the temporal
+    structures the tests use: (tokens, attention window) = (60,2) default, (45,3), (80,1), (70,2); table width 1024 and 256."""
+    print("[fmt tables]")
+    arrs = {}
+    for ntok, win in ((60, 2), (45, 3), (80, 1), (70, 2)):
+        arrs["mask_%d_%d" % (ntok, win)] = ns.FMT.enc_dec_mask(ntok, ntok, 1, expansion=win)
+    for ntok, d in ((60, 1024), (80, 1024), (45, 256), (70, 512)):
+        arrs["pos_%d_%d" % (ntok, d)] = ns.FMT.get_sinusoid_encoding_table(ntok, d)
+    # and as the model registers them (FMT.py:234-236, 249-250)
+    m, _, _ = ref_fmt(ns, config.FmtConfig(), 1)
+    arrs["model_pos_embed"] = m.pos_embed.data
+    arrs["model_alignment_mask"] = m.alignment_mask
+    save("fmt_tables", **arrs)
 
 
 def fmt_inputs(cfg, seed, dynamic=False):
@@ -118,7 +138,7 @@ def gen_fmt_eval(ns, cfg, tag, seed):
     save("fmt_eval_%s" % tag, **arrs)
 
 
-def gen_fmt_sample(ns, cfg, tag, seed, T, nfe, dynamic, a, e, noise_seed=15):
+def gen_fmt_sample(ns, cfg, tag, seed, T, nfe, dynamic, a, e, noise_seed=15, compact=False):
     print("[fmt sample %s] T=%d nfe=%d dynamic=%s" % (tag, T, nfe, dynamic))
     m, sd, opt = ref_fmt(ns, cfg, seed)
     L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
@@ -145,7 +165,26 @@ def gen_fmt_sample(ns, cfg, tag, seed, T, nfe, dynamic, a, e, noise_seed=15):
             a, 1.0, e, False, g)
     orc = O.sample_rd(sd, cfg, r_s, wa, we, noise, nfe, a, 1.0, e)
     print("  oracle32-ref max|d| %.3e rel %.3e ; |ref| rms %.3f" % (maxdiff(orc, ref) + (float(ref.pow(2).mean().sqrt()),)))
-    save("fmt_sample_%s" % tag, seed=seed, T=T, nfe=nfe, a=a, e=e, wa=wa, r_s=r_s, we=we, noise=noise, r_d=ref)
+    if compact:
+        # full-length configs: inputs are regenerated from the seed by the tests (rnd / softmax / draw_noise above are all
+        # seeded numpy / torch-CPU generators); the fixture holds the reference's r_d only
+        save("fmt_sample_%s" % tag, seed=seed, T=T, nfe=nfe, a=a, e=e, dynamic=int(dynamic), noise_seed=noise_seed, r_d=ref)
+    else:
+        save("fmt_sample_%s" % tag, seed=seed, T=T, nfe=nfe, a=a, e=e, wa=wa, r_s=r_s, we=we, noise=noise, r_d=ref)
+    return dict(m=m, sd=sd, wa=wa, r_s=r_s, we=we, noise=noise, r_d=ref)
+
+
+def gen_config_frames(ns, tag, run, seed, pick):
+    """Frames of a full-length configuration: the reference's decode loop (FLOAT.py:113-169) on picked frames of the
+    reference's own r_d, 512x512; lattice + band + mean like dec_512."""
+    d, dsd = ref_dec(ns, 512, seed)
+    feats = weights.synth_feats(512, seed=seed)
+    s_r = rnd(seed + 4, 1, 512)
+    fake = types.SimpleNamespace(motion_autoencoder=types.SimpleNamespace(dec=d), pbar=types.SimpleNamespace(update=lambda n: None))
+    with torch.no_grad():
+        frames = ns.FLOAT.FLOAT.decode_latent_into_processed_images(fake, s_r, feats, run["r_d"][:, pick])
+    save("frames_%s" % tag, seed=seed, pick=np.array(pick), lattice=frames[:, ::7, ::5], band=frames[:, 250:258],
+         mean=frames.mean(dim=(1, 2, 3)))
 
 
 def ref_dec(ns, size, seed):
@@ -445,8 +484,25 @@ def gen_node_surface_va(ns):
     print("  wrote node_surface_va.json (%d classes)" % len(out))
 
 
+def gen_full_configs(ns):
+    """BASELINE.json configs[1] (10 s, 250 frames, 5 windows x 50 Euler evaluations, static emotion, a=2 e=1) and configs[4]
+    (30 s, 750 frames, 15 windows, per-window dynamic emotion, a=1 e=3) through the reference's own sampler
+    (nodes_adv.py:545-694) and decode loop; ~25 s / ~75 s of CPU."""
+    full = config.FmtConfig()
+    run = gen_fmt_sample(ns, full, "config2", seed=2000, T=250, nfe=51, dynamic=False, a=2.0, e=1.0, compact=True)
+    gen_config_frames(ns, "config2", run, 2000, [0, 124, 249])
+    run = gen_fmt_sample(ns, full, "config5", seed=2100, T=750, nfe=51, dynamic=True, a=1.0, e=3.0, compact=True)
+    gen_config_frames(ns, "config5", run, 2100, [0, 374, 749])
+
+
 def main():
     ns = ref_import.load()
+    if os.environ.get("GOLDENS_ONLY") == "tables":
+        gen_fmt_tables(ns)
+        return
+    if os.environ.get("GOLDENS_ONLY") == "configs":
+        gen_full_configs(ns)
+        return
     if os.environ.get("GOLDENS_ONLY") == "va":
         gen_node_surface_va(ns)
         return
@@ -462,8 +518,9 @@ def main():
         gen_encoder(ns, 64, seed=1000, sparse=False)
         gen_encoder(ns, 512, seed=1100, sparse=True)
         return
-    gen_node_surface(ns)
-    gen_node_surface_va(ns)
+    if os.environ.get("GOLDENS_ONLY") != "fmt":
+        gen_node_surface(ns)
+        gen_node_surface_va(ns)
     if os.environ.get("GOLDENS_ONLY") == "nodes":
         return
     gen_e2e_config1(ns)
@@ -476,6 +533,10 @@ def main():
     gen_fmt_sample(ns, small, "small_static", seed=300, T=125, nfe=5, dynamic=False, a=2.0, e=1.0)
     gen_fmt_sample(ns, small, "small_dynamic", seed=400, T=125, nfe=5, dynamic=True, a=1.0, e=3.0)
     gen_fmt_sample(ns, full, "full_static", seed=500, T=25, nfe=10, dynamic=False, a=2.0, e=1.0)
+    gen_fmt_tables(ns)
+    if os.environ.get("GOLDENS_ONLY") == "fmt":
+        return
+    gen_full_configs(ns)
     gen_dec_units(ns, seed=600)
     gen_dec(ns, 64, seed=700, n_frames=3, sparse=False)
     gen_dec(ns, 512, seed=800, n_frames=2, sparse=True)
