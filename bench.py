@@ -1,70 +1,126 @@
 #!/usr/bin/env python3
-"""Benchmark of the FLOAT hot path on MI355X: FMT Euler sampling loop + Synthesis decoder.
+"""Benchmark of the FLOAT audio -> talking-portrait path on MI355X.
 
-One "step" = one clip: `--seconds` of audio at 25 fps (default 10 s -> 250 frames, BASELINE.json
-configs[1]) sampled with `--nfe` grid points (default 51 = 50 Euler evaluations per 50-frame
-window, 3-way CFG a=2,e=1) and decoded to 512x512 frames that stay in HBM.  Conditioning tensors
-(wa, we, r_s, s_r, feats) and the noise are synthetic and resident in HBM before the timed region.
+One "step" = one clip end to end: a 512x512 portrait and `--seconds` of 16 kHz audio, both resident in HBM, through
+every operator of the path - appearance encoder, wav2vec2 audio encoder, FMT sampling (`--nfe` grid points: default 51 =
+50 Euler evaluations per 50-frame window, 3-way CFG a=2 e=1), Synthesis decoder - to `T` fp32 frames in pinned HOST
+memory (the reference's destination, FLOAT.py:139; every finished batch of frames is copied behind its last kernel).  `value` = frames of all ranks / wall-clock of the timed steps.  The FMT sampling + decode part alone (frames left
+in HBM: round 1's headline) is reported beside it as `hot_path`.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, each decoding its own clip (BASELINE.json configs[3], replicas, weak
-scaling); `--mode shard` instead shards ONE N x `--seconds` clip by audio window (configs[2]).
-Prints ONE JSON line on rank 0.
+N > 1 without a launcher: this process starts N ranks itself (one per GPU, before it touches a GPU) and relays rank 0's line.
+Modes for N > 1: `replicas` one clip per GPU (BASELINE.json configs[3], weak scaling, no communication); `shard` ONE
+N x `--seconds` clip, latent chain replicated, frames sharded (exact); `window` windows sharded with an RCCL all_gather of
+boundary latents (configs[2]; approximate unless --window-iters = N-1).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from tests.util import load_pkg  # noqa: E402
 
 # SURVEY.md section 8(d) algorithmic work per unit
-FMT_WEIGHT_BYTES_PER_EVAL = 313.4e6   # bf16 weights streamed once per evaluation
+FMT_WEIGHT_BYTES_PER_EVAL = 313.4e6    # every 16-bit weight of the FMT once
+FMT_ADALN_WEIGHT_BYTES = 51200 * 1024 * 2.0  # of which the fused adaLN projection: now read once per WINDOW, not per evaluation
 FMT_FLOP_PER_EVAL_CFG3 = 55.87e9
 DEC_FLOP_PER_FRAME = 37.79e9
-HBM_PEAK_GBS = 8000.0                 # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
-MFMA_PEAK_TFLOPS = 2500.0             # dense bf16/fp16
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+MFMA_PEAK_TFLOPS = 2500.0              # dense bf16/fp16
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--nfe", type=int, default=51, help="Euler grid points; evaluations = nfe-1")
     ap.add_argument("--size", type=int, default=512)
-    ap.add_argument("--fmt-dtype", default="bf16")
+    ap.add_argument("--fmt-dtype", default="fp16", help="MFMA operand type of the FMT (fp32 accumulate): fp16 holds the stated "
+                    "tolerance (>= 40 dB frames vs the reference); bf16 = BASELINE.json's wording, same speed, 34 dB")
     ap.add_argument("--dec-dtype", default="fp16")
     ap.add_argument("--max-frames", type=int, default=32)
-    ap.add_argument("--mode", default="replicas", choices=["replicas", "shard", "window"],
-                    help="N>1: replicas = one clip per GPU (exact); shard = one N x clip, latent chain replicated, frames "
-                         "sharded (exact); window = one N x clip, windows sharded, RCCL all_gather of boundary latents + "
-                         "re-solve (approximate unless --window-iters = N-1)")
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "shard", "window"])
     ap.add_argument("--window-iters", type=int, default=1)
-    ap.add_argument("--dynamic-we", action="store_true", help="BASELINE configs[4]: per-window emotion")
+    ap.add_argument("--dynamic-we", action="store_true", help="BASELINE configs[4]: per-window emotion, a=1 e=3")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--graph-mode", type=int, default=2, help="2: single-branch hipGraph per window, 1: adaLN GEMM on a parallel branch")
-    ap.add_argument("--fmt-priority", type=int, default=-1)
-    ap.add_argument("--cu-split", type=int, default=0, help="with --overlap: FMT chain on CUs [0,N), decoder on the rest")
-    ap.add_argument("--overlap", action="store_true", help="pipeline FMT sampling of window k+1 with the decode of window k on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--d2h", action="store_true", help="also time the copy of the frames to host memory")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stage split / hot-path side numbers")
     return ap.parse_args()
 
 
-def cpu_baseline(pkg, cfg, fmt_sd, dec_sd, feats, cond, nfe_evals):
-    """The oracle (a port of the reference's torch-CPU path) on this host's cores, bounded sample:
-    a few CFG evaluations of the FMT and a few decoded frames; fps = 1 / (evals/frame * t_eval + t_frame)."""
+# ----------------------------------------------------------------------------------------------- N > 1 self-launch
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n):
+    """Start n fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this process
+    makes any GPU call, wait for all of them, relay rank 0's output.  Exit code != 0 if any rank failed or fewer than n
+    joined (a rank that cannot join the rendezvous exits non-zero by itself)."""
+    env = dict(os.environ)
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].communicate()[0].decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        sys.exit(1)
+    line = [l for l in out0.splitlines() if l.startswith("{")]
+    if not line or json.loads(line[-1]).get("n_gpus") != n:
+        sys.stderr.write("bench.py: expected a result line with n_gpus=%d\n" % n)
+        sys.exit(1)
+    sys.exit(0)
+
+
+def source_hash():
+    """Identity of the kernels a profile summary belongs to: sha256 over the HIP sources (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "comfyui-float_optimized_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_profile_json(name, warnings):
+    """A committed rocprofv3 summary (profiles/<name>), or None when absent or taken on other kernel sources."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return None
+    if d.get("source_hash") != source_hash():
+        warnings.append("profiles/%s was taken on kernel sources %s, this build is %s: counter-derived fields are null"
+                        % (name, d.get("source_hash"), source_hash()))
+        return None
+    return d
+
+
+def cpu_baseline(pkg, torch, cfg, fmt_sd, dec_sd, feats, cond, nfe_evals):
+    """The oracle (a port of the reference's torch-CPU path) on this host's cores, bounded sample: a few CFG evaluations of
+    the FMT and a few decoded frames; fps = 1 / (evals/frame * t_eval + t_frame)."""
     from oracle import float_oracle as O
     n_threads = torch.get_num_threads()
     L = cfg.num_frames_for_clip
@@ -85,12 +141,19 @@ def cpu_baseline(pkg, cfg, fmt_sd, dec_sd, feats, cond, nfe_evals):
     evals_per_frame = nfe_evals / float(L)
     fps = 1.0 / (evals_per_frame * t_eval + t_frame)
     return {"value": round(fps, 4), "unit": "frames/s", "cores": n_threads, "kind": "port",
-            "sample": "%d CFG-3 FMT evaluations (%.3f s each) + %d decoded 512x512 frames (%.3f s each), fp32 oracle"
-                      % (n_eval, t_eval, n_frames, t_frame)}
+            "sample": "%d CFG-3 FMT evaluations (%.3f s each) + %d decoded 512x512 frames (%.3f s each), fp32 oracle; "
+                      "encoders not included" % (n_eval, t_eval, n_frames, t_frame)}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus)  # never returns
+
+    import numpy as np
+    import torch
+    from tests.util import load_pkg
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,6 +161,7 @@ def main():
     n_dev = max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -105,6 +169,8 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != world:
+            raise RuntimeError("rendezvous gave %d ranks, expected %d" % (dist.get_world_size(), world))
 
     pkg = load_pkg()
     cfg = pkg.config.FmtConfig()
@@ -113,203 +179,196 @@ def main():
     fmt_sd = pkg.weights.synth_fmt_state(cfg, seed=1)
     dec_sd = pkg.weights.synth_decoder_state(args.size, seed=1)
     hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, dev, args.size, args.fmt_dtype, args.dec_dtype,
-                                   args.max_frames, use_graph=0 if args.no_graph else args.graph_mode)
-    hp.fmt_stream_priority = args.fmt_priority
-    hp.cu_split = args.cu_split
-    feats = [f.to(dev) for f in pkg.weights.synth_feats(args.size, seed=1 + rank)]
-    hp.dec.set_feats(feats)
+                                   args.max_frames, use_graph=0 if args.no_graph else 2)
+    enc = pkg.encoder.EncoderHIP(pkg.weights.synth_encoder_state(args.size, seed=1), args.size, cfg.dim_w, 20, dev,
+                                 args.dec_dtype, direction_weight=dec_sd["direction.weight"])
+    acfg = pkg.config.AudioConfig()
+    aud = pkg.audio.AudioEncoderHIP(pkg.weights.synth_audio_state(acfg, seed=1), acfg, dev, args.dec_dtype)
 
-    if args.mode in ("shard", "window") and world > 1:
-        # one long clip of world*T frames; every rank runs the identical (deterministic) latent chain,
-        # then decodes its contiguous frame range - see comfyui-float_optimized_amd/distributed.py
-        T_total = T * world
-        cond = pkg.pipeline.synth_conditions(cfg, T_total, seed=0, dynamic_we=args.dynamic_we, device=dev)
-    else:
-        T_total = T
-        cond = pkg.pipeline.synth_conditions(cfg, T, seed=rank, dynamic_we=args.dynamic_we, device=dev)
+    one_clip = args.mode in ("shard", "window") and world > 1
+    T_total = T * world if one_clip else T
+    # inputs of the step, resident in HBM before the timed region: portrait, waveform, emotion scores, noise
+    img = (torch.from_numpy(np.random.RandomState(0 if one_clip else rank).rand(1, 3, args.size, args.size).astype("float32"))
+           * 2 - 1).to(dev)
+    wav = pkg.weights.synth_waveform(args.seconds * (world if one_clip else 1), seed=1 if one_clip else 1 + rank).to(dev)
+    cond = pkg.pipeline.synth_conditions(cfg, T_total, seed=0 if one_clip else rank, dynamic_we=args.dynamic_we, device=dev)
+    we = cond["we"]
     noise = pkg.fmt.draw_noise(hp.n_chunks(T_total), 1, cfg, seed=15).to(dev)
     a_cfg, e_cfg = (1.0, 3.0) if args.dynamic_we else (2.0, 1.0)
-
+    t0f, t1f = pkg.distributed.frame_shard(T_total, world, rank) if (args.mode == "shard" and world > 1) else (0, T_total)
+    if args.mode == "window" and world > 1:
+        L = cfg.num_frames_for_clip
+        w0, w1 = pkg.distributed.window_shard(hp.n_chunks(T_total), world, rank)
+        t0f, t1f = w0 * L, min(T_total, w1 * L)
+    n_local = t1f - t0f
+    host = torch.empty(n_local, args.size, args.size, 3, dtype=torch.float32, pin_memory=True)
+    staging = torch.empty(n_local, args.size, args.size, 3, dtype=torch.float32, device=dev)
     seam = {}
 
+    def conditioning():
+        s_r, _, _, r_s = enc.encode_image_into_latent(img, want_feats=False)
+        enc.hand_feats_to(hp.dec)
+        wa = aud.inference(wav, seq_len=T_total)
+        return s_r, r_s, wa
+
     def step():
+        """(image, waveform) in HBM -> this rank's frames in pinned host memory."""
+        s_r, r_s, wa = conditioning()
         if args.mode == "window" and world > 1:
-            r_loc, (t0, t1), rep = pkg.distributed.sample_window_parallel(
-                hp.fmt, cfg, cond["r_s"], cond["wa"], cond["we"], noise, args.nfe, a_cfg, 1.0, e_cfg, iters=args.window_iters)
+            r_loc, _, rep = pkg.distributed.sample_window_parallel(hp.fmt, cfg, r_s, wa, we, noise, args.nfe, a_cfg, 1.0, e_cfg,
+                                                                   iters=args.window_iters)
             seam.update(rep)
-            if world > 1:  # report the largest seam change over the ranks
-                import torch.distributed as dist
-                t = torch.tensor([rep["seam_rel_change"]], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                seam["seam_rel_change"] = float(t.item())
-            return hp.decode(cond["s_r"], None, r_loc)
-        fr = (rank * T, (rank + 1) * T) if (args.mode == "shard" and world > 1) else None
-        return hp.generate(cond["r_s"], cond["wa"], cond["we"], cond["s_r"], None, args.nfe, a_cfg, 1.0, e_cfg, noise=noise,
-                           overlap=args.overlap, frame_range=fr)
+            hp.dec.decode_into_host(s_r, r_loc[0], host, staging)
+            return
+        r_d = hp.sample(r_s, wa, we, args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+        hp.dec.decode_into_host(s_r, r_d[0, t0f:t1f], host, staging)
 
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        frames = step()
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        frames = step()
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert frames.shape[1:] == (args.size, args.size, 3) and (args.mode == "window" or frames.shape[0] == T)
-    total_frames = T * world * args.steps
-    fps = total_frames / elapsed
+        if args.mode == "window":
+            t = torch.tensor([float(seam.get("seam_rel_change", 0.0))], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seam["seam_rel_change"] = float(t.item())
+    assert float(host[0].min()) >= 0.0 and float(host[-1].max()) <= 1.0 and float(host.mean()) > 0.0
+    frames_per_step = T_total if one_clip else T * world
+    fps = frames_per_step * args.steps / elapsed
 
-    extra = {}
-    if rank == 0:
-        # stage split (one more step, not part of `value`)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        ev[0].record()
-        r_d = hp.sample(cond["r_s"], cond["wa"], cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
-        ev[1].record()
-        fr = hp.decode(cond["s_r"], None, r_d, (0, T))
-        ev[2].record()
-        torch.cuda.synchronize()
-        extra["stage_ms"] = {"fmt_sample": round(ev[0].elapsed_time(ev[1]), 3), "decode": round(ev[1].elapsed_time(ev[2]), 3)}
-        try:
-            # once-per-clip host-side stage (PyTorch-ROCm, not part of `value`): appearance encoder + Direction +
-            # wav2vec2-base audio encoder with random weights on synthetic image/audio (SURVEY.md 8d inputs)
-            enc = pkg.encoder.EncoderHIP(pkg.weights.synth_encoder_state(args.size, seed=1), args.size, cfg.dim_w, 20, dev,
-                                         args.dec_dtype, direction_weight=dec_sd["direction.weight"])
-            acfg = pkg.config.AudioConfig()
-            aud = pkg.audio.AudioEncoderHIP(pkg.weights.synth_audio_state(acfg, seed=1), acfg, dev, args.dec_dtype)
-            img = torch.rand(1, 3, args.size, args.size, device=dev) * 2 - 1
-            wav = pkg.weights.synth_waveform(args.seconds, seed=1).to(dev)
-
-            def timed(fn):
-                fn()
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                fn()
-                torch.cuda.synchronize()
-                return round((time.perf_counter() - t1) * 1e3, 3)
-
-            def enc_stage():  # image -> s_r, r_s, skip features into the decoder (HIP operator float_enc_*)
-                enc.encode_image_into_latent(img, want_feats=False)
-                enc.hand_feats_to(hp.dec)
-
-            def aud_stage():  # waveform -> wa (T, 512): wav2vec2-base + audio projection (HIP operator float_aud_*)
-                aud.inference(wav, seq_len=T)
-            extra["stage_ms"]["appearance_encoder_hip"] = timed(enc_stage)
-            extra["stage_ms"]["audio_encoder_hip"] = timed(aud_stage)
-
-            # SURVEY.md 8(d) wall-clock definition, reported beside `value` (never as it): (image, waveform) in HBM ->
-            # frames in pinned host memory through every operator of the path, one clip
-            host = torch.empty(T, args.size, args.size, 3, dtype=torch.float32, pin_memory=True)
-
-            def end_to_end():
-                s_r, _, _, r_s = enc.encode_image_into_latent(img, want_feats=False)
-                enc.hand_feats_to(hp.dec)
-                wa = aud.inference(wav, seq_len=T)
-                r_d2 = hp.sample(r_s, wa, cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
-                host.copy_(hp.decode(s_r, None, r_d2, (0, T)))
-            e2e_ms = timed(end_to_end)
-            extra["end_to_end"] = {"ms_per_clip": e2e_ms, "frames_per_s": round(T / (e2e_ms * 1e-3), 1),
-                                   "includes": "appearance encoder + audio encoder + FMT sampling + decode + D2H of the frames (pinned)"}
-            hp.dec.set_feats(feats)  # restore the bench's synthetic features
-            del aud, enc, host
-        except Exception as e:  # conditioning is plumbing; never fail the bench for it
-            extra["stage_ms"]["conditioning"] = "n/a (%s: %s)" % (type(e).__name__, e)
-        if args.d2h:
-            host = torch.empty(fr.shape, dtype=torch.float32, pin_memory=True)
-            t1 = time.perf_counter()
-            host.copy_(fr)
+    extra, warnings = {}, []
+    if rank == 0 and not args.no_extras:
+        def ev_ms(fn, reps=3):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
-            extra["stage_ms"]["d2h"] = round((time.perf_counter() - t1) * 1e3, 3)
-            extra["fps_incl_d2h"] = round(T / ((extra["stage_ms"]["fmt_sample"] + extra["stage_ms"]["decode"] + extra["stage_ms"]["d2h"]) * 1e-3), 2)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return round(e0.elapsed_time(e1) / reps, 3)
+
+        s_r, r_s, wa = conditioning()
+        keep = {}
+
+        def f_sample():
+            keep["r_d"] = hp.sample(r_s, wa, we, args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+        st = {"appearance_encoder": ev_ms(lambda: (enc.encode_image_into_latent(img, want_feats=False), enc.hand_feats_to(hp.dec))),
+              "audio_encoder": ev_ms(lambda: aud.inference(wav, seq_len=T_total)),
+              "fmt_sample": ev_ms(f_sample)}
+        rd_loc = keep["r_d"][0, t0f:t1f]
+        st["decode"] = ev_ms(lambda: hp.decode(s_r, None, rd_loc))
+        st["decode_and_d2h"] = ev_ms(lambda: hp.dec.decode_into_host(s_r, rd_loc, host, staging))
+        st["d2h_alone"] = ev_ms(lambda: host.copy_(staging, non_blocking=True))
+        extra["stage_ms"] = st
+        hot = st["fmt_sample"] + st["decode"]
+        extra["hot_path"] = {"ms_per_clip": round(hot, 3), "frames_per_s": round(n_local / (hot * 1e-3), 1),
+                             "what": "FMT sampling + decode of this rank's frames, conditioning pre-staged, frames left in HBM"}
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        # Per-launch kernel durations: one more identical step with hipEvents around every launch of
-        # the two dominant kernel classes, recorded on the stream they are launched on (eager launches;
-        # the timed region above replays the same kernels from a hipGraph).
-        n_chunks_rank = hp.n_chunks(T_total)
+        # Per-launch kernel durations: one more identical pass with hipEvents around every launch of the dominant kernel
+        # classes, recorded on the stream they are launched on (eager launches; the timed region replays the same kernels
+        # from a hipGraph).
+        s_r, r_s, wa = conditioning()
         pkg.native.set_profiling(True)
-        r_d = hp.sample(cond["r_s"], cond["wa"], cond["we"], args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
-        hp.decode(cond["s_r"], None, r_d, (0, T))
+        r_d = hp.sample(r_s, wa, we, args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+        hp.decode(s_r, None, r_d[0, t0f:t1f])
         torch.cuda.synchronize()
         g_ms, g_n = pkg.native.profile_ms(0)
         c_ms, c_n = pkg.native.profile_ms(1)
+        m_ms, m_n = pkg.native.profile_ms(2)
         pkg.native.set_profiling(False)
-        n_eval = n_chunks_rank * (args.nfe - 1)
-        gemm_total_ms, conv_total_ms = g_ms * g_n, c_ms * c_n
-        gemm_bytes = FMT_WEIGHT_BYTES_PER_EVAL * n_eval
-        conv_flop = DEC_FLOP_PER_FRAME * T
-        gemm_roof = {"kernel": "fmt_gemm_kernel", "bound": "hbm", "achieved": round(gemm_bytes / (gemm_total_ms * 1e-3) / 1e9, 1),
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "launches": g_n, "avg_launch_us": round(g_ms * 1e3, 2),
+        n_win = hp.n_chunks(T_total)
+        n_eval = n_win * (args.nfe - 1)
+        gemm_total_ms, conv_total_ms, mod_total_ms = g_ms * g_n, c_ms * c_n, m_ms * max(m_n, 0)
+        gemm_bytes = (FMT_WEIGHT_BYTES_PER_EVAL - FMT_ADALN_WEIGHT_BYTES) * n_eval
+        conv_flop = DEC_FLOP_PER_FRAME * n_local
+        mod_flop = 2.0 * (3 * cfg.n_tokens) * 51200 * 1024 * n_eval
+        gemm_roof = {"kernel": "fmt_gemm_kernel (step chain: qkv / proj / fc1 / fc2 / x-embed / head)", "bound": "hbm",
+                     "achieved": round(gemm_bytes / (gemm_total_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "launches": g_n, "avg_launch_us": round(g_ms * 1e3, 2),
                      "algorithmic_bytes_per_launch": round(gemm_bytes / max(g_n, 1)), "traffic": None}
         gemm_roof["frac"] = round(gemm_roof["achieved"] / HBM_PEAK_GBS, 4)
         conv_roof = {"kernel": "dec_conv_kernel", "bound": "mfma", "achieved": round(conv_flop / (conv_total_ms * 1e-3) / 1e12, 2),
                      "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": c_n, "avg_launch_us": round(c_ms * 1e3, 2),
                      "algorithmic_flop_per_launch": round(conv_flop / max(c_n, 1)), "traffic": None}
         conv_roof["frac"] = round(conv_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
-        # HBM traffic per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-        # separate passes, tools/profile_hotpath.py); null when the summary is not there
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            gemm_roof["traffic"] = pmc["fmt_gemm"]["hbm_bytes_per_launch"]
-            conv_roof["traffic"] = pmc["dec_conv"]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-        try:  # MFMA pipe utilisation of the two classes from the committed SQ counter pass (tools/make_mfma_json.py)
-            mf = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_mfma.json")))
-            gemm_roof["mfma_util_pmc"] = mf["fmt_gemm"]["mfma_util"]
-            conv_roof["mfma_util_pmc"] = mf["dec_conv"]["mfma_util"]
-        except Exception:
-            pass
-        roof = (conv_roof, gemm_roof) if conv_total_ms >= gemm_total_ms else (gemm_roof, conv_roof)
-        extra["kernel_class_ms"] = {"fmt_gemm": round(gemm_total_ms, 2), "dec_conv": round(conv_total_ms, 2)}
+        mod_roof = None
+        if m_n > 0:
+            mod_roof = {"kernel": "fmt_gemm_wide_kernel (adaLN projection of all evaluations of a window)", "bound": "mfma",
+                        "achieved": round(mod_flop / (mod_total_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "launches": m_n, "avg_launch_us": round(m_ms * 1e3, 2), "algorithmic_flop_per_launch": round(mod_flop / m_n),
+                        "traffic": None}
+            mod_roof["frac"] = round(mod_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
+        # HBM traffic per launch / MFMA pipe utilisation from the committed rocprofv3 --pmc passes (tools/profile_round.sh),
+        # only when they were taken on these kernel sources
+        pmc = load_profile_json("r02_pmc_traffic.json", warnings)
+        if pmc:
+            gemm_roof["traffic"] = pmc.get("fmt_gemm", {}).get("hbm_bytes_per_launch")
+            conv_roof["traffic"] = pmc.get("dec_conv", {}).get("hbm_bytes_per_launch")
+        mf = load_profile_json("r02_pmc_mfma.json", warnings)
+        if mf:
+            gemm_roof["mfma_util_pmc"] = mf.get("fmt_gemm", {}).get("mfma_util")
+            conv_roof["mfma_util_pmc"] = mf.get("dec_conv", {}).get("mfma_util")
+        roofs = sorted([(gemm_total_ms, gemm_roof), (conv_total_ms, conv_roof)] + ([(mod_total_ms, mod_roof)] if mod_roof else []),
+                       key=lambda x: -x[0])
+        roof = [r for _, r in roofs]
+        extra["kernel_class_ms"] = {"fmt_gemm": round(gemm_total_ms, 2), "dec_conv": round(conv_total_ms, 2),
+                                    "fmt_adaln_gemm": round(mod_total_ms, 2)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(pkg, cfg, fmt_sd, dec_sd, feats, cond, args.nfe - 1)
+        cpu = cpu_baseline(pkg, torch, cfg, fmt_sd, dec_sd, pkg.weights.synth_feats(args.size, seed=1), cond, args.nfe - 1)
 
     if rank == 0:
+        par = ("replicas x%d (one clip per GPU)" % world) if not one_clip else (
+            "shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world) if args.mode == "shard" else
+            "window: one %d-frame clip, windows sharded x%d, boundary all_gather x%d round(s), max seam change %.3e"
+            % (T_total, world, args.window_iters, seam.get("seam_rel_change", 0.0)))
         out = {
-            "metric": "512x512 frames/sec end-to-end audio->video @50 ODE steps (hot path: FMT sampling + decode)",
+            "metric": "512x512 frames/sec end-to-end audio->video @50 ODE steps",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "weak",  # per-GPU work is fixed as N grows: one clip per GPU, or one N-times-longer clip
             "vs_baseline": None,
             "dtype": "%s+%s" % (args.fmt_dtype, args.dec_dtype) if args.fmt_dtype != args.dec_dtype else args.fmt_dtype,
             "data": "synthetic",
-            "config": {"workload": "configs[1]: %.0f s audio -> %d frames %dx%d, %d Euler evaluations/window, CFG a=%.1f e=%.1f%s"
-                                   % (args.seconds, T, args.size, args.size, args.nfe - 1, a_cfg, e_cfg,
-                                      ", dynamic per-window emotion" if args.dynamic_we else ""),
-                       "nfe": args.nfe, "frames_per_clip": T, "fmt_dtype": args.fmt_dtype, "dec_dtype": args.dec_dtype,
-                       "decode_batch": args.max_frames, "hip_graph": not args.no_graph,
-                       "stage_overlap": args.overlap,
-                       "parallelism": ("replicas x%d (one clip per GPU)" % world) if args.mode == "replicas" or world == 1
-                       else ("shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world)
-                             if args.mode == "shard" else
-                             "window: one %d-frame clip, windows sharded x%d, boundary all_gather x%d round(s), max seam change %.3e"
-                             % (T_total, world, args.window_iters, seam.get("seam_rel_change", 0.0)))},
+            "config": {"workload": "configs[%d]: %.0f s audio + %dx%d portrait in HBM -> %d frames in pinned host memory; appearance "
+                                   "encoder + wav2vec2 audio encoder + FMT sampling (%d Euler evaluations/window, CFG a=%.1f e=%.1f%s) "
+                                   "+ decode + D2H"
+                                   % (4 if args.dynamic_we else 1, args.seconds * (world if one_clip else 1), args.size, args.size,
+                                      T_total, args.nfe - 1, a_cfg, e_cfg, ", dynamic per-window emotion" if args.dynamic_we else ""),
+                       "nfe": args.nfe, "frames_per_clip": T_total, "fmt_dtype": args.fmt_dtype, "dec_dtype": args.dec_dtype,
+                       "decode_batch": args.max_frames, "hip_graph": not args.no_graph, "parallelism": par},
         }
         out.update(extra)
         if roof:
             out["roofline"] = roof[0]
             out["roofline_secondary"] = roof[1]
+            if len(roof) > 2:
+                out["roofline_tertiary"] = roof[2]
         if cpu:
             out["cpu_baseline"] = cpu
+        if warnings:
+            out["warnings"] = warnings
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
-        import torch.distributed as dist
         dist.destroy_process_group()
 
 

@@ -57,6 +57,8 @@ struct float_dec {
   u16 *hiA = nullptr, *hiB = nullptr, *hiZ = nullptr;
   float *loFlow[2] = {nullptr, nullptr}, *loRgb[2] = {nullptr, nullptr};
   float *hiFlow[2] = {nullptr, nullptr}, *hiRgb[2] = {nullptr, nullptr};
+  std::vector<hipEvent_t> copy_events;  // float_dec_frames_host: one per high batch in flight, recycled across calls
+  hipEvent_t join_event = nullptr;
 };
 
 namespace {
@@ -568,9 +570,13 @@ int run_high(float_dec* h, int n, int off, const float* styles, const float* dem
   return FLOAT_OK;
 }
 
+// host != nullptr: every finished high batch is copied to host + (its offset) on `cs` while `st` renders the next one
+// (float_dec_frames_host); `st` is made to wait for the last copy before the call returns.
 template <class T>
-int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, float* out, int final_mode, hipStream_t st) {
+int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, float* out, int final_mode, hipStream_t st,
+                float* host = nullptr, hipStream_t cs = nullptr) {
   const int S = h->cfg.size, sdim = h->cfg.style_dim, FH = h->cfg.max_frames, FL = h->lo_frames;
+  size_t n_copy = 0;
   for (int s0 = 0; s0 < n_frames; s0 += kStyleCap) {
     const int ns = std::min(kStyleCap, n_frames - s0);
     // every style modulation (22 EqualLinears) and every demod factor for `ns` frames: 2 launches
@@ -606,11 +612,29 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
       if (rc) return rc;
       for (int b0 = 0; b0 < na; b0 += FH) {
         const int nb = std::min(FH, na - b0);
-        rc = run_high<T>(h, nb, b0, st_a + (size_t)b0 * h->Stot, dm_a + (size_t)b0 * h->Dtot, skip_idx,
-                         out + (size_t)(s0 + a0 + b0) * S * S * 3, final_mode, st);
+        const size_t off = (size_t)(s0 + a0 + b0) * S * S * 3;
+        rc = run_high<T>(h, nb, b0, st_a + (size_t)b0 * h->Stot, dm_a + (size_t)b0 * h->Dtot, skip_idx, out + off, final_mode, st);
         if (rc) return rc;
+        if (host && cs == st) {  // in-order copy behind the batch's last kernel
+          FH_CHECK_HIP(hipMemcpyAsync(host + off, out + off, (size_t)nb * S * S * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        } else if (host) {
+          if (n_copy >= h->copy_events.size()) {
+            hipEvent_t e;
+            FH_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->copy_events.push_back(e);
+          }
+          hipEvent_t e = h->copy_events[n_copy++];
+          FH_CHECK_HIP(hipEventRecord(e, st));
+          FH_CHECK_HIP(hipStreamWaitEvent(cs, e, 0));
+          FH_CHECK_HIP(hipMemcpyAsync(host + off, out + off, (size_t)nb * S * S * 3 * sizeof(float), hipMemcpyDeviceToHost, cs));
+        }
       }
     }
+  }
+  if (host && n_copy) {  // join: work queued on `st` after this call sees the frames in host memory
+    if (!h->join_event) FH_CHECK_HIP(hipEventCreateWithFlags(&h->join_event, hipEventDisableTiming));
+    FH_CHECK_HIP(hipEventRecord(h->join_event, cs));
+    FH_CHECK_HIP(hipStreamWaitEvent(st, h->join_event, 0));
   }
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
@@ -637,11 +661,13 @@ int float_dec_create(const float_dec_cfg_t* cfg, const float_tensor_t* tensors, 
              "decoder size must be a power of two in [64, 512] (got %d)", cfg->size);
   FH_REQUIRE(cfg->style_dim > 0 && cfg->style_dim <= 2048, "style_dim %d unsupported", cfg->style_dim);
   FH_REQUIRE(cfg->max_frames >= 1 && cfg->max_frames <= 128, "max_frames must be in [1,128] (got %d)", cfg->max_frames);
-  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
+  // fp16 operands only: with bf16 the 512-px frames sat at the 40 dB limit (40.7 dB, max |d| 0.15 on a [0,1] pixel: the
+  // flow field positions the bilinear sampling, 8 mantissa bits are too few there); fp16 runs at the same MFMA rate
+  FH_REQUIRE(cfg->dtype == FLOAT_DT_FP16, "the decoder supports FLOAT_DT_FP16 operands only (got dtype %d)", cfg->dtype);
   float_dec* h = new float_dec();
   h->cfg = *cfg;
   TensorTable tt(tensors, n_tensors);
-  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);
+  int rc = create_impl<FP16>(h, tt);
   if (!rc) {
     if (const float_tensor_t* dw = tt.find("direction.weight")) {
       if (dw->ndim == 2 && dw->shape[0] == cfg->style_dim) {
@@ -669,6 +695,8 @@ int float_dec_direction(float_dec_t* h, const float* lam, float* r_s, void* stre
 
 void float_dec_destroy(float_dec_t* h) {
   if (!h) return;
+  for (hipEvent_t e : h->copy_events) (void)hipEventDestroy(e);
+  if (h->join_event) (void)hipEventDestroy(h->join_event);
   h->pool.release();
   delete h;
 }
@@ -678,7 +706,7 @@ int float_dec_set_feats(float_dec_t* h, const float* const* feats, int32_t n_fea
   FH_REQUIRE(n_feats == h->n_levels, "expected %d feature maps (8..%d), got %d", h->n_levels, h->cfg.size, n_feats);
   for (int i = 0; i < n_feats; ++i) FH_REQUIRE(feats[i] != nullptr, "feats[%d] is null", i);
   hipStream_t st = (hipStream_t)stream;
-  int rc = h->cfg.dtype == FLOAT_DT_BF16 ? set_feats_impl<BF16>(h, feats, st) : set_feats_impl<FP16>(h, feats, st);
+  int rc = set_feats_impl<FP16>(h, feats, st);
   if (!rc) h->feats_set = true;
   return rc;
 }
@@ -702,12 +730,28 @@ static int dec_run(float_dec_t* h, const float* s_r, const float* r_d, int32_t n
   FH_REQUIRE(h->feats_set, "float_dec_set_feats must be called before decoding");
   FH_REQUIRE(n_frames >= 1, "n_frames must be >= 1 (got %d)", n_frames);
   hipStream_t st = (hipStream_t)stream;
-  return h->cfg.dtype == FLOAT_DT_BF16 ? frames_impl<BF16>(h, s_r, r_d, n_frames, out, mode, st)
-                                       : frames_impl<FP16>(h, s_r, r_d, n_frames, out, mode, st);
+  return frames_impl<FP16>(h, s_r, r_d, n_frames, out, mode, st);
 }
 
 int float_dec_frames(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames, float* out_hwc, void* stream) {
   return dec_run(h, s_r, r_d, n_frames, out_hwc, 1, stream);
+}
+
+int float_dec_frames_host(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames, float* out_hwc, float* host_hwc,
+                          void* stream, void* copy_stream) {
+  FH_REQUIRE(h && s_r && r_d && out_hwc && host_hwc, "null argument to float_dec_frames_host");
+  FH_REQUIRE(h->feats_set, "float_dec_set_feats must be called before decoding");
+  FH_REQUIRE(n_frames >= 1, "n_frames must be >= 1 (got %d)", n_frames);
+  hipStream_t st = (hipStream_t)stream, cs = copy_stream ? (hipStream_t)copy_stream : st;
+  return frames_impl<FP16>(h, s_r, r_d, n_frames, out_hwc, 1, st, host_hwc, cs);
+}
+
+int float_dec_feat_shape(float_dec_t* h, int32_t i, int32_t* channels, int32_t* resolution) {
+  FH_REQUIRE(h && channels && resolution, "null argument to float_dec_feat_shape");
+  FH_REQUIRE(i >= 0 && i < h->n_levels, "feature index %d out of range (the decoder takes %d maps)", i, h->n_levels);
+  *channels = h->levels[i].C;
+  *resolution = h->levels[i].R;
+  return FLOAT_OK;
 }
 
 int float_dec_frames_raw(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames, float* out_chw, void* stream) {

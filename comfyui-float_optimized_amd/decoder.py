@@ -8,7 +8,9 @@ from . import native
 
 
 class SynthesisHIP:
-    def __init__(self, state_dict, size=512, style_dim=512, device="cuda:0", dtype="bf16", max_frames=16):
+    def __init__(self, state_dict, size=512, style_dim=512, device="cuda:0", dtype="fp16", max_frames=16):
+        if native.DTYPES.get(dtype) != native.FLOAT_DT_FP16:
+            raise ValueError("the decoder runs fp16 operands only (got %r): bf16 left the 512-px frames at the 40 dB limit" % (dtype,))
         self.size, self.style_dim = size, style_dim
         self.device = torch.device(device)
         self.dtype = dtype
@@ -31,8 +33,26 @@ class SynthesisHIP:
 
     __del__ = close
 
+    def feat_shapes(self):
+        """[(C, R)] of the skip features the operator reads (float_dec_feat_shape), reference order 8..size."""
+        out, i = [], 0
+        c, r = C.c_int32(0), C.c_int32(0)
+        while native.lib().float_dec_feat_shape(self._h, i, C.byref(c), C.byref(r)) == 0:
+            out.append((c.value, r.value))
+            i += 1
+        return out
+
     def set_feats(self, feats):
-        """feats: the encoder's skip list (encoder.py:220-231), 7 tensors (1,C,R,R), R = 8..size."""
+        """feats: the encoder's skip list (encoder.py:220-231), 7 tensors (1,C,R,R), R = 8..size.  Every tensor is checked
+        against the decoder's level table first: the repack kernel reads C*R*R floats from each pointer, so a map from a
+        differently sized or channelled encoder (the VA nodes let users wire any loader to any loader) must not reach it."""
+        want = self.feat_shapes()
+        if len(feats) != len(want):
+            raise ValueError("expected %d feature maps (8..%d), got %d" % (len(want), self.size, len(feats)))
+        for i, (f, (c, r)) in enumerate(zip(feats, want)):
+            if f.dim() not in (3, 4) or tuple(f.shape[-3:]) != (c, r, r) or (f.dim() == 4 and f.shape[0] != 1):
+                raise ValueError("feats[%d] must be (1,%d,%d,%d) for a %d-px decoder, got %s"
+                                 % (i, c, r, r, self.size, tuple(f.shape)))
         fs = [f.to(self.device, torch.float32).reshape(f.shape[-3], f.shape[-2], f.shape[-1]).contiguous() for f in feats]
         ptrs = (C.c_void_p * len(fs))(*[f.data_ptr() for f in fs])
         with torch.cuda.device(self.device):
@@ -57,6 +77,27 @@ class SynthesisHIP:
         if s_r_feats is not None:
             self.set_feats(s_r_feats)
         return self._run(native.lib().float_dec_frames, s_r, r_d, (self.size, self.size, 3))
+
+    @torch.no_grad()
+    def decode_into_host(self, s_r, r_d, host, staging=None, copy_stream=None):
+        """decode_latent_into_processed_images with the reference's destination (a pre-allocated CPU tensor, FLOAT.py:139):
+        `host` (T, size, size, 3) fp32, pinned for the copies to be asynchronous.  Every finished batch of frames is copied
+        behind its last kernel on the current stream, or on `copy_stream` (a torch stream) while the next batch renders -
+        see include/float_hip.h for why the second form does not pay on MI355X.  Returns the device staging tensor; the
+        frames are in `host` once the current stream has been synchronised."""
+        s_r = s_r.to(self.device, torch.float32).reshape(-1).contiguous()
+        r_d = r_d.to(self.device, torch.float32).reshape(-1, self.style_dim).contiguous()
+        T = r_d.shape[0]
+        shape = (T, self.size, self.size, 3)
+        if tuple(host.shape) != shape or host.dtype != torch.float32 or host.is_cuda or not host.is_contiguous():
+            raise ValueError("host must be a contiguous CPU float32 tensor of shape %s" % (shape,))
+        if staging is None or tuple(staging.shape) != shape:
+            staging = torch.empty(shape, device=self.device, dtype=torch.float32)
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_dec_frames_host(
+                self._h, native.dev_ptr(s_r), native.dev_ptr(r_d), T, native.dev_ptr(staging), C.c_void_p(host.data_ptr()),
+                native.stream_ptr(self.device), C.c_void_p(copy_stream.cuda_stream) if copy_stream is not None else None))
+        return staging
 
     @torch.no_grad()
     def direction(self, lam):

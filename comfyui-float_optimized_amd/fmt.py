@@ -14,7 +14,7 @@ class FlowMatchingTransformerHIP:
     """Holds packed weights + workspace on one GPU.  Batch items are looped on the host, like the
     reference's FloatProcess (nodes.py:189-209)."""
 
-    def __init__(self, state_dict, cfg: FmtConfig = None, device="cuda:0", dtype="bf16", use_graph=2):
+    def __init__(self, state_dict, cfg: FmtConfig = None, device="cuda:0", dtype="fp16", use_graph=2):
         self.cfg = cfg or FmtConfig()
         self.device = torch.device(device)
         self.dtype = dtype

@@ -12,7 +12,7 @@ from .fmt import FlowMatchingTransformerHIP, WindowSampler, draw_noise
 
 
 class FloatHotPath:
-    def __init__(self, fmt_state, dec_state, cfg: FmtConfig = None, device="cuda:0", size=512, fmt_dtype="bf16",
+    def __init__(self, fmt_state, dec_state, cfg: FmtConfig = None, device="cuda:0", size=512, fmt_dtype="fp16",
                  dec_dtype="fp16", max_frames=32, use_graph=2):
         self.cfg = cfg or FmtConfig()
         self.device = torch.device(device)

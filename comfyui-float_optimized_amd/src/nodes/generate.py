@@ -95,18 +95,21 @@ class InferenceAgent:
 
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
-    def conditions(self, ref_img, ref_audio, emo=None):
-        """Once-per-clip stage, all on HIP operators: image -> (s_r, feats, r_s), audio -> (wa, T), and for
-        emotion='none' the speech-emotion scores (FLOAT.py:196-198)."""
+    def conditions(self, ref_img, ref_audio, emo=None, no_crop=True):
+        """Once-per-clip stage, all on HIP operators: image -> (s_r, feats, r_s), audio -> (wa, T), and for any `emo` that
+        is not one of the seven labels (None, 'none', 'S2E', ...) the speech-emotion scores (FLOAT.py:196-198)."""
         o = self.opt
-        s = host_models.preprocess_image(ref_img[0] if ref_img.dim() == 4 else ref_img, o.input_size).to(self.rank)
+        img = ref_img[0] if ref_img.dim() == 4 else ref_img
+        if not no_crop:  # generate.py:77-78
+            img, _ = host_models.process_img(img[..., :3].float(), o.input_size, getattr(o, "face_margin", 1.6), logger=main_logger)
+        s = host_models.preprocess_image(img, o.input_size).to(self.rank)
         a = host_models.preprocess_audio(ref_audio["waveform"][0], ref_audio["sample_rate"], o.sampling_rate).to(self.rank)
         s_r, _, _, r_s = self.enc.encode_image_into_latent(s, want_feats=False)  # FLOAT.py:283-291
         self.enc.hand_feats_to(self.G.dec)
         feats = None  # already in the decoder (NHWC 16-bit)
         T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
         wa = self.audio_encoder.inference(a, seq_len=T)
-        if emo is None or str(emo).lower() == "none":
+        if host_models.emotion_index(emo) is None:
             if self.emotion_predictor is None:
                 raise NotImplementedError(
                     "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198) but the checkpoint has "
@@ -121,10 +124,7 @@ class InferenceAgent:
                       emo="S2E", nfe=10, no_crop=False, seed=25):
         """Reference signature (generate.py:154-173).  Returns (T,H,W,3) fp32 in [0,1] on the CPU.
         Like the reference, the grid size comes from opt.nfe, not from the `nfe` argument (FLOAT.py:188)."""
-        if not no_crop:
-            raise NotImplementedError("face_align=True needs the face_alignment detector, which is not part of this "
-                                      "build; pass a cropped square portrait and face_align=False")
-        c = self.conditions(ref_img, ref_audio, emo)
+        c = self.conditions(ref_img, ref_audio, emo, no_crop=no_crop)
         n_chunks = int(math.ceil(c["T"] / self.cfg.num_frames_for_clip))
         noise = draw_noise(n_chunks, 1, self.cfg, seed if seed is not None else self.opt.seed)
         frames = self.G.generate(c["r_s"], c["wa"], c["we"], c["s_r"], c["feats"], self.opt.nfe, a_cfg_scale, r_cfg_scale,

@@ -131,7 +131,7 @@ int float_fmt_debug(float_fmt_t* h, int32_t what, const float* in, float* out, v
 typedef struct {
   int32_t size;        /* output resolution, 64..512 (styledecoder.py:448) */
   int32_t style_dim;   /* 512 */
-  int32_t dtype;       /* FLOAT_DT_* for activations / conv weights */
+  int32_t dtype;       /* FLOAT_DT_FP16 (activations / conv weights); bf16 is refused: too few mantissa bits for the warp */
   int32_t max_frames;  /* frames decoded per internal batch (sizes the workspace) */
 } float_dec_cfg_t;
 
@@ -150,6 +150,22 @@ int float_dec_set_feats(float_dec_t* h, const float* const* feats, int32_t n_fea
  *   out: (n_frames, size, size, 3) fp32 in [0,1] = clamp(rgb,-1,1)*0.5+0.5, HWC. */
 int float_dec_frames(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames,
                      float* out_hwc, void* stream);
+
+/* The same with the reference's hand-over to host memory (FLOAT.py:139,157-167: frames land in a pre-allocated CPU tensor):
+ * frames are rendered into out_hwc (device, n_frames * size * size * 3) and every finished batch of max_frames frames is
+ * copied to host_hwc (same layout; pinned host memory for the copy to be asynchronous).
+ *   copy_stream == NULL or == stream: the copies are queued on `stream` behind each batch (in order).
+ *   another stream: the copy of batch i runs there while `stream` renders batch i+1, and `stream` is made to wait for the
+ *     last copy before the call returns.  Measured on MI355X / ROCm 7.2 this does NOT pay inside the whole path: the
+ *     decode + copy phase drops from 42 to 30 ms per 250 frames, but a device-to-host copy issued on a second stream leaves
+ *     the FMT chain that follows 12 ms slower (84.6 -> 97 ms, even after a full device synchronisation), see DESIGN.md.
+ * Either way, synchronising `stream` (or an event recorded on it) means the frames are in host memory. */
+int float_dec_frames_host(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames,
+                          float* out_hwc, float* host_hwc, void* stream, void* copy_stream);
+
+/* Shape (channels, resolution) of skip feature i as float_dec_set_feats reads it: feats[i] must hold
+ * channels * resolution * resolution floats.  Lets the caller validate tensors wired from an arbitrary encoder. */
+int float_dec_feat_shape(float_dec_t* h, int32_t i, int32_t* channels, int32_t* resolution);
 
 /* Same, but returns the un-clamped NCHW rgb of Synthesis.forward (styledecoder.py:532-534);
  * parity tests use it to look under the clamp. */

@@ -1,6 +1,7 @@
 """GPU parity of the decoder operator against the CPU oracle / goldens, through the C ABI.
 16-bit activations with fp32 accumulation.  Stated tolerances (calibrated on MI355X):
-frames in [0,1]: PSNR >= 40 dB and mean |d| <= 2/255 for bf16; fp16 is held 4x tighter."""
+frames in [0,1]: PSNR >= 52 dB and mean |d| <= 0.5/255 with fp16 operands (the only operand type of the decoder: bf16 sat at
+40.7 dB against the 40 dB of SURVEY 8d and was dropped)."""
 import math
 
 import pytest
@@ -19,10 +20,10 @@ def psnr(a, b):
     return 99.0 if mse == 0 else 10 * math.log10(1.0 / mse)
 
 
-LIMITS = {"bf16": dict(psnr=40.0, mean=2.0 / 255), "fp16": dict(psnr=52.0, mean=0.5 / 255)}
+LIMITS = {"fp16": dict(psnr=52.0, mean=0.5 / 255)}
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp16"])
 def test_dec_64_golden(dtype):
     g = golden("dec_64")
     sd = W.synth_decoder_state(64, seed=g["seed"])
@@ -38,7 +39,7 @@ def test_dec_64_golden(dtype):
     assert frames.min() >= 0 and frames.max() <= 1
 
 
-@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("dtype", ["fp16"])
 def test_dec_512_golden_lattice(dtype):
     g = golden("dec_512")
     sd = W.synth_decoder_state(512, seed=g["seed"])
@@ -61,7 +62,7 @@ def test_dec_512_vs_oracle_levels():
     gen = torch.Generator().manual_seed(5)
     s_r, r_d = torch.randn(1, 512, generator=gen), torch.randn(1, 1, 512, generator=gen) * 0.5
     want = O.synthesis(sd, s_r + r_d[:, 0], feats)
-    dec = pkg.decoder.SynthesisHIP(sd, 512, 512, "cuda:0", dtype="bf16", max_frames=1)
+    dec = pkg.decoder.SynthesisHIP(sd, 512, 512, "cuda:0", dtype="fp16", max_frames=1)
     dec.set_feats(feats)
     raw = dec.synthesis_raw(s_r, r_d).cpu()
     d = (raw - want).abs()
@@ -92,3 +93,40 @@ def test_dec_errors():
     del bad["to_flows.0.conv.weight"]
     with pytest.raises(KeyError):
         pkg.decoder.SynthesisHIP(bad, 64, 512, "cuda:0")
+
+
+def test_decoder_refuses_bf16():
+    with pytest.raises(ValueError, match="fp16"):
+        pkg.decoder.SynthesisHIP(W.synth_decoder_state(64, seed=1), 64, 512, "cuda:0", dtype="bf16")
+
+
+@pytest.mark.parametrize("side_stream", [False, True])
+def test_decode_into_host_equals_decode(side_stream):
+    """float_dec_frames_host: the frames that land in (pinned) host memory batch by batch - behind each batch on the same
+    stream, or on a second stream while the next batch renders - are bitwise the frames of float_dec_frames."""
+    sd = W.synth_decoder_state(64, seed=4)
+    feats = W.synth_feats(64, seed=4)
+    gen = torch.Generator().manual_seed(1)
+    s_r, r_d = torch.randn(1, 512, generator=gen), torch.randn(1, 11, 512, generator=gen) * 0.5
+    dec = pkg.decoder.SynthesisHIP(sd, 64, 512, "cuda:0", max_frames=4)  # 11 frames -> 3 batches
+    want = dec.decode_latent_into_processed_images(s_r, r_d, feats).cpu()
+    host = torch.full((11, 64, 64, 3), -1.0).pin_memory()
+    staging = dec.decode_into_host(s_r, r_d, host, copy_stream=torch.cuda.Stream("cuda:0") if side_stream else None)
+    torch.cuda.current_stream().synchronize()
+    assert torch.equal(host, want) and torch.equal(staging.cpu(), want)
+    with pytest.raises(ValueError):
+        dec.decode_into_host(s_r, r_d, torch.empty(10, 64, 64, 3))
+
+
+def test_set_feats_validates_every_map():
+    """A feature list from a differently sized encoder must be refused before the repack kernel reads it."""
+    dec = pkg.decoder.SynthesisHIP(W.synth_decoder_state(64, seed=1), 64, 512, "cuda:0")
+    assert dec.feat_shapes() == [(512, 8), (512, 16), (512, 32), (256, 64)]
+    good = W.synth_feats(64, seed=1)
+    dec.set_feats(good)
+    bad = list(good)
+    bad[2] = bad[2][:, :, :16, :16]
+    with pytest.raises(ValueError, match=r"feats\[2\]"):
+        dec.set_feats(bad)
+    with pytest.raises(ValueError):
+        dec.set_feats(good[:3])

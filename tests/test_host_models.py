@@ -1,0 +1,58 @@
+"""Host-side plumbing in front of the HIP operators (host_models.py): the band-limited resampler that replaces the
+reference's librosa soxr_hq path, the face-aligned crop with its no-detector / no-face fallback (utils/image.py:135-180),
+and the emotion-label rule of FLOAT.py:196 (anything that is not one of the seven labels = predict from the audio)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.util import load_pkg
+
+pkg = load_pkg()
+hm = pkg.host_models
+
+
+@pytest.mark.parametrize("src", [48000, 44100, 22050, 8000])
+def test_resampler_matches_polyphase_reference_in_band(src):
+    from math import gcd
+    from scipy.signal import resample_poly
+    t = np.arange(src) / src
+    x = (0.5 * np.sin(2 * np.pi * 440 * t) + 0.3 * np.sin(2 * np.pi * 2500 * t)).astype(np.float32)
+    y = hm.resample_sinc(torch.from_numpy(x), src, 16000).numpy()
+    g = gcd(src, 16000)
+    ref = resample_poly(x.astype(np.float64), 16000 // g, src // g)
+    assert len(y) == 16000 == len(ref)
+    assert np.abs(y[300:-300] - ref[300:-300]).max() < 2e-3
+
+
+def test_resampler_suppresses_what_would_alias():
+    """An 11 kHz tone at 48 kHz lies above the 8 kHz Nyquist of the target: linear interpolation folds it to 5 kHz at full
+    amplitude (rms 0.35), the band-limited resampler removes it."""
+    t = np.arange(48000) / 48000
+    hi = torch.from_numpy((0.5 * np.sin(2 * np.pi * 11000 * t)).astype(np.float32))
+    y = hm.resample_sinc(hi, 48000, 16000)
+    assert float(y[300:-300].pow(2).mean().sqrt()) < 1e-3
+    a = hm.preprocess_audio(torch.stack([hi, hi]), 48000)
+    assert a.shape == (1, 16000) and abs(float(a.mean())) < 1e-4
+
+
+def test_face_crop_fallback_is_the_reference_no_face_branch():
+    """Without the optional detector (or without a face) the reference crops the centre square (utils/image.py:151-158)."""
+    img = torch.rand(720, 800, 3)  # taller than 360 px: the reference shrinks with INTER_AREA (mult < 1)
+    crop, bbox = hm.process_img(img, 360)
+    assert bbox == (40, 0, 720, 720) and crop.shape == (360, 360, 3)
+    want = torch.nn.functional.adaptive_avg_pool2d(img[:, 40:760].permute(2, 0, 1)[None], (360, 360))[0].permute(1, 2, 0)
+    try:
+        import face_alignment  # noqa: F401
+    except ImportError:
+        assert torch.allclose(crop, want, atol=1e-6)
+    same, bbox = hm.process_img(torch.rand(64, 64, 3), 64)
+    assert same.shape == (64, 64, 3) and bbox == (0, 0, 64, 64)
+
+
+def test_emotion_labels_follow_label2id_get():
+    assert hm.emotion_index("Happy") == 3 and hm.emotion_index("neutral") == 4
+    for other in (None, "none", "S2E", "s2e", "joyful"):
+        assert hm.emotion_index(other) is None  # -> speech-to-emotion prediction (FLOAT.py:196-198)
+    assert hm.emotion_one_hot("sad").tolist() == [[[0, 0, 0, 0, 0, 1, 0]]]
+    with pytest.raises(ValueError):
+        hm.emotion_one_hot("S2E")

@@ -56,8 +56,18 @@ def test_float_process_errors(pipe):
     with pytest.raises(NotImplementedError):
         node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "none", False, 7)   # no SER weights in the checkpoint
     pipe.emotion_predictor = saved
-    with pytest.raises(NotImplementedError):
-        node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", True, 7)   # needs the face detector
+    # face_align=True (the widget's default): the reference's crop; without the optional detector (or a detected face) the
+    # centre square, which for a square portrait is the image itself (utils/image.py:151-158)
+    aligned, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", True, 7)
+    plain, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    assert aligned.shape == plain.shape
+    try:
+        import face_alignment  # noqa: F401
+    except ImportError:
+        assert float((aligned - plain).abs().mean()) < 1e-4
+    # run_inference's own default emo='S2E' is not a label: speech-to-emotion, like the reference (FLOAT.py:196-198)
+    s2e2 = pipe.run_inference(None, img, audio, no_crop=True, seed=7)
+    assert torch.equal(s2e2, s2e)
     with pytest.raises(ValueError):
         pkg.NODE_CLASS_MAPPINGS["LoadFloatModelsOpt"]().loadmodel("x.safetensors", "cuda:0", False,
                                                                   {"torchdiffeq_ode_method": "dopri5"})

@@ -8,10 +8,14 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (identity of the kernel sources the counters were taken on)
+
 N_SIMD = 256 * 4
-CLASSES = (("fmt_gemm", ("void fmt_gemm",)), ("dec_conv", ("void dec_conv", "void dec_zconv")), ("fmt_small", ("void fmt_lnmod", "void fmt_attn")),
+CLASSES = (("fmt_adaln_gemm", ("void fmt_gemm_wide",)), ("fmt_gemm", ("void fmt_gemm_kernel",)), ("dec_conv", ("void dec_conv", "void dec_zconv")), ("fmt_small", ("void fmt_lnmod", "void fmt_attn")),
            ("dec_flow", ("void dec_flow",)), ("dec_blur", ("void dec_blur",)))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)
@@ -33,5 +37,6 @@ for cls, c in agg.items():
                 "wave_wait_any": round(c.get("SQ_WAIT_ANY", 0.0) / wc, 3), "wave_wait_inst": round(c.get("SQ_WAIT_INST_ANY", 0.0) / wc, 3),
                 "wave_active": round(c.get("SQ_ACTIVE_INST_ANY", 0.0) / wc, 3), "wave_active_lds": round(c.get("SQ_ACTIVE_INST_LDS", 0.0) / wc, 3),
                 "wave_active_valu": round(c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc, 3)}
+out["source_hash"] = source_hash()
 json.dump(out, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r01_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE collected
+"""profiles/rNN_pmc_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE collected
 SEPARATELY, MI355X_MICROARCH.md 'rocprofv3 PMC slots') of tools/profile_hotpath.py.
 HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE is in KB and reads exactly half of a wide
 coalesced stream on gfx950 (MI355X_MICROARCH.md 'HBM'); WRITE_SIZE is exact for 16-B-per-lane stores."""
@@ -7,7 +7,11 @@ import collections
 import csv
 import glob
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import source_hash  # noqa: E402  (identity of the kernel sources the counters were taken on)
 
 
 def per_class(d):
@@ -15,7 +19,9 @@ def per_class(d):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            cls = "fmt_gemm" if n.startswith("void fmt_gemm") else ("dec_conv" if n.startswith(("void dec_conv", "void dec_zconv")) else None)
+            cls = ("fmt_adaln_gemm" if n.startswith("void fmt_gemm_wide") else "fmt_gemm" if n.startswith("void fmt_gemm_kernel") else
+                   "dec_conv" if n.startswith(("void dec_conv", "void dec_zconv")) else "dec_flow" if n.startswith("void dec_flow") else
+                   "dec_zblur" if n.startswith("void dec_zblur") else "dec_other" if n.startswith("void dec_") else None)
             if cls:
                 out[cls][0] += float(r["Counter_Value"])
                 out[cls][1] += 1
@@ -39,5 +45,6 @@ for k in F:
     fetch_kb, write_kb = F[k][0] / n, W[k][0] / max(W[k][1], 1)
     res[k] = {"launches_profiled": n, "fetch_size_kb_per_launch": round(fetch_kb, 1), "write_size_kb_per_launch": round(write_kb, 1),
               "hbm_bytes_per_launch": int((2 * fetch_kb + write_kb) * 1024)}
+res["source_hash"] = source_hash()
 json.dump(res, open(dst, "w"), indent=1)
 print(json.dumps(res))

@@ -35,7 +35,7 @@ if args.what == "dec":
     print("decoded", tuple(out.shape), float(out.mean()))
 else:
     sd = pkg.weights.synth_fmt_state(cfg, seed=1)
-    fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, dev, "bf16", use_graph=0)
+    fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, dev, "fp16", use_graph=0)
     c = pkg.pipeline.synth_conditions(cfg, 50, seed=0)
     noise = pkg.fmt.draw_noise(1, 1, cfg, 15)
     for _ in range(args.reps):

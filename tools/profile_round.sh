@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/s2_final; mkdir -p $O
+O=gpurun_out/${1:-r02_prof}; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --no-cpu-baseline --no-roofline > $O/stats.log 2>&1
 find $O/stats -name "*kernel_trace.csv" -delete
