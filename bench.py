@@ -242,7 +242,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if args.mode == "window":
-            t = torch.tensor([float(seam.get("seam_rel_change", 0.0))], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+            t = torch.as_tensor(seam.get("seam_rel_change", 0.0)).reshape(1).to(dev if backend == "nccl" else "cpu", torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             seam["seam_rel_change"] = float(t.item())
     assert float(host[0].min()) >= 0.0 and float(host[-1].max()) <= 1.0 and float(host.mean()) > 0.0

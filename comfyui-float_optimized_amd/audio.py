@@ -54,6 +54,17 @@ class AudioEncoderHIP:
 
     __del__ = close
 
+    def reserve(self, n_samples, seq_len=0):
+        """Workspace for clips of up to n_samples samples / seq_len frames (float_aud_reserve): the operator's run-time calls
+        never allocate, so this mirror grows the reservation (a stream synchronise + hipMalloc) before a longer clip."""
+        cap = getattr(self, "_reserved", (0, 0))
+        frames = int(seq_len) if seq_len > 0 else int(n_samples) // 320 + 1
+        if n_samples <= cap[0] and frames <= cap[1]:
+            return
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_aud_reserve(self._h, int(n_samples), int(seq_len), native.stream_ptr(self.device)))
+        self._reserved = (max(cap[0], int(n_samples)), max(cap[1], frames))
+
     @torch.no_grad()
     def inference(self, a, seq_len):
         """AudioEncoder.inference (FLOAT.py:370-375): a (B,N) normalised 16 kHz waveform -> wa (B,seq_len,dim_w)."""
@@ -64,6 +75,7 @@ class AudioEncoderHIP:
         if a.shape[1] % need != 0:  # FLOAT.py:371-373
             a = F.pad(a[:, None], (0, need - a.shape[1]), mode="replicate")[:, 0]
         a = a.contiguous()
+        self.reserve(a.shape[1], seq_len)
         out = torch.empty(a.shape[0], seq_len, self.cfg.dim_w, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             for b in range(a.shape[0]):
@@ -98,6 +110,7 @@ class Audio2EmotionHIP(AudioEncoderHIP):
         if a.dim() == 1:
             a = a[None]
         a = a.contiguous()
+        self.reserve(a.shape[1], 0)
         out = torch.empty(a.shape[0], self.cfg.num_labels, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             for b in range(a.shape[0]):

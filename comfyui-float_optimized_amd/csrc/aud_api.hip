@@ -220,6 +220,7 @@ int create_impl(float_aud* h, const TensorTable& tt) {
   return FLOAT_OK;
 }
 
+// float_aud_reserve: the only place the operator allocates after create.  Run-time calls check the capacity and refuse.
 int ensure_workspace(float_aud* h, int n_samples, int Tn, hipStream_t st) {
   if ((size_t)n_samples <= h->cap_samples && Tn <= h->cap_T) return FLOAT_OK;
   const float_aud_cfg_t& c = h->cfg;
@@ -294,7 +295,9 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   FH_REQUIRE(Lfeat >= 1, "audio too short for the feature extractor (%d samples)", n_samples);
   if (Tn <= 0) Tn = Lfeat;
   FH_REQUIRE(Tn <= 3900, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit 3900 frames per call)", Tn);
-  if ((rc = ensure_workspace(h, n_samples, Tn, st))) return rc;
+  FH_REQUIRE((size_t)n_samples <= h->cap_samples && Tn <= h->cap_T,
+             "clip of %d samples / %d frames exceeds the reserved workspace (%zu samples / %d frames): call float_aud_reserve "
+             "first (run-time calls do not allocate)", n_samples, Tn, h->cap_samples, h->cap_T);
   // ---- feature extractor
   int L = (n_samples - c.conv_kernel[0]) / c.conv_stride[0] + 1;
   FH_REQUIRE(c.conv_kernel[0] == 10, "first conv kernel must be 10 (got %d)", c.conv_kernel[0]);
@@ -498,6 +501,15 @@ int float_aud_classify(float_aud_t* h, const float* a, int32_t n_samples, float*
   hipStream_t st = (hipStream_t)stream;
   return h->cfg.dtype == FLOAT_DT_BF16 ? inference_impl<BF16>(h, a, n_samples, 0, scores, st)
                                        : inference_impl<FP16>(h, a, n_samples, 0, scores, st);
+}
+
+int float_aud_reserve(float_aud_t* h, int32_t n_samples, int32_t seq_len, void* stream) {
+  FH_REQUIRE(h != nullptr, "null audio handle");
+  FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
+  const int Lfeat = feature_len(h->cfg, n_samples);
+  const int Tn = seq_len > 0 ? seq_len : Lfeat;
+  FH_REQUIRE(Tn >= 1 && Tn <= 3900, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit 3900 frames per call)", Tn);
+  return ensure_workspace(h, n_samples, Tn, (hipStream_t)stream);
 }
 
 int float_aud_inference(float_aud_t* h, const float* a, int32_t n_samples, int32_t seq_len, float* wa, void* stream) {

@@ -70,7 +70,8 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
     """Window-parallel sampling of one clip.  Every rank passes the FULL wa/we/noise (they are tiny);
     returns (r_d_local, (t0, t1), report) where r_d_local are the rank's frames of r_d and report has
     the seam error of the last round: rel-L2 change of the rank's latents caused by that exchange
-    (0 once the rank's history has converged to the sequential chain's)."""
+    (0 once the rank's history has converged to the sequential chain's), as a 0-dim tensor on the
+    latents' device - the caller converts it (float(...)) when it reports, not inside the timed loop."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
@@ -78,7 +79,7 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
     n_win = int(math.ceil(T / L))
     w0, w1 = window_shard(n_win, world, rank)
     xs, tail = sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, None)
-    seam = 0.0
+    seam = torch.zeros((), device=xs.device, dtype=torch.float32)  # stays on the device: no host sync per round
     for _ in range(iters if world > 1 else 0):
         # boundary latents of every rank: [x tail | wa tail | we tail] flattened, one all_gather
         mine = torch.cat([t.reshape(t.shape[0], -1) for t in tail], dim=1).contiguous()
@@ -91,7 +92,7 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
             hist = (g[:, :nx].reshape(B, P, cfg.dim_w), g[:, nx:nx + na].reshape(B, P, cfg.dim_a),
                     g[:, nx + na:].reshape(B, P, cfg.dim_e))
             new_xs, new_tail = sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, hist)
-            seam = float((new_xs - xs).norm() / (new_xs.norm() + 1e-30))
+            seam = ((new_xs - xs).norm() / (new_xs.norm() + 1e-30)).float()
             xs, tail = new_xs, new_tail
     t0, t1 = w0 * L, min(T, w1 * L)
     return xs[:, :t1 - t0], (t0, t1), {"seam_rel_change": seam, "windows": (w0, w1), "rounds": iters}

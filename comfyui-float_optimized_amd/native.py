@@ -78,6 +78,7 @@ _SIGNATURES = {
     "float_enc_forward": (C.c_int, [C.c_void_p] * 5 + [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "float_aud_create": (C.c_int, [C.POINTER(AudCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_aud_destroy": (None, [C.c_void_p]),
+    "float_aud_reserve": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "float_aud_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_aud_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_enc_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),

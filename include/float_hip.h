@@ -248,10 +248,14 @@ int float_aud_create(const float_aud_cfg_t* cfg, const float_tensor_t* tensors, 
                      float_aud_t** out);
 void float_aud_destroy(float_aud_t* h);
 
+/* Sizes the workspace for clips of up to n_samples samples and seq_len transformer frames (seq_len <= 0: the feature
+ * extractor's own length, as float_aud_classify uses it).  The ONLY call that allocates after create: it synchronises
+ * `stream` first when buffers have to grow (earlier work may still read the old ones) and never shrinks.  Not capturable. */
+int float_aud_reserve(float_aud_t* h, int32_t n_samples, int32_t seq_len, void* stream);
+
 /* a: (n_samples) fp32 device, the normalised 16 kHz waveform already replicate-padded by the caller to a
  * multiple of seq_len * sampling_rate / fps when needed (FLOAT.py:371-373);  wa: (seq_len, dim_w) fp32.
- * Exception to the no-allocation rule: the workspace is (re)grown, after a stream synchronise, when a clip is
- * longer than any seen before. */
+ * Allocation-free: a clip beyond the reserved capacity is refused (FLOAT_E_INVALID) - call float_aud_reserve first. */
 int float_aud_inference(float_aud_t* h, const float* a, int32_t n_samples, int32_t seq_len, float* wa,
                         void* stream);
 

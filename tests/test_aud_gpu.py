@@ -102,3 +102,23 @@ def test_speech_emotion_live_oracle_ragged():
     # prev_a is concatenated in front (FLOAT.py:397-398)
     a, p = W.synth_waveform(1.0, seed=2), W.synth_waveform(0.4, seed=3)
     assert torch.equal(ser.predict_emotion(a, p), ser.predict_emotion(torch.cat([p, a], dim=1)))
+
+
+def test_run_time_calls_do_not_allocate():
+    """float_aud_inference refuses a clip beyond the reserved workspace (float_aud_reserve is the only allocating call);
+    the Python mirror reserves before it calls."""
+    import ctypes as C
+    cfg = pkg.config.small_audio_config()
+    sd = W.synth_audio_state(cfg, seed=3)
+    enc = pkg.audio.AudioEncoderHIP(sd, cfg, "cuda:0", "fp16")
+    a = W.synth_waveform(1.0, seed=2).cuda()
+    out = torch.empty(25, cfg.dim_w, device="cuda:0")
+    L, N = pkg.native.lib(), pkg.native
+    rc = L.float_aud_inference(enc._h, N.dev_ptr(a[0]), a.shape[1], 25, N.dev_ptr(out), N.stream_ptr("cuda:0"))
+    assert rc == 1 and b"float_aud_reserve" in L.float_last_error()
+    N.check(L.float_aud_reserve(enc._h, a.shape[1], 25, N.stream_ptr("cuda:0")))
+    N.check(L.float_aud_inference(enc._h, N.dev_ptr(a[0]), a.shape[1], 25, N.dev_ptr(out), N.stream_ptr("cuda:0")))
+    wa = enc.inference(a, 25)[0]
+    assert torch.equal(wa, out)
+    longer = enc.inference(W.synth_waveform(2.0, seed=2).cuda(), 50)  # the mirror grows the reservation itself
+    assert longer.shape == (1, 50, cfg.dim_w) and torch.isfinite(longer).all()

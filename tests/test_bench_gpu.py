@@ -1,0 +1,45 @@
+"""bench.py as the driver runs it: one JSON line with the contract's fields, `value` = the end-to-end rate, and `--gpus N`
+without a launcher starting N ranks itself (here two gloo ranks sharing the one GPU of the test box)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.util import ROOT
+
+pytestmark = pytest.mark.gpu
+SHORT = ["--seconds", "2", "--nfe", "6", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, capture_output=True, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line_has_the_contract_fields():
+    r = _run(SHORT)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline" if False else "stage_ms"):
+        assert k in r, k
+    assert r["n_gpus"] == 1 and r["unit"] == "frames/s" and r["value"] > 0 and r["vs_baseline"] is None
+    assert "workload" in r["config"] and "pinned host memory" in r["config"]["workload"]
+    # value is the end-to-end rate: frames / wall of the timed steps
+    assert abs(r["value"] - 50 * r["steps"] / (r["ms_per_step"] * r["steps"] * 1e-3)) < 0.01 * r["value"]
+    ro = r["roofline"]
+    assert ro["bound"] in ("hbm", "mfma") and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and "traffic" in ro
+
+
+@pytest.mark.parametrize("mode", ["replicas", "window", "shard"])
+def test_gpus_2_launches_its_own_ranks(mode):
+    r = _run(SHORT + ["--gpus", "2", "--mode", mode, "--no-roofline", "--no-extras"], {"FLOAT_BENCH_BACKEND": "gloo"})
+    assert r["n_gpus"] == 2
+    assert r["config"]["frames_per_clip"] == (50 if mode == "replicas" else 100)
+    if mode == "window":
+        assert "seam change" in r["config"]["parallelism"]

@@ -80,7 +80,7 @@ def _worker(rank, world, port, q):
         # broadcast of r_d
         r_d = ref.clone() if rank == 0 else torch.zeros_like(ref)
         D.broadcast_latents(r_d, 0)
-        q.put((rank, t0, t1, err1, err0, rep["seam_rel_change"], bool(torch.equal(r_d, ref))))
+        q.put((rank, t0, t1, err1, err0, float(rep["seam_rel_change"]), bool(torch.equal(r_d, ref))))
     finally:
         dist.destroy_process_group()
 
@@ -103,3 +103,111 @@ def test_window_parallel_two_ranks_gloo():
     assert e0_0 < 1e-6 and e0_1 > 1e-3                       # without the exchange rank 1 is visibly off
     assert seam0 == 0.0 and seam1 > 0.0                      # and the seam report says so
     assert bc0 and bc1
+
+
+class OracleHotPath:
+    """CPU double of pipeline.FloatHotPath (sample / decode / generate) on the oracle: 64-px decoder, small FMT."""
+
+    def __init__(self, cfg, fmt_sd, dec_sd, feats):
+        self.cfg, self.fmt_sd, self.dec_sd, self.feats = cfg, fmt_sd, dec_sd, feats
+        self.device = torch.device("cpu")
+        self.sample_calls = 0
+
+    def sample(self, r_s, wa, we, nfe, a, r, e, seed=15, noise=None):
+        self.sample_calls += 1
+        return O.sample_rd(self.fmt_sd, self.cfg, r_s, wa, we, noise, nfe, a, r, e)
+
+    def decode(self, s_r, feats, r_d, frame_range=None):
+        rd = r_d if frame_range is None else r_d[:, frame_range[0]:frame_range[1]]
+        return O.decode_frames(self.dec_sd, s_r, rd, self.feats)
+
+    def generate(self, r_s, wa, we, s_r, feats, nfe, a, r, e, seed=15, noise=None, frame_range=None):
+        return self.decode(s_r, feats, self.sample(r_s, wa, we, nfe, a, r, e, noise=noise), frame_range)
+
+
+def _shard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    try:
+        cfg = pkg.config.small_fmt_config()
+        cfg.dim_w = cfg.dim_a = 512  # the decoder's style width
+        fmt_sd = pkg.weights.synth_fmt_state(cfg, seed=6)
+        dec_sd = pkg.weights.synth_decoder_state(64, seed=6)
+        feats = pkg.weights.synth_feats(64, seed=6)
+        T = 13
+        c = pkg.pipeline.synth_conditions(cfg, T, seed=1)
+        noise = pkg.fmt.draw_noise(1, 1, cfg, seed=15)
+        hp = OracleHotPath(cfg, fmt_sd, dec_sd, feats)
+        whole = hp.generate(c["r_s"], c["wa"], c["we"], c["s_r"], None, 3, 2.0, 1.0, 1.0, noise=noise)
+        hp.sample_calls = 0
+        out = {}
+        for chain in ("replicate", "broadcast"):
+            fr, (t0, t1) = D.generate_frame_sharded(hp, c["r_s"], c["wa"], c["we"], c["s_r"], None, 3, noise=noise, chain=chain)
+            out[chain] = (bool(torch.equal(fr, whole[t0:t1])), t0, t1)
+        q.put((rank, out, hp.sample_calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_frame_shard_replicate_and_broadcast_two_ranks_gloo():
+    """Exact multi-GPU rendering: each rank's shard equals the same frames of the single-process clip, with the latent
+    chain replicated (no communication) and with rank 0 sampling and broadcasting r_d (only rank 0 samples)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, out, calls in res:
+        for chain in ("replicate", "broadcast"):
+            ok, t0, t1 = out[chain]
+            assert ok and (t0, t1) == D.frame_shard(13, 2, rank), (rank, chain)
+        assert calls == (2 if rank == 0 else 1)  # replicate: both sample; broadcast: rank 0 only
+
+
+def _exact_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        # history must reach a window's LAST 10 frames for a wrong tail to matter downstream: the band lets information move
+        # attention_window tokens per layer, so 2 layers x 5 tokens x 6 evaluations = 60 tokens >= the 50-frame window (with
+        # the default window of 2 and a short grid the tail of a window does not depend on its history at all)
+        cfg, _, T, wa, r_s, we, noise = _problem(False)
+        cfg.attention_window = 5
+        sd = pkg.weights.synth_fmt_state(cfg, seed=4)
+        fmt = OracleFmt(sd, cfg)
+        nfe = 7
+        ref = O.sample_rd(sd, cfg, r_s, wa, we, noise, nfe, 2.0, 1.0, 1.0)
+        loc, (t0, t1), rep = D.sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, 2.0, 1.0, 1.0, iters=world - 1)
+        under, _, rep_u = D.sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, 2.0, 1.0, 1.0, iters=world - 2)
+        q.put((rank, t0, t1, bool(torch.equal(loc, ref[:, t0:t1])), float(rep["seam_rel_change"]),
+               bool(torch.equal(under, ref[:, t0:t1]))))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_window_parallel_world_minus_one_rounds_is_the_sequential_chain():
+    """--window-iters = world-1 reproduces the sequential AR chain bit for bit on every rank (rank k's history is exact after
+    k rounds); one round fewer leaves the last rank off, and the last round's seam change of converged ranks is 0."""
+    world, port = 3, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_exact_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=500) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(a, b) for _, a, b, _, _, _ in res] == [(0, 100), (100, 150), (150, 170)]
+    assert all(exact for _, _, _, exact, _, _ in res)
+    assert res[0][4] == 0.0 and res[1][4] == 0.0 and res[2][4] > 0.0  # only the last rank still moved in the last round
+    assert res[0][5] and res[1][5] and not res[2][5]

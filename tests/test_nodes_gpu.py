@@ -67,7 +67,7 @@ def test_float_process_errors(pipe):
         assert float((aligned - plain).abs().mean()) < 1e-4
     # run_inference's own default emo='S2E' is not a label: speech-to-emotion, like the reference (FLOAT.py:196-198)
     s2e2 = pipe.run_inference(None, img, audio, no_crop=True, seed=7)
-    assert torch.equal(s2e2, s2e)
+    assert s2e2.shape == s2e.shape and float((s2e2 - s2e).abs().mean()) < 1e-4
     with pytest.raises(ValueError):
         pkg.NODE_CLASS_MAPPINGS["LoadFloatModelsOpt"]().loadmodel("x.safetensors", "cuda:0", False,
                                                                   {"torchdiffeq_ode_method": "dopri5"})
