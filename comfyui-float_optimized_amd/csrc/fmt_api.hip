@@ -22,6 +22,7 @@ struct float_fmt {
   float_fmt_cfg_t cfg;
   DevicePool pool;
   int D, ntok, Mpad, Kc, Ntot, Kx;
+  int Bmax = 1;  // clips per launch chain the workspace is sized for (float_fmt_cfg_t::max_batch)
   Lin x_embed, t0, t2, c_embed, adaln_all, final_lin;
   std::vector<Blk> blk;
   float* pos = nullptr;
@@ -39,7 +40,7 @@ struct float_fmt {
   int Mmod = 0;
   // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, method, scales); least recently used entry evicted
   struct GraphKey {
-    int nfe, bc, we_len, method;
+    int nfe, bc, we_len, method, nclip;
     float a, r, e;
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
   };
@@ -55,7 +56,7 @@ struct float_fmt {
   struct {
     const float *wr, *wa, *we, *noise;
     float* r_d;
-    int T, we_len, nfe, include_r, next, n_chunks;
+    int T, we_len, nfe, include_r, next, n_chunks, B;
     float a, r, e;
     std::vector<float> ts;
     bool active = false;
@@ -142,7 +143,10 @@ int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
     return FLOAT_OK;
   }
   if (mt <= 4) return launch_wide_t<T, 4, 4>(g, false, s);
-  if (mt <= 12) {
+  // 192-row blocks also for the stacked clips of a batch (mt > 12): the last block reads up to 11 row tiles past the batch (the
+  // operand buffers are padded for it, the rows are never stored); 80-row blocks ran the batched projection at 240 TFLOP/s
+  // against 700 for 192-row ones
+  if (mt <= 12 || g_fmt_wide_variant == 2) {
     switch (g_fmt_wide_variant) {
       case 1: return launch_wide_t<T, 6, 2>(g, false, s);
       case 2: return launch_wide_t<T, 12, 2>(g, false, s);
@@ -272,6 +276,12 @@ Tiling pick_tiling(int M, int N, int K, bool need_full_rows) {
     }
   }
   if (wide) return {mt <= 4 ? 4 : 6, 2, std::min(8, pick_nw(K, 0))};
+  // stacked clips (float_fmt_sample_batch, more than 15 row tiles): the one-clip tile (48 x 64) with 4 K-splitting waves, so that
+  // two or three workgroups share a CU (49 KB of LDS each instead of 98).  Measured per 250 evaluations, B = 2 / 4 clips:
+  // 120.7 / 184.5 ms against 136.4 / 200.6 with the 80-row tiles this function would pick below, 130.1 / 208.1 with 8 waves
+  // (one clip: 85.0).  Operands come straight from L2 per workgroup, so the traffic grows with rows x column blocks: the
+  // batched chain wants an LDS-staged large-tile kernel like fmt_gemm_wide_kernel with these epilogues.
+  if (mt > 15 && N % 64 == 0) return {3, 4, 4};
   // column tiles per workgroup: the widest (<= 4) that still gives >= ~200 workgroups, so that each CU
   // runs ONE workgroup (two back-to-back workgroups per CU double the latency chain of the layer)
   int nt = 1;
@@ -447,8 +457,8 @@ int g_fmt_hoist = 1;
 int g_fmt_zgroup = 4;  // FLOAT_FMT_ZGROUP: column blocks of an XCD that share activation tiles through L2 (fmt_gemm_wide_kernel)
 
 template <class T>
-int run_mod_all(float_fmt* h, int bc, int e0, int n, hipStream_t s) {
-  const int D = h->D, M = bc * h->ntok;
+int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
+  const int D = h->D;
   FH_REQUIRE(n >= 1 && n <= kScSteps, "modulation batch of %d evaluations (max %d)", n, kScSteps);
   hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256, n), dim3(256), 0, s, h->sc16, h->temb + (size_t)e0 * D,
                      h->ccond, M, D, (size_t)h->Mpad * D);
@@ -474,14 +484,14 @@ int run_mod_all(float_fmt* h, int bc, int e0, int n, hipStream_t s) {
 // Block chain of an evaluation on the rows staged in the workspace, using the modulations in modbuf.
 // euler: update xcur/xin16 with dt, else write vout.
 template <class T>
-int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, float a, float r, float e, hipStream_t s,
+int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler, float dt, float a, float r, float e, hipStream_t s,
                float* vout_to = nullptr) {
   const float_fmt_cfg_t& c = h->cfg;
-  const int D = h->D, ntok = h->ntok, M = bc * ntok;
+  const int D = h->D, ntok = h->ntok, M = nclip * bc * ntok;
   int rc;
   // x_embedder + pos_embed; the CFG rows share x, so 60 rows are computed and broadcast
   {
-    GemmArgs g = base_args(h->xin16, h->x_embed, ntok);
+    GemmArgs g = base_args(h->xin16, h->x_embed, nclip * ntok);
     g.out_f32 = h->xres;
     g.ldo = D;
     g.pos = h->pos;
@@ -549,11 +559,13 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
     // head: token-blocked rows (every CFG row of 16 tokens in one workgroup: 4 x 32 workgroups of bc row tiles) unless the
     // CFG batch is not one of the combine's shapes; then all rows per workgroup (32 workgroups)
     static const bool tokblk_on = !getenv("FLOAT_FMT_NO_TOKBLK");
-    const bool tokblk = tokblk_on && (bc == 1 || bc == 3 || bc == 4) && h->final_lin.K % 256 == 0;
-    const int nblk = (ntok + 15) / 16;
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, nullptr, tokblk ? h->hfin16 : nullptr, tokblk ? bc * 16 : 0))) return rc;
-    GemmArgs g = base_args(tokblk ? h->hfin16 : h->h16, h->final_lin, tokblk ? nblk * bc * 16 : M);
+    const bool tokblk = (tokblk_on || nclip > 1) && (bc == 1 || bc == 3 || bc == 4) && h->final_lin.K % 256 == 0;
+    FH_REQUIRE(tokblk || nclip == 1, "batched sampling needs the token-blocked head GEMM");
+    const int nblk = (ntok + 15) / 16, seqs = nclip * bc;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, nullptr, tokblk ? h->hfin16 : nullptr, tokblk ? seqs * 16 : 0))) return rc;
+    GemmArgs g = base_args(tokblk ? h->hfin16 : h->h16, h->final_lin, tokblk ? nblk * seqs * 16 : M);
     g.tokblk = tokblk ? 1 : 0;
+    g.nclip = nclip;
     g.bc = bc;
     g.ntok = ntok;
     g.n_prev = c.n_prev;
@@ -568,6 +580,7 @@ int run_blocks(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, 
     } else {
       g.vout = vout_to ? vout_to : h->vout;
     }
+    // token-blocked: a workgroup = the bc row tiles of one (token block, clip) pair; row blocks = token blocks x clips
     if (tokblk) rc = launch_gemm<T, EPI_CFG>(g, bc, 1, 8, false, s);
     else rc = run_gemm<T, EPI_CFG>(g, s, true);
     if (rc) return rc;
@@ -614,12 +627,13 @@ int prepare_time(float_fmt* h, const TimeSpec& ts, int n, hipStream_t s) {
 struct CfgMode {
   int bc;
   unsigned wr_mask, wa_mask, we_mask;
+  int nclip = 1;  // clips stacked along the rows
 };
 
 CfgMode cfg_mode(float a, float r, float e, int include_r) {
-  if (a == 1.0f && r == 1.0f && e == 1.0f) return {1, 1u, 1u, 1u};  // FMT.py:346,400-401
-  if (!include_r) return {3, 0b111u, 0b110u, 0b010u};                // [null_wa,wa,wa] [null_we,we,null_we]
-  return {4, 0b1110u, 0b1100u, 0b0100u};                             // FMT.py:382-384
+  if (a == 1.0f && r == 1.0f && e == 1.0f) return {1, 1u, 1u, 1u, 1};  // FMT.py:346,400-401
+  if (!include_r) return {3, 0b111u, 0b110u, 0b010u, 1};                // [null_wa,wa,wa] [null_we,we,null_we]
+  return {4, 0b1110u, 0b1100u, 0b0100u, 1};                             // FMT.py:382-384
 }
 
 // Stage the conditions of one window (device pointers) and compute c_cond = c_embedder([wr,wa,we]).
@@ -627,7 +641,7 @@ template <class T>
 int stage_window(float_fmt* h, const CfgMode& m, const float* x0, const float* wa, const float* wr, const float* we,
                  int we_len, const float* prev_x, const float* prev_wa, const float* prev_we, hipStream_t s) {
   const float_fmt_cfg_t& c = h->cfg;
-  const int M = m.bc * h->ntok;
+  const int M = m.nclip * m.bc * h->ntok;
   hipLaunchKernelGGL((fmt_build_cond_kernel<T>), dim3(M), dim3(256), 0, s, h->cond16, h->Kc, m.bc, h->ntok, c.n_prev,
                      c.dim_w, c.dim_a, c.dim_e, wr, wa, prev_wa, we, we_len, prev_we, m.wr_mask, m.wa_mask, m.we_mask);
   GemmArgs g = base_args(h->cond16, h->c_embed, M);
@@ -635,9 +649,9 @@ int stage_window(float_fmt* h, const CfgMode& m, const float* x0, const float* w
   g.ldo = h->D;
   int rc;
   if ((rc = run_gemm<T, EPI_F32>(g, s))) return rc;
-  const int n = h->ntok * c.dim_w;
+  const int n = m.nclip * h->ntok * c.dim_w;
   hipLaunchKernelGGL((fmt_init_x_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->xin16, h->Kx / 32, x0, prev_x,
-                     c.n_prev, c.n_cur, c.dim_w);
+                     c.n_prev, c.n_cur, c.dim_w, m.nclip);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -691,7 +705,8 @@ int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<
                      hipStream_t s) {
   const Tableau& tb = tableau(h->method);
   const float_fmt_cfg_t& c = h->cfg;
-  const int kstride = kMaxTok * c.dim_w, n = c.n_cur * c.dim_w;
+  const size_t kstride = (size_t)h->Bmax * kMaxTok * c.dim_w;  // one stage's velocities: [clip][ntok][dim_w]
+  const int n = m.nclip * c.n_cur * c.dim_w, rows = m.nclip * m.bc * h->ntok;
   const int nev = n_evals(h->method, nfe), batch = g_fmt_hoist ? kScSteps : 1;
   const size_t zs = (size_t)h->Mmod * h->Ntot;
   const bool euler = h->method == FLOAT_ODE_EULER;
@@ -699,23 +714,23 @@ int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<
   for (int ev = 0; ev < nev; ++ev) {
     const int i = ev / tb.s, j = ev - i * tb.s, z = ev % batch;
     const float dt = ts[i + 1] - ts[i];
-    if (z == 0 && (rc = run_mod_all<T>(h, m.bc, ev, std::min(batch, nev - ev), s))) return rc;
+    if (z == 0 && (rc = run_mod_all<T>(h, rows, ev, std::min(batch, nev - ev), s))) return rc;
     const float* mod = h->modall + (size_t)z * zs;
     if (euler) {
-      if ((rc = run_blocks<T>(h, m.bc, mod, true, dt, a, r, e, s))) return rc;
+      if ((rc = run_blocks<T>(h, m.nclip, m.bc, mod, true, dt, a, r, e, s))) return rc;
       continue;
     }
     // fixed-grid explicit Runge-Kutta: stage j evaluates at y0 + dt sum_m a[j][m] k_m, the update is dt sum_j b_j k_j
     if (j > 0) {
       hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, j,
                          dt * tb.a[j][0], dt * tb.a[j][1], dt * tb.a[j][2], 0.f, 0, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
-                         c.dim_w);
+                         c.dim_w, m.nclip);
     }
-    if ((rc = run_blocks<T>(h, m.bc, mod, false, 0.f, a, r, e, s, h->kbuf + (size_t)j * kstride))) return rc;
+    if ((rc = run_blocks<T>(h, m.nclip, m.bc, mod, false, 0.f, a, r, e, s, h->kbuf + (size_t)j * kstride))) return rc;
     if (j == tb.s - 1) {
       hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, tb.s,
                          dt * tb.b[0], dt * tb.b[1], dt * tb.b[2], dt * tb.b[3], 1, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
-                         c.dim_w);
+                         c.dim_w, m.nclip);
     }
   }
   FH_CHECK_HIP(hipGetLastError());
@@ -734,6 +749,7 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
   key.nfe = nfe;
   key.method = h->method;
   key.bc = m.bc;
+  key.nclip = m.nclip;
   key.we_len = we_len;
   key.a = a;
   key.r = r;
@@ -775,8 +791,9 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
 template <class T>
 int window_impl(float_fmt* h, const float* x0, const float* wa, const float* wr, const float* we, int we_len,
                 const float* prev_x, const float* prev_wa, const float* prev_we, int nfe, const std::vector<float>& ts,
-                float a, float r, float e, int include_r, hipStream_t s) {
-  const CfgMode m = cfg_mode(a, r, e, include_r);
+                float a, float r, float e, int include_r, hipStream_t s, int nclip = 1) {
+  CfgMode m = cfg_mode(a, r, e, include_r);
+  m.nclip = nclip;
   // only the all-rows-per-workgroup head (FLOAT_FMT_NO_TOKBLK, a debugging aid) is limited to 15 row tiles
   FH_REQUIRE(!getenv("FLOAT_FMT_NO_TOKBLK") || m.bc * h->ntok <= 240,
              "%d-way CFG of %d tokens is %d rows; the all-rows CFG epilogue GEMM holds at most 240 (15 row tiles)", m.bc, h->ntok,
@@ -810,8 +827,8 @@ int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const floa
              "%d-way CFG of %d tokens is %d rows; the all-rows CFG epilogue GEMM holds at most 240 (15 row tiles)", m.bc, h->ntok,
              m.bc * h->ntok);
   if ((rc = stage_window<T>(h, m, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s))) return rc;
-  if ((rc = run_mod_all<T>(h, m.bc, 0, 1, s))) return rc;
-  if ((rc = run_blocks<T>(h, m.bc, h->modall, false, 0.f, a, r, e, s))) return rc;
+  if ((rc = run_mod_all<T>(h, m.bc * h->ntok, 0, 1, s))) return rc;
+  if ((rc = run_blocks<T>(h, 1, m.bc, h->modall, false, 0.f, a, r, e, s))) return rc;
   FH_CHECK_HIP(hipMemcpyAsync(out, h->vout, (size_t)h->ntok * h->cfg.dim_w * sizeof(float), hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
 }
@@ -821,38 +838,34 @@ template <class T>
 int sample_window(float_fmt* h, int k, hipStream_t s) {
   const float_fmt_cfg_t& c = h->cfg;
   auto& J = h->job;
-  const int L = c.n_cur, P = c.n_prev, Tn = J.T;
+  const int L = c.n_cur, P = c.n_prev, Tn = J.T, B = J.B;
   const bool dynamic = J.we_len > 1;
   int rc;
+  auto blocks = [](int n) { return dim3((n + 255) / 256); };
   if (k == 0) {
     if ((rc = prepare_time<T>(h, time_spec(h->method, J.nfe), std::max(1, n_evals(h->method, J.nfe)), s))) return rc;
     // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
-    FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)P * c.dim_w * sizeof(float), s));
-    FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)P * c.dim_a * sizeof(float), s));
-    FH_CHECK_HIP(hipMemsetAsync(h->prev_we, 0, (size_t)P * c.dim_e * sizeof(float), s));
-  } else {
-    // AR hand-off: last P frames of the previous final sample / (padded) wa window / we window
-    FH_CHECK_HIP(hipMemcpyAsync(h->prev_x, h->xcur + (size_t)(L - P) * c.dim_w, (size_t)P * c.dim_w * sizeof(float),
-                                hipMemcpyDeviceToDevice, s));
-    FH_CHECK_HIP(hipMemcpyAsync(h->prev_wa, h->wa_c + (size_t)(L - P) * c.dim_a, (size_t)P * c.dim_a * sizeof(float),
-                                hipMemcpyDeviceToDevice, s));
-    if (dynamic)
-      FH_CHECK_HIP(hipMemcpyAsync(h->prev_we, h->we_c + (size_t)(L - P) * c.dim_e, (size_t)P * c.dim_e * sizeof(float),
-                                  hipMemcpyDeviceToDevice, s));
+    FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)B * P * c.dim_w * sizeof(float), s));
+    FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)B * P * c.dim_a * sizeof(float), s));
+    FH_CHECK_HIP(hipMemsetAsync(h->prev_we, 0, (size_t)B * P * c.dim_e * sizeof(float), s));
+  } else if (P > 0) {
+    // AR hand-off: last P frames of the previous final sample / (padded) wa window / we window, per clip
+    hipLaunchKernelGGL(fmt_tail_kernel, blocks(B * P * c.dim_w), dim3(256), 0, s, h->prev_x, h->xcur, P, L, c.dim_w, B);
+    hipLaunchKernelGGL(fmt_tail_kernel, blocks(B * P * c.dim_a), dim3(256), 0, s, h->prev_wa, h->wa_c, P, L, c.dim_a, B);
+    if (dynamic) hipLaunchKernelGGL(fmt_tail_kernel, blocks(B * P * c.dim_e), dim3(256), 0, s, h->prev_we, h->we_c, P, L, c.dim_e, B);
   }
-  hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_a + 255) / 256), dim3(256), 0, s, h->wa_c, J.wa, k * L, Tn, L, c.dim_a);
-  if (dynamic)
-    hipLaunchKernelGGL(fmt_slice_pad_kernel, dim3((L * c.dim_e + 255) / 256), dim3(256), 0, s, h->we_c, J.we, k * L, Tn, L,
-                       c.dim_e);
-  // x0 is copied into the workspace so the window chain only ever sees handle-owned pointers
-  FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, J.noise + (size_t)k * L * c.dim_w, (size_t)L * c.dim_w * sizeof(float),
+  hipLaunchKernelGGL(fmt_slice_pad_kernel, blocks(B * L * c.dim_a), dim3(256), 0, s, h->wa_c, J.wa, k * L, Tn, L, c.dim_a, B);
+  if (dynamic) hipLaunchKernelGGL(fmt_slice_pad_kernel, blocks(B * L * c.dim_e), dim3(256), 0, s, h->we_c, J.we, k * L, Tn, L, c.dim_e, B);
+  // x0 is copied into the workspace so the window chain only ever sees handle-owned pointers; noise is (windows, clips, L, dim_w)
+  FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, J.noise + (size_t)k * B * L * c.dim_w, (size_t)B * L * c.dim_w * sizeof(float),
                               hipMemcpyDeviceToDevice, s));
   rc = window_impl<T>(h, h->x0_c, h->wa_c, J.wr, dynamic ? h->we_c : J.we, dynamic ? L : 1, h->prev_x, h->prev_wa,
-                      dynamic ? h->prev_we : nullptr, J.nfe, J.ts, J.a, J.r, J.e, J.include_r, s);
+                      dynamic ? h->prev_we : nullptr, J.nfe, J.ts, J.a, J.r, J.e, J.include_r, s, B);
   if (rc) return rc;
   const int rows = (k == J.n_chunks - 1) ? (Tn - k * L) : L;  // trim to T (FLOAT.py:252)
-  FH_CHECK_HIP(hipMemcpyAsync(J.r_d + (size_t)k * L * c.dim_w, h->xcur, (size_t)rows * c.dim_w * sizeof(float),
-                              hipMemcpyDeviceToDevice, s));
+  FH_CHECK_HIP(hipMemcpy2DAsync(J.r_d + (size_t)k * L * c.dim_w, (size_t)Tn * c.dim_w * sizeof(float), h->xcur,
+                                (size_t)L * c.dim_w * sizeof(float), (size_t)rows * c.dim_w * sizeof(float), (size_t)B,
+                                hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
 }
 
@@ -978,13 +991,15 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   FH_REQUIRE(cfg->n_prev + cfg->n_cur <= kMaxTok, "at most %d tokens per window (got %d)", kMaxTok, cfg->n_prev + cfg->n_cur);
   FH_REQUIRE(cfg->n_prev >= 0 && cfg->n_prev <= cfg->n_cur, "n_prev must be in [0, n_cur]");
   FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
+  FH_REQUIRE(cfg->max_batch >= 0 && cfg->max_batch <= 16, "max_batch must be in [0, 16] (got %d)", cfg->max_batch);
   float_fmt* h = new float_fmt();
   h->cfg = *cfg;
   h->D = cfg->dim_h;
   h->ntok = cfg->n_prev + cfg->n_cur;
   // rows of every activation buffer: the 4-way CFG batch plus the row tiles a row-blocked tiling reads past it (row blocks
   // are 3-6 tiles; their operand loads are not guarded, the rows are zero and their results are dropped)
-  h->Mpad = 16 * ((4 * h->ntok + 15) / 16 + 6);
+  h->Bmax = cfg->max_batch > 0 ? cfg->max_batch : 1;
+  h->Mpad = 16 * ((h->Bmax * 4 * h->ntok + 15) / 16 + 6);
   h->Kc = round_up(cfg->dim_w + cfg->dim_a + cfg->dim_e, 128);
   h->Kx = round_up(cfg->dim_w, 128);
   if (const char* wd = getenv("FLOAT_FMT_WIDE")) g_fmt_wide = atoi(wd) != 0;
@@ -1008,32 +1023,32 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->pos, (size_t)kMaxTok * D);
   A(&h->freqs, 128);
   A(&h->cond16, (size_t)Mp * h->Kc);
-  A(&h->sc16, (size_t)kScSteps * Mp * D);
+  A(&h->sc16, (size_t)kScSteps * Mp * D + (size_t)12 * 16 * D);  // + the row tiles a 192-row block reads past the last batch
   A(&h->h16, (size_t)Mp * D);
-  A(&h->hfin16, (size_t)64 * ((kMaxTok + 15) / 16) * D);  // token-blocked rows of the head GEMM, 4 CFG rows x 16 tokens per block
+  A(&h->hfin16, (size_t)h->Bmax * 64 * ((kMaxTok + 15) / 16) * D);  // token-blocked rows of the head GEMM, clips x 4 CFG rows x 16 tokens per block
   A(&h->qkv16, (size_t)Mp * 3 * D);
   A(&h->att16, (size_t)Mp * D);
   A(&h->hid16, (size_t)Mp * cfg->mlp_hidden);
-  A(&h->xin16, (size_t)(kMaxTok + 6 * 16) * h->Kx);  // + the row tiles a row-blocked tiling reads past the last token (zero)
+  A(&h->xin16, (size_t)(h->Bmax * kMaxTok + 6 * 16) * h->Kx);  // + the row tiles a row-blocked tiling reads past the last token (zero)
   A(&h->tsin16, (size_t)kMaxSteps * 256);
   A(&h->th16, (size_t)kMaxSteps * D);
   A(&h->ccond, (size_t)Mp * D);
   // modulations of a batch of evaluations (run_mod_all): never zero-filled or read before written, up to 3.1 GB at the
   // default shape (64 x 240 x 51 200 fp32) of the 288 GB
-  h->Mmod = 16 * ((4 * h->ntok + 15) / 16);
+  h->Mmod = 16 * ((h->Bmax * 4 * h->ntok + 15) / 16);
   if (!rc) rc = h->pool.alloc(&h->modall, (size_t)kScSteps * h->Mmod * h->Ntot, false);
-  A(&h->kbuf, (size_t)4 * kMaxTok * cfg->dim_w);
+  A(&h->kbuf, (size_t)4 * h->Bmax * kMaxTok * cfg->dim_w);
   A(&h->xres, (size_t)Mp * D);
   A(&h->slab, (size_t)4 * Mp * D);
-  A(&h->xcur, (size_t)cfg->n_cur * cfg->dim_w);
+  A(&h->xcur, (size_t)h->Bmax * cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
-  A(&h->vout, (size_t)kMaxTok * cfg->dim_w);
-  A(&h->wa_c, (size_t)cfg->n_cur * cfg->dim_a);
-  A(&h->we_c, (size_t)cfg->n_cur * cfg->dim_e);
-  A(&h->x0_c, (size_t)cfg->n_cur * cfg->dim_w);
-  A(&h->prev_x, (size_t)cfg->n_cur * cfg->dim_w);
-  A(&h->prev_wa, (size_t)cfg->n_cur * cfg->dim_a);
-  A(&h->prev_we, (size_t)cfg->n_cur * cfg->dim_e);
+  A(&h->vout, (size_t)h->Bmax * kMaxTok * cfg->dim_w);
+  A(&h->wa_c, (size_t)h->Bmax * cfg->n_cur * cfg->dim_a);
+  A(&h->we_c, (size_t)h->Bmax * cfg->n_cur * cfg->dim_e);
+  A(&h->x0_c, (size_t)h->Bmax * cfg->n_cur * cfg->dim_w);
+  A(&h->prev_x, (size_t)h->Bmax * cfg->n_cur * cfg->dim_w);
+  A(&h->prev_wa, (size_t)h->Bmax * cfg->n_cur * cfg->dim_a);
+  A(&h->prev_we, (size_t)h->Bmax * cfg->n_cur * cfg->dim_e);
   if (!rc) {
     // pos_embed: from the checkpoint when present, else regenerated like the VA loader does
     // (nodes_vadv_loader.py:822-840): sin on even, cos on odd feature indices (FMT.py:29-37).
@@ -1156,6 +1171,7 @@ int float_fmt_sample_begin(float_fmt_t* h, const float* wr, const float* wa, int
   J.a = a_cfg;
   J.r = r_cfg;
   J.e = e_cfg;
+  J.B = 1;
   J.next = 0;
   J.n_chunks = (T + h->cfg.n_cur - 1) / h->cfg.n_cur;
   linspace01(nfe, &J.ts);
@@ -1177,6 +1193,20 @@ int float_fmt_sample_next(float_fmt_t* h, void* stream, int32_t* window_done, in
   if (window_done) *window_done = k;
   if (windows_left) *windows_left = J.n_chunks - J.next;
   if (J.next >= J.n_chunks) J.active = false;
+  return FLOAT_OK;
+}
+
+int float_fmt_sample_batch(float_fmt_t* h, int32_t n_clips, const float* wr, const float* wa, int32_t T, const float* we,
+                           int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg, float e_cfg,
+                           int32_t include_r_cfg, float* r_d, void* stream) {
+  FH_REQUIRE(h != nullptr, "null FMT handle");
+  FH_REQUIRE(n_clips >= 1 && n_clips <= h->Bmax, "batch of %d clips, the handle was created with max_batch = %d", n_clips, h->Bmax);
+  int rc = float_fmt_sample_begin(h, wr, wa, T, we, we_len, noise, nfe, a_cfg, r_cfg, e_cfg, include_r_cfg, r_d);
+  if (rc) return rc;
+  h->job.B = n_clips;
+  int32_t left = 1;
+  while (left > 0)
+    if ((rc = float_fmt_sample_next(h, stream, nullptr, &left))) return rc;
   return FLOAT_OK;
 }
 

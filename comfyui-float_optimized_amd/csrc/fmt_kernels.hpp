@@ -146,9 +146,13 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
     return a;
   };
   if constexpr (EPI == EPI_CFG) {
-    // rows of the tile: b * ntok + i, or b * 16 + i % 16 of token block `by` (g.tokblk).  Combine the CFG rows of token i,
-    // then (optionally) Euler.
-    const int ni = g.tokblk ? 16 : g.ntok, i0 = g.tokblk ? by * 16 : 0, rstride = g.tokblk ? 16 : g.ntok;
+    // rows of the tile: b * ntok + i (one clip, all rows in the workgroup), or b * 16 + i % 16 of (token block, clip) pair `by`
+    // (g.tokblk: by = token block * nclip + clip).  Combine the CFG rows of token i, then (optionally) Euler.
+    const int nclip = g.nclip > 1 ? g.nclip : 1;
+    const int tb = g.tokblk ? by / nclip : 0, q = g.tokblk ? by - tb * nclip : 0;
+    const int ni = g.tokblk ? 16 : g.ntok, i0 = tb * 16, rstride = g.tokblk ? 16 : g.ntok;
+    float* const vout_q = g.vout ? g.vout + (size_t)q * g.ntok * g.N : nullptr;
+    float* const xcur_q = g.xcur ? g.xcur + (size_t)q * (g.ntok - g.n_prev) * g.N : nullptr;
     for (int idx = threadIdx.x; idx < ni * BN; idx += NTHR) {
       const int il = idx / BN, i = i0 + il, c = idx % BN, n = n0 + c;
       if (i >= g.ntok) break;
@@ -171,12 +175,12 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
       } else {  // [null-ref | uncond | all | audio-only]
         out = v[0] + g.r_cfg * (v[1] - v[0]) + g.a_cfg * (v[3] - v[1]) + g.e_cfg * (v[2] - v[3]);
       }
-      if (g.vout) g.vout[(size_t)i * g.N + n] = out;
-      if (g.xcur && i >= g.n_prev) {
+      if (vout_q) vout_q[(size_t)i * g.N + n] = out;
+      if (xcur_q && i >= g.n_prev) {
         const size_t xo = (size_t)(i - g.n_prev) * g.N + n;
-        const float xn = g.xcur[xo] + g.dt * out;  // x_{k+1} = x_k + dt * v  (fixed-grid Euler)
-        g.xcur[xo] = xn;
-        g.xin16[fmt_pack_off(i, n, g.ldx)] = T::from_float(xn);
+        const float xn = xcur_q[xo] + g.dt * out;  // x_{k+1} = x_k + dt * v  (fixed-grid Euler)
+        xcur_q[xo] = xn;
+        g.xin16[fmt_pack_off(q * g.ntok + i, n, g.ldx)] = T::from_float(xn);
       }
     }
   } else {
@@ -243,11 +247,13 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
           *reinterpret_cast<float4*>(o + e) = x;
         }
       } else if constexpr (EPI == EPI_XEMBED) {
-        const float* ps = g.pos + (size_t)row * g.N + nb;
+        // input row = clip * ntok + token (the CFG rows of a clip share x); output rows (clip * bc + b2) * ntok + token
+        const int q = row / g.ntok, tok = row - q * g.ntok;
+        const float* ps = g.pos + (size_t)tok * g.N + nb;
 #pragma unroll
         for (int i = 0; i < 8; ++i) v[i] += ps[i];
         for (int b2 = 0; b2 < g.bc; ++b2) {
-          float* o = g.out_f32 + (size_t)(b2 * g.ntok + row) * g.ldo + nb;
+          float* o = g.out_f32 + (size_t)((q * g.bc + b2) * g.ntok + tok) * g.ldo + nb;
           *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
           *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
         }
@@ -483,7 +489,8 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
     s2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
   }
   const float rstd = rsqrtf(wave_sum(s2) * (1.f / D) + 1e-6f);
-  // perm = bc * 16: token-blocked output rows for the CFG head GEMM (GemmArgs::tokblk)
+  // perm = (clips * bc) * 16: token-blocked output rows for the CFG head GEMM (GemmArgs::tokblk); b counts the
+  // (clip, CFG row) sequences, so a token block holds clip-major, CFG-row-minor row tiles
   int orow = row;
   if (perm) {
     const int b = row / ntok, i = row - b * ntok;
@@ -622,9 +629,16 @@ __global__ void fmt_build_cond_kernel(u16* __restrict__ out, int ld, int bc, int
                                       const float* __restrict__ prev_wa, const float* __restrict__ we, int we_len,
                                       const float* __restrict__ prev_we, unsigned wr_mask, unsigned wa_mask,
                                       unsigned we_mask) {
+  // row = (clip * bc + b) * ntok + i; per-clip tensors are stacked: wr (clips, dim_w), wa (clips, n_cur, dim_a),
+  // prev_wa (clips, n_prev, dim_a), we (clips, we_len, dim_e), prev_we (clips, n_prev, dim_e)
   const int row = blockIdx.x;
-  const int b = row / ntok, i = row % ntok;
+  const int s = row / ntok, i = row % ntok, q = s / bc, b = s - q * bc, n_cur = ntok - n_prev;
   const bool on_r = (wr_mask >> b) & 1, on_a = (wa_mask >> b) & 1, on_e = (we_mask >> b) & 1;
+  wr += (size_t)q * dim_w;
+  wa += (size_t)q * n_cur * dim_a;
+  prev_wa += (size_t)q * n_prev * dim_a;
+  we += (size_t)q * we_len * dim_e;
+  if (prev_we) prev_we += (size_t)q * n_prev * dim_e;
   for (int c = threadIdx.x; c < ld; c += blockDim.x) {
     float v = 0.f;
     if (c < dim_w) {
@@ -702,48 +716,61 @@ __global__ void fmt_silu_c_kernel(u16* __restrict__ out, const float* __restrict
   *reinterpret_cast<uint4*>(out + fmt_pack_off(row, c, D / 32)) = u;
 }
 
-// Euler state and x_embedder input rows for a new window: xcur = x0; xin16 = [prev_x ; x0].
+// Euler state and x_embedder input rows for a new window, per clip q: xcur[q] = x0[q]; xin16 rows q * ntok + i = [prev_x[q] ; x0[q]].
 template <class T>
 __global__ void fmt_init_x_kernel(float* __restrict__ xcur, u16* __restrict__ xin16, int ldx, const float* __restrict__ x0,
-                                  const float* __restrict__ prev_x, int n_prev, int n_cur, int dim_w) {
+                                  const float* __restrict__ prev_x, int n_prev, int n_cur, int dim_w, int nclip) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int ntok = n_prev + n_cur;
-  if (idx >= ntok * dim_w) return;
-  const int i = idx / dim_w, c = idx % dim_w;
+  if (idx >= nclip * ntok * dim_w) return;
+  const int q = idx / (ntok * dim_w), r = idx - q * ntok * dim_w;
+  const int i = r / dim_w, c = r % dim_w;
   float v;
   if (i < n_prev) {
-    v = prev_x[i * dim_w + c];
+    v = prev_x[((size_t)q * n_prev + i) * dim_w + c];
   } else {
-    v = x0[(i - n_prev) * dim_w + c];
-    xcur[(i - n_prev) * dim_w + c] = v;
+    v = x0[((size_t)q * n_cur + (i - n_prev)) * dim_w + c];
+    xcur[((size_t)q * n_cur + (i - n_prev)) * dim_w + c] = v;
   }
-  xin16[fmt_pack_off(i, c, ldx)] = T::from_float(v);
+  xin16[fmt_pack_off(q * ntok + i, c, ldx)] = T::from_float(v);
 }
 
 // Explicit Runge-Kutta glue for the non-Euler fixed-grid solvers: y = xcur + sum_m coef[m] * k_m over the
-// current-window rows (coef already includes dt).  final = 0: y is the next stage's input (packed 16-bit
+// current-window rows of every clip (coef already includes dt).  final = 0: y is the next stage's input (packed 16-bit
 // rows of the x_embedder operand); final = 1: y becomes the new state and the next step's stage-0 input.
+// kbuf: [stage][clip][ntok][W] with stage stride kstride.
 template <class T>
-__global__ void fmt_rk_combine_kernel(float* __restrict__ xcur, const float* __restrict__ kbuf, int kstride, int nk, float c0,
+__global__ void fmt_rk_combine_kernel(float* __restrict__ xcur, const float* __restrict__ kbuf, size_t kstride, int nk, float c0,
                                       float c1, float c2, float c3, int final, u16* __restrict__ xin16, int ldx, int n_prev,
-                                      int n_cur, int W) {
+                                      int n_cur, int W, int nclip) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n_cur * W) return;
-  const int i = idx / W, c = idx % W;
+  if (idx >= nclip * n_cur * W) return;
+  const int q = idx / (n_cur * W), r = idx - q * n_cur * W;
+  const int i = r / W, c = r % W, ntok = n_prev + n_cur;
   const float cf[4] = {c0, c1, c2, c3};
   float y = xcur[idx];
-  for (int m = 0; m < nk; ++m) y += cf[m] * kbuf[(size_t)m * kstride + (size_t)(n_prev + i) * W + c];
+  for (int m = 0; m < nk; ++m) y += cf[m] * kbuf[(size_t)m * kstride + ((size_t)q * ntok + n_prev + i) * W + c];
   if (final) xcur[idx] = y;
-  xin16[fmt_pack_off(n_prev + i, c, ldx)] = T::from_float(y);
+  xin16[fmt_pack_off(q * ntok + n_prev + i, c, ldx)] = T::from_float(y);
 }
 
-// Window slice with replicate padding along time (FLOAT.py:224-227): dst[i] = src[min(t0+i, T-1)].
-__global__ void fmt_slice_pad_kernel(float* __restrict__ dst, const float* __restrict__ src, int t0, int T, int n, int dim) {
+// Window slice with replicate padding along time (FLOAT.py:224-227), per clip: dst[q][i] = src[q][min(t0+i, T-1)].
+__global__ void fmt_slice_pad_kernel(float* __restrict__ dst, const float* __restrict__ src, int t0, int T, int n, int dim,
+                                     int nclip) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= n * dim) return;
-  const int i = idx / dim, c = idx % dim;
+  if (idx >= nclip * n * dim) return;
+  const int q = idx / (n * dim), r = idx - q * n * dim;
+  const int i = r / dim, c = r % dim;
   const int t = min(t0 + i, T - 1);
-  dst[idx] = src[(size_t)t * dim + c];
+  dst[idx] = src[((size_t)q * T + t) * dim + c];
+}
+
+// AR hand-off (FLOAT.py:217-222; nodes_adv.py:682-686), per clip: dst[q] = the last n_prev rows of src[q] (n_cur rows).
+__global__ void fmt_tail_kernel(float* __restrict__ dst, const float* __restrict__ src, int n_prev, int n_cur, int dim, int nclip) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nclip * n_prev * dim) return;
+  const int q = idx / (n_prev * dim), r = idx - q * n_prev * dim;
+  dst[idx] = src[((size_t)q * n_cur + (n_cur - n_prev)) * dim + r];
 }
 
 // Test hook (float_fmt_debug): fp32 rows -> the row-major 16-bit q|k|v operand of fmt_attn_kernel, and its packed output back.

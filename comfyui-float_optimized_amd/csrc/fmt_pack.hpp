@@ -72,6 +72,7 @@ struct GemmArgs {
   int ldg;
   const float* pos;
   int bc, ntok, n_prev;
+  int nclip;      // independent clips stacked along the rows (row = (clip * bc + cfg row) * ntok + token); 0 / 1 = one clip
   // EPI_CFG
   float a_cfg, r_cfg, e_cfg, dt;
   float* vout;   // (ntok, N) combined velocity (float_fmt_eval) or nullptr

@@ -11,18 +11,22 @@ from .config import FmtConfig
 
 
 class FlowMatchingTransformerHIP:
-    """Holds packed weights + workspace on one GPU.  Batch items are looped on the host, like the
+    """Holds packed weights + workspace on one GPU.  `sample` stacks up to `max_batch` clips per launch chain
+    (float_fmt_sample_batch); the single-evaluation / single-window calls loop batch items on the host, like the
     reference's FloatProcess (nodes.py:189-209)."""
 
-    def __init__(self, state_dict, cfg: FmtConfig = None, device="cuda:0", dtype="fp16", use_graph=2):
+    def __init__(self, state_dict, cfg: FmtConfig = None, device="cuda:0", dtype="fp16", use_graph=2, max_batch=1):
+        """max_batch: clips `sample` may run through one launch chain (float_fmt_sample_batch); larger batches are cut
+        into groups of that size.  Sizes the workspace (3.1 GB of modulation slab per clip at the default shape)."""
         self.cfg = cfg or FmtConfig()
         self.device = torch.device(device)
         self.dtype = dtype
+        self.max_batch = max(1, int(max_batch))
         L = native.lib()
         c = self.cfg
         ncfg = native.FmtCfg(c.dim_w, c.dim_a, c.dim_e, c.dim_h, c.fmt_depth, c.num_heads,
                              int(c.dim_h * c.mlp_ratio), c.num_prev_frames, c.num_frames_for_clip,
-                             c.attention_window, native.DTYPES[dtype], int(use_graph))
+                             c.attention_window, native.DTYPES[dtype], int(use_graph), self.max_batch)
         sd = {k[4:] if k.startswith("fmt.") else k: v for k, v in state_dict.items()
               if k not in ("alignment_mask", "fmt.alignment_mask")}
         arr, keep = native.tensor_table(sd)
@@ -153,12 +157,13 @@ class FlowMatchingTransformerHIP:
         r_d = torch.empty(B, T, c.dim_w, device=self.device, dtype=torch.float32)
         with torch.cuda.device(self.device):
             s = native.stream_ptr(self.device)
-            for b in range(B):
-                nb = noise[:, b].contiguous()
-                native.check(L.float_fmt_sample(
-                    self._h, native.dev_ptr(r_s[b]), native.dev_ptr(wa[b]), T, native.dev_ptr(we[b]), we.shape[1],
-                    native.dev_ptr(nb), int(nfe), a_cfg_scale, r_cfg_scale, e_cfg_scale, 1 if include_r_cfg else 0,
-                    native.dev_ptr(r_d[b]), s))
+            for b0 in range(0, B, self.max_batch):
+                nb = min(self.max_batch, B - b0)
+                nz = noise[:, b0:b0 + nb].contiguous()
+                native.check(L.float_fmt_sample_batch(
+                    self._h, nb, native.dev_ptr(r_s[b0:b0 + nb]), native.dev_ptr(wa[b0:b0 + nb]), T,
+                    native.dev_ptr(we[b0:b0 + nb]), we.shape[1], native.dev_ptr(nz), int(nfe), a_cfg_scale, r_cfg_scale,
+                    e_cfg_scale, 1 if include_r_cfg else 0, native.dev_ptr(r_d[b0:b0 + nb]), s))
         return r_d
 
 

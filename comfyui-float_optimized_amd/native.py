@@ -24,7 +24,7 @@ class FloatTensor(C.Structure):
 
 class FmtCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("dim_w", "dim_a", "dim_e", "dim_h", "depth", "heads", "mlp_hidden",
-                                         "n_prev", "n_cur", "attn_window", "dtype", "use_graph")]
+                                         "n_prev", "n_cur", "attn_window", "dtype", "use_graph", "max_batch")]
 
 
 class DecCfg(C.Structure):
@@ -60,6 +60,8 @@ _SIGNATURES = {
                                [C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "float_fmt_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                    C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
+    "float_fmt_sample_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                         C.c_void_p, C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_void_p]),
     "float_fmt_sample_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p]),
     "float_fmt_sample_next": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -108,7 +110,7 @@ def lib():
             raise NativeLibraryError("libfloat_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if L.float_hip_abi_version() != 1:
+    if L.float_hip_abi_version() != 2:
         raise NativeLibraryError("libfloat_hip.so ABI version mismatch")
     _lib = L
     return L

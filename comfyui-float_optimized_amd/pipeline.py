@@ -13,11 +13,11 @@ from .fmt import FlowMatchingTransformerHIP, WindowSampler, draw_noise
 
 class FloatHotPath:
     def __init__(self, fmt_state, dec_state, cfg: FmtConfig = None, device="cuda:0", size=512, fmt_dtype="fp16",
-                 dec_dtype="fp16", max_frames=32, use_graph=2):
+                 dec_dtype="fp16", max_frames=32, use_graph=2, max_batch=1):
         self.cfg = cfg or FmtConfig()
         self.device = torch.device(device)
         self.size = size
-        self.fmt = FlowMatchingTransformerHIP(fmt_state, self.cfg, device, fmt_dtype, use_graph)
+        self.fmt = FlowMatchingTransformerHIP(fmt_state, self.cfg, device, fmt_dtype, use_graph, max_batch)
         self.dec = SynthesisHIP(dec_state, size, self.cfg.dim_w, device, dec_dtype, max_frames)
 
     def n_chunks(self, T):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define FLOAT_HIP_ABI_VERSION 1
+#define FLOAT_HIP_ABI_VERSION 2
 
 enum {
   FLOAT_OK = 0,
@@ -65,6 +65,9 @@ typedef struct {
   int32_t use_graph;       /* 0: eager launches; != 0: replay each window's chain from a cached hipGraph (at most 8
                               graphs per handle, least recently used evicted).  1 and 2 are the same (1 used to put the
                               adaLN GEMM on a parallel branch; that GEMM now runs once per window, not per step). */
+  int32_t max_batch;       /* clips float_fmt_sample_batch may stack per launch chain (sizes the workspace: rows = max_batch x 4 CFG
+                              rows x tokens; the per-window modulation slab is 64 x rows x (depth * 6 + 2) * dim_h fp32, 3.1 GB per
+                              clip at the default shape); 0 = 1 */
 } float_fmt_cfg_t;
 
 typedef struct float_fmt float_fmt_t;
@@ -104,6 +107,16 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
 int float_fmt_sample(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we,
                      int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg,
                      float e_cfg, int32_t include_r_cfg, float* r_d, void* stream);
+
+/* B independent clips of equal length through ONE launch chain (the reference's samplers take a batch: nodes_vadv.py:618-735
+ * -> nodes_adv.py:545-694, x0 = randn(B, 50, 512) at FLOAT.py:215): the clips' rows are stacked, so every weight is read once
+ * per evaluation for all of them.  Each clip's result is what float_fmt_sample gives for it alone, bit for bit where the
+ * GEMM tilings coincide and within rounding otherwise (the tiling depends on the row count).
+ *   wr: (B, dim_w)   wa: (B, T, dim_a)   we: (B, we_len, dim_e)   noise: (windows, B, n_cur, dim_w)   r_d: (B, T, dim_w)
+ * n_clips <= max_batch of the handle. */
+int float_fmt_sample_batch(float_fmt_t* h, int32_t n_clips, const float* wr, const float* wa, int32_t T,
+                           const float* we, int32_t we_len, const float* noise, int32_t nfe, float a_cfg,
+                           float r_cfg, float e_cfg, int32_t include_r_cfg, float* r_d, void* stream);
 
 /* The same loop one window at a time, so the caller can overlap the decode of window k (on another
  * stream) with the sampling of window k+1: _begin only records the job (pointers must stay valid

@@ -114,3 +114,46 @@ def test_other_temporal_structures(n_prev, n_cur, window):
     assert got.shape == (1, T, cfg.dim_w) and rel_l2(got, want) < 4e-3
     got4 = f.sample(r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, include_r_cfg=True).cpu()  # up to 4 x 70 = 280 rows
     assert rel_l2(got4, O.sample_rd(sd, cfg, r_s, wa, we, noise, 4, 2.0, 1.5, 1.0, True)) < 4e-3
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("B,dynamic,rcfg", [(2, False, False), (4, True, False), (3, False, True)])
+def test_batched_sampling_equals_per_clip(B, dynamic, rcfg, dtype):
+    """float_fmt_sample_batch: B clips stacked along the rows of ONE launch chain (nodes_vadv.py:618-735 takes batches).  Each
+    clip must be what the one-clip chain gives for it - within rounding, the GEMM tilings depend on the row count - and
+    within the operand type's tolerance of the oracle; 70 frames = 2 windows, so the per-clip AR hand-off, replicate pad and
+    (dynamic) prev_we are covered."""
+    sd = pkg.weights.synth_fmt_state(CFG, seed=41)
+    one = pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", dtype)
+    many = pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", dtype, max_batch=B)
+    T = 70
+    cs = [pkg.pipeline.synth_conditions(CFG, T, seed=50 + q, dynamic_we=dynamic) for q in range(B)]
+    cat = lambda k: torch.cat([c[k] for c in cs])  # noqa: E731
+    noise = pkg.fmt.draw_noise(2, B, CFG, seed=15)
+    a, r, e = (1.0, 1.0, 3.0) if dynamic else ((2.0, 1.5, 1.2) if rcfg else (2.0, 1.0, 1.0))
+    got = many.sample(cat("r_s"), cat("wa"), cat("we"), noise, 5, a, r, e, include_r_cfg=rcfg).cpu()
+    assert got.shape == (B, T, 512)
+    tol = 2e-2 if dtype == "bf16" else 4e-3
+    for q in range(B):
+        alone = one.sample(cs[q]["r_s"], cs[q]["wa"], cs[q]["we"], noise[:, q:q + 1], 5, a, r, e, include_r_cfg=rcfg).cpu()
+        assert rel_l2(got[q:q + 1], alone) < 0.25 * tol, (q, rel_l2(got[q:q + 1], alone))
+    q = B - 1
+    ref = O.sample_rd(sd, CFG, cs[q]["r_s"], cs[q]["wa"], cs[q]["we"], noise[:, q:q + 1], 5, a, r, e, include_r_cfg=rcfg)
+    assert rel_l2(got[q:q + 1], ref) < tol
+    with pytest.raises(ValueError, match="max_batch"):
+        pkg.native.check(pkg.native.lib().float_fmt_sample_batch(
+            one._h, 2, None, None, T, None, 1, None, 5, a, r, e, 0, None, None))
+
+
+def test_batched_sampling_runge_kutta():
+    sd = pkg.weights.synth_fmt_state(CFG, seed=42)
+    one = pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", "fp16")
+    many = pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", "fp16", max_batch=2)
+    one.set_method("heun3")
+    many.set_method("heun3")
+    cs = [pkg.pipeline.synth_conditions(CFG, 60, seed=60 + q) for q in range(2)]
+    noise = pkg.fmt.draw_noise(2, 2, CFG, seed=15)
+    got = many.sample(torch.cat([c["r_s"] for c in cs]), torch.cat([c["wa"] for c in cs]), torch.cat([c["we"] for c in cs]), noise, 3).cpu()
+    for q in range(2):
+        alone = one.sample(cs[q]["r_s"], cs[q]["wa"], cs[q]["we"], noise[:, q:q + 1], 3).cpu()
+        assert rel_l2(got[q:q + 1], alone) < 1e-3
