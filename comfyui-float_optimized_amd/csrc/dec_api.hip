@@ -57,6 +57,14 @@ struct float_dec {
   u16 *hiA = nullptr, *hiB = nullptr, *hiZ = nullptr;
   float *loFlow[2] = {nullptr, nullptr}, *loRgb[2] = {nullptr, nullptr};
   float *hiFlow[2] = {nullptr, nullptr}, *hiRgb[2] = {nullptr, nullptr};
+  // float_dec_frames_host, ride-along mode: the frames of the previous high batch still to be copied to the host by copy
+  // workgroups inside the next batch's launches (CopyTail, dec_kernels.hpp)
+  struct {
+    const float* src = nullptr;
+    float* dst = nullptr;
+    size_t left16 = 0;   // 16-byte units not yet handed to a launch
+    double wleft = 0.0;  // sum of the weights of the carrying launches still to come in this batch
+  } ride;
   std::vector<hipEvent_t> copy_events;  // float_dec_frames_host: one per high batch in flight, recycled across calls
   hipEvent_t join_event = nullptr;
 };
@@ -290,8 +298,51 @@ int create_impl(float_dec* h, const TensorTable& tt) {
   return FLOAT_OK;
 }
 
+// Copy workgroups per carrying launch (a multiple of 8), the lowest resolution whose launches carry a share, and the pause
+// between a wave's 1-KiB stores in units of 512 clocks.  Unpaced, the copy saturates PCIe (55 GB/s) and its posted writes
+// queue in front of the compute workgroups' memory traffic: the 512-px flow launch took 665 us instead of 508 with a 217 us
+// copy inside; at ~45 GB/s (16 workgroups, pace 4) it takes 548 (in-kernel stamps, -DDEC_STAMPS).
+static const unsigned kRideWgs = getenv("FLOAT_DEC_RIDE_WGS") ? (unsigned)atoi(getenv("FLOAT_DEC_RIDE_WGS")) / 8 * 8 : 16;
+static const int kRideMinRes = getenv("FLOAT_DEC_RIDE_MIN_RES") ? atoi(getenv("FLOAT_DEC_RIDE_MIN_RES")) : 64;
+static const unsigned kRidePace = getenv("FLOAT_DEC_RIDE_PACE") ? (unsigned)atoi(getenv("FLOAT_DEC_RIDE_PACE")) : 4;
+
+// Relative duration of a carrying launch (kind 0 = up-conv + blur, 1 = conv2, 2 = flow / warp / ToRGB) at resolution R: the
+// share of the pending copy it takes is proportional to it, so that every share ends inside its launch (measured per 32-frame
+// batch, us; other resolutions: equal shares).
+static double ride_weight(int R, int kind) {
+  static const bool equal = getenv("FLOAT_DEC_RIDE_EQUAL") != nullptr;
+  if (equal) return 1.0;
+  static const double w[4][3] = {{211, 210, 99}, {184, 224, 99}, {268, 295, 354}, {393, 328, 508}};
+  const int li = R == 64 ? 0 : R == 128 ? 1 : R == 256 ? 2 : R == 512 ? 3 : -1;
+  return li < 0 ? 250.0 : w[li][kind];
+}
+
+// The share of the pending device-to-host copy that the next carrying launch takes.
+static CopyTail take_ride(float_dec* h, int R, int kind) {
+  CopyTail ct{};
+  auto& r = h->ride;
+  if (!r.left16 || r.wleft <= 0.0 || !kRideWgs || R < kRideMinRes) return ct;
+  const double w = ride_weight(R, kind);
+  size_t n = (size_t)((double)r.left16 * std::min(1.0, w / r.wleft)) + 1;
+  n = std::min(n, r.left16);
+  r.wleft -= w;
+  if (r.wleft < 1e-9) n = r.left16;  // the batch's last carrier takes what is left
+  ct.src = reinterpret_cast<const u32x4*>(r.src);
+  ct.dst = reinterpret_cast<u32x4*>(r.dst);
+  ct.n16 = n;
+  ct.nwg = kRideWgs;
+  ct.pace = kRidePace;
+  static const int test = getenv("FLOAT_DEC_RIDE_TEST") ? atoi(getenv("FLOAT_DEC_RIDE_TEST")) : 0;  // probes, wrong results
+  if (test == 1) ct.dst = const_cast<u32x4*>(ct.src);  // device -> device instead of device -> host
+  if (test == 2) ct.n16 = 1;                            // copy workgroups with nothing to do
+  r.src += n * 4;
+  r.dst += n * 4;
+  r.left16 -= n;
+  return ct;
+}
+
 template <class T>
-int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, int ntaps, const int* dy, const int* dx,
+int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, int ntaps, const int* dy, const int* dx,
                 u16* Y, int Ho, int Wo, int OH, int OW, int sy, int sx, int py, int px, int F, const float* demod, int ldd,
                 const float* bias, int act, const float* snext, int lds, hipStream_t st) {
   ConvArgs g;
@@ -359,7 +410,8 @@ int launch_conv(const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, in
     static const int tpw_env = getenv("FLOAT_DEC_TPW") ? atoi(getenv("FLOAT_DEC_TPW")) : 0;  // tuning aid
     g.tpw = tpw_env ? tpw_env : (total >= 16384 ? 4 : (total >= 4096 ? 2 : 1));
     const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64;
-    dim3 grid((total + g.tpw - 1) / g.tpw, s.cout / bn);
+    if (h) g.ct = take_ride(h, Ho, 1);
+    dim3 grid((total + g.tpw - 1) / g.tpw + g.ct.nwg, s.cout / bn);
 #define CONV16(NTv, TYv, TXv)                                                                                    \
   if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv) {                                                       \
     if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
@@ -421,7 +473,8 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
     z.tiles_x = z.tiles_y = (R + 27) / 28;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = fh_prof_pair(1, &e0, &e1);
-    dim3 grid(z.tiles_x * z.tiles_y * n, up.cout / 32);
+    z.ct = take_ride(h, R, 0);
+    dim3 grid(z.tiles_x * z.tiles_y * n + z.ct.nwg, up.cout / 32);
     const size_t smem = 32 * 32 * 64;
     if (prof) hipExtLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, e0, e1, 0, z);
     else hipLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, z);
@@ -451,7 +504,7 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
     for (int pu = 0; pu < 2; ++pu)
       for (int pv = 0; pv < 2; ++pv) {
         const ClassTaps c = class_taps(pu, pv);
-        if ((rc = launch_conv<T>(x_in, Ri, Ri, up, up.W + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Zb, Ri + 1 - pu, Ri + 1 - pv,
+        if ((rc = launch_conv<T>(nullptr, x_in, Ri, Ri, up, up.W + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Zb, Ri + 1 - pu, Ri + 1 - pv,
                                  R + 1, R + 1, 2, 2, pu, pv, n, demod + up.demod_off, h->Dtot, nullptr, 0, nullptr, 0, st)))
           return rc;
         t0 += c.n;
@@ -465,7 +518,7 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   }
   }  // unfused path
   // conv2 (plain 3x3); its unscaled output feeds ToFlow
-  if ((rc = launch_conv<T>(U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
+  if ((rc = launch_conv<T>(h, U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
                            c2.abias, 1, nullptr, 0, st)))
     return rc;
   // ToFlow + warp + blend + ToRGB
@@ -506,9 +559,16 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   if (bx >= 8) bx &= ~7;  // bands in multiples of 8: band <-> XCD affinity (dec_flow_kernel)
   g.band_pix = ((R * R + bx - 1) / bx + step - 1) / step * step;
   g.nbands = bx = (R * R + g.band_pix - 1) / g.band_pix;
-  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n), dim3(256), 0, st, g);
-  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n), dim3(256), 0, st, g);
+  g.ct = take_ride(h, R, 2);
+#ifdef DEC_STAMPS
+  if (last) {
+    const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
+    FH_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dec_stamps), init, sizeof(init), 0, hipMemcpyHostToDevice, st));
+  }
+#endif
+  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
+  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -523,7 +583,7 @@ int run_low(float_dec* h, int n, const float* styles, const float* demod, int* s
   hipLaunchKernelGGL((dec_input_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, h->loB, h->cin_hwc, styles + c1.style_off,
                      h->Stot, n, 16, c1.cin);
   u16* first_out = h->lo_levels > 0 ? h->loA : h->loX;
-  if ((rc = launch_conv<T>(h->loB, 4, 4, c1, c1.W, 9, kDy9, kDx9, first_out, 4, 4, 4, 4, 1, 1, 0, 0, n, demod + c1.demod_off,
+  if ((rc = launch_conv<T>(nullptr, h->loB, 4, 4, c1, c1.W, 9, kDy9, kDx9, first_out, 4, 4, 4, 4, 1, 1, 0, 0, n, demod + c1.demod_off,
                            h->Dtot, c1.abias, 1, styles + h->convs[1].style_off, h->Stot, st)))
     return rc;
   int cur = 0;
@@ -577,6 +637,11 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
                 float* host = nullptr, hipStream_t cs = nullptr) {
   const int S = h->cfg.size, sdim = h->cfg.style_dim, FH = h->cfg.max_frames, FL = h->lo_frames;
   size_t n_copy = 0;
+  // same-stream hand-over: copy workgroups ride along the next batch's launches unless FLOAT_DEC_COPY=memcpy
+  static const bool ride_on = !(getenv("FLOAT_DEC_COPY") && !strcmp(getenv("FLOAT_DEC_COPY"), "memcpy"));
+  const bool ride = host && cs == st && ride_on && (((size_t)S * S * 3 * sizeof(float)) % 16 == 0);
+  h->ride.left16 = 0;
+  h->ride.wleft = 0.0;
   for (int s0 = 0; s0 < n_frames; s0 += kStyleCap) {
     const int ns = std::min(kStyleCap, n_frames - s0);
     // every style modulation (22 EqualLinears) and every demod factor for `ns` frames: 2 launches
@@ -613,10 +678,25 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
       for (int b0 = 0; b0 < na; b0 += FH) {
         const int nb = std::min(FH, na - b0);
         const size_t off = (size_t)(s0 + a0 + b0) * S * S * 3;
+        if (host && ride) {
+          // launches of this batch that carry a share: up-conv, conv2 and flow kernel of every level from kRideMinRes up
+          double wsum = 0.0;
+          for (int li = h->lo_levels; li < h->n_levels; ++li)
+            if (h->levels[li].R >= kRideMinRes)
+              for (int kind = 0; kind < 3; ++kind) wsum += ride_weight(h->levels[li].R, kind);
+          h->ride.wleft = h->ride.left16 ? wsum : 0.0;
+        }
         rc = run_high<T>(h, nb, b0, st_a + (size_t)b0 * h->Stot, dm_a + (size_t)b0 * h->Dtot, skip_idx, out + off, final_mode, st);
         if (rc) return rc;
-        if (host && cs == st) {  // in-order copy behind the batch's last kernel
-          FH_CHECK_HIP(hipMemcpyAsync(host + off, out + off, (size_t)nb * S * S * 3 * sizeof(float), hipMemcpyDeviceToHost, st));
+        const size_t bytes = (size_t)nb * S * S * 3 * sizeof(float);
+        if (host && ride) {
+          if (h->ride.left16)  // what no launch took (a decoder without carrying levels): plain copy, in order
+            FH_CHECK_HIP(hipMemcpyAsync(h->ride.dst, h->ride.src, h->ride.left16 * 16, hipMemcpyDeviceToHost, st));
+          h->ride.src = out + off;  // this batch crosses PCIe under the next one's kernels
+          h->ride.dst = host + off;
+          h->ride.left16 = bytes / 16;
+        } else if (host && cs == st) {  // in-order copy behind the batch's last kernel
+          FH_CHECK_HIP(hipMemcpyAsync(host + off, out + off, bytes, hipMemcpyDeviceToHost, st));
         } else if (host) {
           if (n_copy >= h->copy_events.size()) {
             hipEvent_t e;
@@ -626,10 +706,14 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
           hipEvent_t e = h->copy_events[n_copy++];
           FH_CHECK_HIP(hipEventRecord(e, st));
           FH_CHECK_HIP(hipStreamWaitEvent(cs, e, 0));
-          FH_CHECK_HIP(hipMemcpyAsync(host + off, out + off, (size_t)nb * S * S * 3 * sizeof(float), hipMemcpyDeviceToHost, cs));
+          FH_CHECK_HIP(hipMemcpyAsync(host + off, out + off, bytes, hipMemcpyDeviceToHost, cs));
         }
       }
     }
+  }
+  if (host && ride && h->ride.left16) {  // the last batch has no successor to ride along
+    FH_CHECK_HIP(hipMemcpyAsync(h->ride.dst, h->ride.src, h->ride.left16 * 16, hipMemcpyDeviceToHost, st));
+    h->ride.left16 = 0;
   }
   if (host && n_copy) {  // join: work queued on `st` after this call sees the frames in host memory
     if (!h->join_event) FH_CHECK_HIP(hipEventCreateWithFlags(&h->join_event, hipEventDisableTiming));
@@ -745,6 +829,14 @@ int float_dec_frames_host(float_dec_t* h, const float* s_r, const float* r_d, in
   hipStream_t st = (hipStream_t)stream, cs = copy_stream ? (hipStream_t)copy_stream : st;
   return frames_impl<FP16>(h, s_r, r_d, n_frames, out_hwc, 1, st, host_hwc, cs);
 }
+
+#ifdef DEC_STAMPS
+int float_dec_debug_stamps(unsigned long long* out4) {
+  FH_CHECK_HIP(hipDeviceSynchronize());
+  FH_CHECK_HIP(hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_dec_stamps), 4 * sizeof(unsigned long long)));
+  return FLOAT_OK;
+}
+#endif
 
 int float_dec_feat_shape(float_dec_t* h, int32_t i, int32_t* channels, int32_t* resolution) {
   FH_REQUIRE(h && channels && resolution, "null argument to float_dec_feat_shape");

@@ -107,6 +107,65 @@ __global__ void dec_input_kernel(u16* __restrict__ out, const float* __restrict_
 // Implicit-GEMM convolution over a tap list.  M = output pixels (256 per workgroup: nf frames x
 // th x tw), N = BN output channels, K = taps x Cin in chunks of 32 input channels.  The input halo
 // tile and the weight slab of the chunk are staged in LDS once and re-used by every tap.
+// Device-to-host copy that rides along a compute launch (float_dec_frames_host): the first `nwg` workgroups of
+// the grid (x < nwg, y == 0; dispatched first) move n16 16-byte units from device memory to pinned host memory while the
+// rest of the grid computes, so the frames of batch i cross PCIe under the kernels of batch i+1 WITHOUT a second stream (a
+// copy issued on another stream left the FMT chain that followed 12 ms slower per clip).  nwg is a multiple of 8, so the
+// XCD classes (id mod 8) of the compute workgroups are unchanged.
+struct CopyTail {
+  const u32x4* src;
+  u32x4* dst;
+  unsigned long long n16;
+  unsigned nwg;
+  unsigned pace;  // 0: as fast as the stores are accepted
+};
+
+__device__ __forceinline__ void dec_copy_tail(const CopyTail& ct, unsigned wg) {
+  const unsigned long long stride = (unsigned long long)ct.nwg * 256;
+  unsigned long long i = (unsigned long long)wg * 256 + threadIdx.x;
+  if (ct.pace) {
+    // paced: one 1-KiB store per wave, then a pause of pace x 512 clocks, so that the copy stays below the PCIe rate and
+    // its posted writes do not pile up in front of the compute workgroups' memory traffic
+    for (; i < ct.n16; i += stride) {
+      ct.dst[i] = __builtin_nontemporal_load(ct.src + i);
+      for (unsigned k = 0; k < ct.pace; ++k) __builtin_amdgcn_s_sleep(8);
+    }
+    return;
+  }
+  for (; i + 3 * stride < ct.n16; i += 4 * stride) {  // 4 loads in flight per lane
+    const u32x4 a = __builtin_nontemporal_load(ct.src + i), b = __builtin_nontemporal_load(ct.src + i + stride);
+    const u32x4 c = __builtin_nontemporal_load(ct.src + i + 2 * stride), d = __builtin_nontemporal_load(ct.src + i + 3 * stride);
+    ct.dst[i] = a;
+    ct.dst[i + stride] = b;
+    ct.dst[i + 2 * stride] = c;
+    ct.dst[i + 3 * stride] = d;
+  }
+  for (; i < ct.n16; i += stride) ct.dst[i] = __builtin_nontemporal_load(ct.src + i);
+}
+#ifdef DEC_STAMPS
+// diagnostic build only (make CXXFLAGS+=-DDEC_STAMPS): wall-clock (100 MHz) of the copy workgroups and of the compute
+// workgroups of the LAST carrying launch: [copy first start, copy last end, compute first start, compute last end]
+__device__ unsigned long long g_dec_stamps[4];
+#define DEC_STAMP_MIN(i) if (threadIdx.x == 0) atomicMin(&g_dec_stamps[i], __builtin_amdgcn_s_memrealtime())
+#define DEC_STAMP_MAX(i) if (threadIdx.x == 0) atomicMax(&g_dec_stamps[i], __builtin_amdgcn_s_memrealtime())
+#else
+#define DEC_STAMP_MIN(i)
+#define DEC_STAMP_MAX(i)
+#endif
+// at the top of a kernel that may carry a copy: the copy workgroups do their share and leave; BID = the compute block id
+#define DEC_COPY_PROLOGUE(g, BID)                                   \
+  if (blockIdx.x < (g).ct.nwg) {                                    \
+    if (blockIdx.y == 0) {                                          \
+      DEC_STAMP_MIN(0);                                             \
+      dec_copy_tail((g).ct, blockIdx.x);                            \
+      __syncthreads();                                              \
+      DEC_STAMP_MAX(1);                                             \
+    }                                                               \
+    return;                                                         \
+  }                                                                 \
+  DEC_STAMP_MIN(2);                                                 \
+  const unsigned BID = blockIdx.x - (g).ct.nwg;
+
 struct ConvArgs {
   const u16* X;   // [F][Hi][Wi][Cin], already multiplied by the layer's style
   const u16* Wt;  // [ntaps][Cout][Cin]
@@ -124,6 +183,7 @@ struct ConvArgs {
   int act;                          // 1: + bias, leaky_relu(0.2) * sqrt(2)
   int tpw;                          // dec_conv16_kernel: consecutive tiles per workgroup
   signed char dy[9], dx[9];
+  CopyTail ct;                      // dec_conv16_kernel / dec_zblur_kernel: copy that rides along (nwg == 0: none)
 };
 
 template <class T, int NT>
@@ -271,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
 //     loads of item i+1 are issued into registers before the MFMAs of item i (single LDS buffer).
 template <class T, int NT, int TY, int TX>
 __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
+  DEC_COPY_PROLOGUE(g, bid)
   constexpr int BN = NT * 16, HH = 15 + TY, HW = 15 + TX, NPIX = HH * HW, NTAPS = TY * TX;
   constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -303,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
   const int tiles_pf = g.tiles_x * g.tiles_y;
   const int total = tiles_pf * g.F;
   const int nchunks = g.Cin >> 5;
-  const int tile0 = blockIdx.x * g.tpw;
+  const int tile0 = bid * g.tpw;
   const int ntile = min(g.tpw, total - tile0);
   const int nitems = ntile * nchunks;
   const int n0 = blockIdx.y * BN;
@@ -585,6 +646,7 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
 // 1.31x the MFMA work of the unfused kernel buys 59 -> 25 MB of traffic per frame at 512x512.
 template <class T>
 __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
+  DEC_COPY_PROLOGUE(g, bid)
   constexpr int NT = 2, BN = 32, HW = 17, NPIX = HW * HW, NTAPS = 9;
   constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -607,7 +669,7 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
   }
   const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);
   const int tiles_pf = g.tiles_x * g.tiles_y;
-  const int tile = blockIdx.x;
+  const int tile = bid;
   const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
   const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
   const int n0 = blockIdx.y * BN;
@@ -892,6 +954,7 @@ struct FlowArgs {
   int write_pyr;       // store flow_out / rgb_out (0 on the last level: nobody reads them)
   int F, R, C, ld_s;
   int nbands, band_pix;  // the image is cut into nbands runs of band_pix consecutive pixels (multiple of gpb*PIX)
+  CopyTail ct;           // copy that rides along (nwg == 0: none)
 };
 
 __device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, int Rp, int Y, int X, float out[3]) {
@@ -934,6 +997,7 @@ __device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x});
 // 56 registers per lane and ran at ONE wave per SIMD (r01 PMC: waves parked 56 % of their life).
 template <class T, int PIX>
 __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
+  DEC_COPY_PROLOGUE(g, bid)
   __shared__ __attribute__((aligned(16))) float sw[7 * 512];  // [wf0 wf1 wf2 | wr0 wr1 wr2 | sn][C]
   const int C = g.C;
   const int lpp = C >> 3;            // lanes per pixel (4..64)
@@ -944,7 +1008,7 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   // frame and sent the bilinear gathers to the Infinity Cache.
   int f, band;
   {
-    const int id = blockIdx.x, nb = g.nbands;
+    const int id = bid, nb = g.nbands;
     if ((nb & 7) == 0) {
       const int slot = id >> 3;
       f = slot % g.F;
@@ -1114,6 +1178,7 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
       }
     }
   }
+  DEC_STAMP_MAX(3);
 }
 
 // Encoder skip feature NCHW fp32 -> NHWC 16-bit (once per clip).

@@ -26,7 +26,7 @@ dev = "cuda:0"
 g = torch.Generator().manual_seed(0)
 if args.what == "dec":
     sd = pkg.weights.synth_decoder_state(512, seed=1)
-    dec = pkg.decoder.SynthesisHIP(sd, 512, 512, dev, "fp16", max_frames=16)
+    dec = pkg.decoder.SynthesisHIP(sd, 512, 512, dev, "fp16", max_frames=max(16, min(args.frames, 32)))
     dec.set_feats(pkg.weights.synth_feats(512, seed=1))
     s_r, r_d = torch.randn(1, 512, generator=g), torch.randn(1, args.frames, 512, generator=g) * 0.5
     for _ in range(args.reps):
