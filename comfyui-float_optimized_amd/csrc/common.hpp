@@ -38,6 +38,28 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
+// Every operand type T gives: elem (storage element), pack8 (8 consecutive elements = one lane's share of an MFMA fragment
+// and the unit of the packed epilogue stores), load8 / load8_nt / store8 / store4, get / set of one element as float, mfma.
+#define FH_PACK16_HELPERS                                                                                                   \
+  typedef u16 elem;                                                                                                         \
+  typedef u32x4 pack8;                                                                                                      \
+  static constexpr bool is32 = false;                                                                                       \
+  static __device__ __forceinline__ pack8 load8(const elem* p) { return *reinterpret_cast<const u32x4*>(p); }               \
+  static __device__ __forceinline__ pack8 load8_nt(const elem* p) {                                                         \
+    return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));                                                   \
+  }                                                                                                                         \
+  static __device__ __forceinline__ void store8(elem* p, const pack8& v) { *reinterpret_cast<u32x4*>(p) = v; }              \
+  static __device__ __forceinline__ float get(const pack8& v, int j) { return to_float(reinterpret_cast<const u16*>(&v)[j]); } \
+  static __device__ __forceinline__ void set(pack8& v, int j, float x) { reinterpret_cast<u16*>(&v)[j] = from_float(x); }   \
+  static __device__ __forceinline__ void store4(elem* p, float a, float b, float c, float d) {                              \
+    ushort4 o;                                                                                                              \
+    o.x = from_float(a);                                                                                                    \
+    o.y = from_float(b);                                                                                                    \
+    o.z = from_float(c);                                                                                                    \
+    o.w = from_float(d);                                                                                                    \
+    *reinterpret_cast<ushort4*>(p) = o;                                                                                     \
+  }
+
 struct BF16 {
   typedef bf16x8_t vec8;
   static __device__ __forceinline__ u16 from_float(float x) {
@@ -50,6 +72,7 @@ struct BF16 {
   static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
   }
+  FH_PACK16_HELPERS
   static u16 host_from_float(float x) {
     uint32_t u;
     memcpy(&u, &x, 4);
@@ -71,6 +94,7 @@ struct FP16 {
   static __device__ __forceinline__ f32x4 mfma(const u32x4& a, const u32x4& b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(vec8, a), __builtin_bit_cast(vec8, b), c, 0, 0, 0);
   }
+  FH_PACK16_HELPERS
   static u16 host_from_float(float x) {
     // round-to-nearest-even fp32 -> fp16 on the host (weight packing)
     uint32_t u;
@@ -97,6 +121,46 @@ struct FP16 {
     uint32_t half = 1u << (shift - 1);
     if (rem > half || (rem == half && (r & 1u))) r++;
     return (u16)(sign | (base + r));
+  }
+};
+
+// fp32 operands (FLOAT_DT_FP32): the verification mode of the FMT operator.  Same chain, same packed operand order with
+// 4-byte elements; a lane's 8 consecutive k of a fragment feed 8 v_mfma_f32_16x16x4_f32 (lane group g supplies k = 8g + j in
+// step j, the instruction sums its 4 groups: any assignment of k to groups works as long as A and B agree).  Exact fp32
+// products and sums (an fmaf chain), 1/16 of the 16-bit MFMA rate - irrelevant for a mode that exists to hold the HIP logic
+// to the reference at 1e-4.
+struct F32x8 {
+  f32x4 lo, hi;
+};
+struct FP32 {
+  typedef float elem;
+  typedef F32x8 pack8;
+  static constexpr bool is32 = true;
+  static __device__ __forceinline__ float from_float(float x) { return x; }
+  static __device__ __forceinline__ float to_float(float v) { return v; }
+  static float host_from_float(float x) { return x; }
+  static __device__ __forceinline__ pack8 load8(const elem* p) {
+    return pack8{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
+  }
+  static __device__ __forceinline__ pack8 load8_nt(const elem* p) { return load8(p); }
+  static __device__ __forceinline__ void store8(elem* p, const pack8& v) {
+    *reinterpret_cast<f32x4*>(p) = v.lo;
+    *reinterpret_cast<f32x4*>(p + 4) = v.hi;
+  }
+  static __device__ __forceinline__ float get(const pack8& v, int j) { return j < 4 ? v.lo[j] : v.hi[j - 4]; }
+  static __device__ __forceinline__ void set(pack8& v, int j, float x) {
+    if (j < 4) v.lo[j] = x;
+    else v.hi[j - 4] = x;
+  }
+  static __device__ __forceinline__ void store4(elem* p, float a, float b, float c, float d) {
+    *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
+  }
+  static __device__ __forceinline__ f32x4 mfma(const pack8& a, const pack8& b, f32x4 c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], c, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.hi[j], b.hi[j], c, 0, 0, 0);
+    return c;
   }
 };
 

@@ -71,9 +71,11 @@ template <class T>
 int pack_linear_pool(DevicePool* pool, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
                      Lin* out) {
   // Concatenate the named Linear layers along N (used to fuse every adaLN projection into one GEMM).
+  typedef typename T::elem E;
+  constexpr size_t esz = sizeof(E) / sizeof(u16);  // u16 slots per element (Lin::W is typed u16* for every operand type)
   const int Kp = round_up(K, 128);
   const int N = N_each * (int)names.size();
-  std::vector<u16> hw((size_t)N * Kp, 0);
+  std::vector<E> hw((size_t)N * Kp, (E)0);
   std::vector<float> hb(N, 0.f);
   int n0 = 0;
   for (const std::string& nm : names) {
@@ -96,9 +98,9 @@ int pack_linear_pool(DevicePool* pool, const TensorTable& tt, const std::vector<
     n0 += N_each;
   }
   int rc;
-  if ((rc = pool->alloc(&out->W, hw.size(), false))) return rc;
+  if ((rc = pool->alloc(&out->W, hw.size() * esz, false))) return rc;
   if ((rc = pool->alloc(&out->b, hb.size(), false))) return rc;
-  FH_CHECK_HIP(hipMemcpy(out->W, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
+  FH_CHECK_HIP(hipMemcpy(out->W, hw.data(), hw.size() * sizeof(E), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMemcpy(out->b, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
   out->N = N;
   out->K = Kp;
@@ -200,9 +202,17 @@ int launch_gemm(const GemmArgs& g, int mtw, int nt, int nw, bool prime, hipStrea
   }
 #define FMT_CASE(MTW, NT, NW, E) \
   if (mtw == MTW && nt == NT && nw == NW) return launch_gemm_t<T, MTW, NT, NW, E>(g, prime, s);
-  FMT_FOR_SPLIT(FMT_CASE, EPI)
-  if constexpr (EPI == EPI_F32 || EPI == EPI_CFG) {
-    FMT_FOR_FULL(FMT_CASE, EPI)
+  if constexpr (T::is32) {
+    // the fp32 verification mode runs a handful of 16-column tilings (pick_tiling): speed is not its point
+    FMT_CASE(1, 1, 4, EPI) FMT_CASE(2, 1, 4, EPI) FMT_CASE(3, 1, 4, EPI) FMT_CASE(4, 1, 4, EPI) FMT_CASE(5, 1, 4, EPI)
+    if constexpr (EPI == EPI_CFG) {
+      FMT_CASE(1, 1, 8, EPI) FMT_CASE(3, 1, 8, EPI) FMT_CASE(4, 1, 8, EPI)
+    }
+  } else {
+    FMT_FOR_SPLIT(FMT_CASE, EPI)
+    if constexpr (EPI == EPI_F32 || EPI == EPI_CFG) {
+      FMT_FOR_FULL(FMT_CASE, EPI)
+    }
   }
 #undef FMT_CASE
   fh_set_error("no GEMM tiling (%d x %d tiles, %d waves) for epilogue %d", mtw, nt, nw, EPI);
@@ -213,6 +223,12 @@ template <class T, int EPI>
 void prime_epi() {
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  if constexpr (T::is32) {
+    for (int mtw = 1; mtw <= 5; ++mtw) (void)launch_gemm<T, EPI>(g, mtw, 1, 4, true, nullptr);
+    if (EPI == EPI_CFG)
+      for (int mtw : {1, 3, 4}) (void)launch_gemm<T, EPI>(g, mtw, 1, 8, true, nullptr);
+    return;
+  }
   static const int shapes[][2] = {{3, 1}, {3, 2}, {3, 4}, {5, 1}, {5, 2}, {5, 4}, {4, 1}, {4, 2}, {6, 2}, {2, 1}, {1, 1}};
   for (auto& c : shapes)
     for (int nw : {4, 8, 16}) (void)launch_gemm<T, EPI>(g, c[0], c[1], nw, true, nullptr);
@@ -236,9 +252,11 @@ void prime_kernels() {
   prime_epi<T, EPI_CFG>();
   prime_epi<T, EPI_PARTIAL>();
   prime_epi<T, EPI_GELUERF_P16>();
-  GemmArgs g;
-  memset(&g, 0, sizeof(g));
-  (void)launch_wide<T>(g, true, nullptr);
+  if constexpr (!T::is32) {
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    (void)launch_wide<T>(g, true, nullptr);
+  }
 }
 
 // Tiling choice: split the rows over row blocks so that narrow layers still fill the 256 CUs, and
@@ -306,8 +324,21 @@ GemmArgs base_args(const u16* A, const Lin& L, int M) {
   return g;
 }
 
+// fp32 verification mode: 16 columns per workgroup, 4 K-splitting waves, the row split of the 16-bit tilings capped at 5 tiles
+Tiling pick_tiling32(int M) {
+  const int mt = (M + 15) / 16;
+  return {mt <= 5 ? mt : (mt <= 12 ? 3 : 5), 1, 4};
+}
+
 template <class T, int EPI>
 int run_gemm(const GemmArgs& g, hipStream_t s, bool need_full_rows = false) {
+  if constexpr (T::is32) {
+    FH_REQUIRE(!need_full_rows, "the fp32 mode has no all-rows CFG epilogue tiling (token-blocked head only)");
+    const Tiling t = pick_tiling32(g.M);
+    GemmArgs g2 = g;
+    g2.touch.W = nullptr;
+    return launch_gemm<T, EPI>(g2, t.mtw, t.nt, t.nw, false, s);
+  }
   const Tiling t = pick_tiling(g.M, g.N, g.K, need_full_rows);
   return launch_gemm<T, EPI>(g, t.mtw, t.nt, t.nw, false, s);
 }
@@ -328,8 +359,9 @@ int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
   g.out_f32 = h->slab;
   g.ldo = g.N;
   g.slab_stride = (size_t)h->Mpad * g.N;
-  Tiling t = pick_tiling(g.M, g.N * ksplit, g.K / ksplit, false);
+  Tiling t = T::is32 ? pick_tiling32(g.M) : pick_tiling(g.M, g.N * ksplit, g.K / ksplit, false);
   while (t.nt > 1 && g.N % (t.nt * 16)) t.nt >>= 1;
+  if (T::is32) g.touch.W = nullptr;
   return launch_gemm<T, EPI_PARTIAL>(g, t.mtw, t.nt, t.nw, false, s);
 }
 
@@ -387,7 +419,7 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   LnRed red{};
   if (ks) red = pend->red;
   TouchSpec pf{};
-  if (next && (g_fmt_touch & (1 | touch_bit)) && rpw == 1) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
+  if (next && (g_fmt_touch & (1 | touch_bit)) && rpw == 1 && !T::is32) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
 #define LN_LAUNCH(NV, KS)                                                                                                          \
   do {                                                                                                                             \
     if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
@@ -430,7 +462,7 @@ void launch_attn(float_fmt* h, int M, const Lin* pull, hipStream_t s) {
   (void)parsed;
   dim3 grid(c.heads, (M + qpw - 1) / qpw), block(qpw * lpq);
   TouchSpec pf{};
-  if (pull) pf = make_touch(*pull, M, 0, (grid.x * grid.y / 8) * block.x, 2);
+  if (pull && !T::is32) pf = make_touch(*pull, M, 0, (grid.x * grid.y / 8) * block.x, 2);
 #define ATTN_LAUNCH(LPQ, TCH) \
   hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf)
   if (lpq == 16) {
@@ -469,10 +501,12 @@ int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
   g.zgroup = g_fmt_zgroup;
   g.a_zstride = (size_t)h->Mpad * D;
   g.o_zstride = (size_t)h->Mmod * h->Ntot;
-  if (g_fmt_wide && g.N % 128 == 0 && g.K % 128 == 0) return launch_wide<T>(g, false, s);
+  if constexpr (!T::is32) {
+    if (g_fmt_wide && g.N % 128 == 0 && g.K % 128 == 0) return launch_wide<T>(g, false, s);
+  }
   for (int z = 0; z < n; ++z) {  // shapes the wide kernel does not tile: the generic GEMM, one batch at a time
     GemmArgs gz = g;
-    gz.A = g.A + (size_t)z * g.a_zstride;
+    gz.A = g.A + (size_t)z * g.a_zstride * (sizeof(typename T::elem) / sizeof(u16));
     gz.out_f32 = g.out_f32 + (size_t)z * g.o_zstride;
     gz.zcount = 0;
     int rc = run_gemm<T, EPI_F32>(gz, s);
@@ -616,11 +650,11 @@ int prepare_time(float_fmt* h, const TimeSpec& ts, int n, hipStream_t s) {
   GemmArgs g = base_args(h->tsin16, h->t0, n);
   g.out16 = h->th16;
   g.ldo16 = h->t2.K / 32;
-  if ((rc = launch_gemm<T, EPI_SILU_P16>(g, 4, 1, pick_nw(g.K, 0), false, s))) return rc;
+  if ((rc = launch_gemm<T, EPI_SILU_P16>(g, 4, 1, T::is32 ? 4 : pick_nw(g.K, 0), false, s))) return rc;
   GemmArgs g2 = base_args(h->th16, h->t2, n);
   g2.out_f32 = h->temb;
   g2.ldo = h->D;
-  if ((rc = launch_gemm<T, EPI_F32>(g2, 4, 1, pick_nw(g2.K, 0), false, s))) return rc;
+  if ((rc = launch_gemm<T, EPI_F32>(g2, 4, 1, T::is32 ? 4 : pick_nw(g2.K, 0), false, s))) return rc;
   return FLOAT_OK;
 }
 
@@ -897,10 +931,11 @@ int create_impl(float_fmt* h, const TensorTable& tt) {
     Lin fused;
     fused.N = h->adaln_all.N + tail.N;
     fused.K = h->adaln_all.K;
-    if ((rc = h->pool.alloc(&fused.W, (size_t)fused.N * fused.K, false))) return rc;
+    constexpr size_t esz = sizeof(typename T::elem) / sizeof(u16);
+    if ((rc = h->pool.alloc(&fused.W, (size_t)fused.N * fused.K * esz, false))) return rc;
     if ((rc = h->pool.alloc(&fused.b, (size_t)fused.N, false))) return rc;
-    FH_CHECK_HIP(hipMemcpy(fused.W, h->adaln_all.W, (size_t)h->adaln_all.N * fused.K * sizeof(u16), hipMemcpyDeviceToDevice));
-    FH_CHECK_HIP(hipMemcpy(fused.W + (size_t)h->adaln_all.N * fused.K, tail.W, (size_t)tail.N * fused.K * sizeof(u16),
+    FH_CHECK_HIP(hipMemcpy(fused.W, h->adaln_all.W, (size_t)h->adaln_all.N * fused.K * esz * sizeof(u16), hipMemcpyDeviceToDevice));
+    FH_CHECK_HIP(hipMemcpy(fused.W + (size_t)h->adaln_all.N * fused.K * esz, tail.W, (size_t)tail.N * fused.K * esz * sizeof(u16),
                            hipMemcpyDeviceToDevice));
     FH_CHECK_HIP(hipMemcpy(fused.b, h->adaln_all.b, (size_t)h->adaln_all.N * sizeof(float), hipMemcpyDeviceToDevice));
     FH_CHECK_HIP(hipMemcpy(fused.b + h->adaln_all.N, tail.b, (size_t)tail.N * sizeof(float), hipMemcpyDeviceToDevice));
@@ -916,6 +951,7 @@ int create_impl(float_fmt* h, const TensorTable& tt) {
 // ---------------------------------------------------------------- GEMM service (fmt_gemm.hpp)
 int fmt_pack_linear(DevicePool* pool, int dtype, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
                     FmtLin* out) {
+  FH_REQUIRE(dtype == FLOAT_DT_BF16 || dtype == FLOAT_DT_FP16, "the GEMM service runs 16-bit operands (dtype %d)", dtype);
   return dtype == FLOAT_DT_BF16 ? pack_linear_pool<BF16>(pool, tt, names, N_each, K, out)
                                 : pack_linear_pool<FP16>(pool, tt, names, N_each, K, out);
 }
@@ -990,7 +1026,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   FH_REQUIRE(cfg->dim_w % 128 == 0 && cfg->mlp_hidden % 128 == 0, "dim_w / mlp_hidden must be multiples of 128");
   FH_REQUIRE(cfg->n_prev + cfg->n_cur <= kMaxTok, "at most %d tokens per window (got %d)", kMaxTok, cfg->n_prev + cfg->n_cur);
   FH_REQUIRE(cfg->n_prev >= 0 && cfg->n_prev <= cfg->n_cur, "n_prev must be in [0, n_cur]");
-  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
+  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16 || cfg->dtype == FLOAT_DT_FP32, "unknown dtype %d", cfg->dtype);
   FH_REQUIRE(cfg->max_batch >= 0 && cfg->max_batch <= 16, "max_batch must be in [0, 16] (got %d)", cfg->max_batch);
   float_fmt* h = new float_fmt();
   h->cfg = *cfg;
@@ -1015,10 +1051,13 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
            &g_fmt_plan_override[3], &g_fmt_plan_override[4], &g_fmt_plan_override[5]);
   h->Ntot = cfg->depth * 6 * h->D + 2 * h->D;
   TensorTable tt(tensors, n_tensors);
-  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);
+  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt)
+           : (cfg->dtype == FLOAT_DT_FP16) ? create_impl<FP16>(h, tt) : create_impl<FP32>(h, tt);
   const int D = h->D, Mp = h->Mpad;
+  const size_t esz = cfg->dtype == FLOAT_DT_FP32 ? 2 : 1;  // u16 slots per operand element
   auto A = [&](auto** p, size_t n) {
-    if (!rc) rc = h->pool.alloc(p, n, true);
+    // operand buffers (typed u16*) hold 4-byte elements in the fp32 mode
+    if (!rc) rc = h->pool.alloc(p, std::is_same<std::remove_reference_t<decltype(**p)>, u16>::value ? n * esz : n, true);
   };
   A(&h->pos, (size_t)kMaxTok * D);
   A(&h->freqs, 128);
@@ -1096,7 +1135,9 @@ int float_fmt_eval(float_fmt_t* h, float t, const float* x, const float* wa, con
   hipStream_t s = (hipStream_t)stream;
   return h->cfg.dtype == FLOAT_DT_BF16
              ? eval_impl<BF16>(h, t, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, a_cfg, r_cfg, e_cfg, include_r_cfg, out, s)
-             : eval_impl<FP16>(h, t, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, a_cfg, r_cfg, e_cfg, include_r_cfg, out, s);
+         : h->cfg.dtype == FLOAT_DT_FP16
+             ? eval_impl<FP16>(h, t, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, a_cfg, r_cfg, e_cfg, include_r_cfg, out, s)
+             : eval_impl<FP32>(h, t, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, a_cfg, r_cfg, e_cfg, include_r_cfg, out, s);
 }
 
 int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, const float* wr, const float* we,
@@ -1123,13 +1164,16 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
   const float* pwe_p = we_len > 1 ? h->prev_we : nullptr;
   const TimeSpec tsp = time_spec(h->method, nfe);
   const int nev = std::max(1, n_evals(h->method, nfe));
-  if (c.dtype == FLOAT_DT_BF16) {
-    if ((rc = prepare_time<BF16>(h, tsp, nev, s))) return rc;
-    rc = window_impl<BF16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
-  } else {
-    if ((rc = prepare_time<FP16>(h, tsp, nev, s))) return rc;
-    rc = window_impl<FP16>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg, include_r_cfg, s);
-  }
+#define FMT_CHUNK(TT)                                                                                                          \
+  do {                                                                                                                           \
+    if ((rc = prepare_time<TT>(h, tsp, nev, s))) return rc;                                                                      \
+    rc = window_impl<TT>(h, h->x0_c, h->wa_c, wr, we_p, we_len, h->prev_x, h->prev_wa, pwe_p, nfe, ts, a_cfg, r_cfg, e_cfg,      \
+                         include_r_cfg, s);                                                                                      \
+  } while (0)
+  if (c.dtype == FLOAT_DT_BF16) FMT_CHUNK(BF16);
+  else if (c.dtype == FLOAT_DT_FP16) FMT_CHUNK(FP16);
+  else FMT_CHUNK(FP32);
+#undef FMT_CHUNK
   if (rc) return rc;
   FH_CHECK_HIP(hipMemcpyAsync(out, h->xcur, (size_t)c.n_cur * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
   return FLOAT_OK;
@@ -1137,8 +1181,9 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
 
 int float_fmt_debug(float_fmt_t* h, int32_t what, const float* in, float* out, void* stream) {
   FH_REQUIRE(h != nullptr && out != nullptr, "null argument to float_fmt_debug");
-  return h->cfg.dtype == FLOAT_DT_BF16 ? debug_impl<BF16>(h, what, in, out, (hipStream_t)stream)
-                                       : debug_impl<FP16>(h, what, in, out, (hipStream_t)stream);
+  return h->cfg.dtype == FLOAT_DT_BF16   ? debug_impl<BF16>(h, what, in, out, (hipStream_t)stream)
+         : h->cfg.dtype == FLOAT_DT_FP16 ? debug_impl<FP16>(h, what, in, out, (hipStream_t)stream)
+                                         : debug_impl<FP32>(h, what, in, out, (hipStream_t)stream);
 }
 
 int float_fmt_set_method(float_fmt_t* h, int32_t method) {
@@ -1184,7 +1229,9 @@ int float_fmt_sample_next(float_fmt_t* h, void* stream, int32_t* window_done, in
   auto& J = h->job;
   hipStream_t s = (hipStream_t)stream;
   const int k = J.next;
-  int rc = h->cfg.dtype == FLOAT_DT_BF16 ? sample_window<BF16>(h, k, s) : sample_window<FP16>(h, k, s);
+  int rc = h->cfg.dtype == FLOAT_DT_BF16   ? sample_window<BF16>(h, k, s)
+           : h->cfg.dtype == FLOAT_DT_FP16 ? sample_window<FP16>(h, k, s)
+                                           : sample_window<FP32>(h, k, s);
   if (rc) {
     J.active = false;
     return rc;

@@ -23,7 +23,9 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   // k-steps of operands in flight per wave.  With 4 k-blocks per wave (K = 1024 over 8 waves) PF = 4 puts the whole
   // K slice in flight at once: one memory round trip instead of two for the 48x64 tilings (7 fragments per k-step,
   // 112 operand registers + 48 accumulators still fit two waves per SIMD)
-  constexpr int PF = (MTW + NT <= 7) ? 4 : ((MTW + NT <= 8) ? 3 : 2);
+  constexpr int PF = T::is32 ? 1 : ((MTW + NT <= 7) ? 4 : ((MTW + NT <= 8) ? 3 : 2));
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [NW][ROWS][BN]
   const int lane = threadIdx.x & 63;
   const int w = threadIdx.x >> 6;
@@ -69,8 +71,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   const int KB = g.K >> 5;
   const int KBs = (EPI == EPI_PARTIAL) ? KB / g.ksplit : KB;  // k-blocks of this workgroup's K slice
   const int KBw = KBs / NW;                                   // k-blocks per wave
-  const u16* Ap = g.A + ((size_t)mt0 * KB + ks * KBs + w * KBw) * 512 + lane * 8;
-  const u16* Wp = g.W + ((size_t)nb0 * KB + ks * KBs + w * KBw) * 512 + lane * 8;
+  const E* Ap = reinterpret_cast<const E*>(g.A) + ((size_t)mt0 * KB + ks * KBs + w * KBw) * 512 + lane * 8;
+  const E* Wp = reinterpret_cast<const E*>(g.W) + ((size_t)nb0 * KB + ks * KBs + w * KBw) * 512 + lane * 8;
   const size_t tstride = (size_t)KB * 512;
   // EPI_GATE_RES with one epilogue item per thread: fetch residual and gate now, not after the K loop
   constexpr bool kEarlyRes = (EPI == EPI_GATE_RES) && (MTW * 16 * (NT * 2) <= NW * 64);
@@ -88,14 +90,14 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
     }
   }
 
-  u32x4 a[PF][MTW], b[PF][NT];
+  P8 a[PF][MTW], b[PF][NT];
 #pragma unroll
   for (int p = 0; p < PF; ++p) {
     if (p < KBw) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + j * tstride + (size_t)p * 512));
+      for (int j = 0; j < NT; ++j) b[p][j] = T::load8_nt(Wp + j * tstride + (size_t)p * 512);
 #pragma unroll
-      for (int i = 0; i < MTW; ++i) a[p][i] = *reinterpret_cast<const u32x4*>(Ap + i * tstride + (size_t)p * 512);
+      for (int i = 0; i < MTW; ++i) a[p][i] = T::load8(Ap + i * tstride + (size_t)p * 512);
     }
   }
   // only the epilogue kinds whose launches are given a TouchSpec carry the code (2 registers, a branch)
@@ -116,9 +118,9 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         if (kb + PF < KBw) {
 #pragma unroll
           for (int j = 0; j < NT; ++j)
-            b[p][j] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(Wp + j * tstride + (size_t)(kb + PF) * 512));
+            b[p][j] = T::load8_nt(Wp + j * tstride + (size_t)(kb + PF) * 512);
 #pragma unroll
-          for (int i = 0; i < MTW; ++i) a[p][i] = *reinterpret_cast<const u32x4*>(Ap + i * tstride + (size_t)(kb + PF) * 512);
+          for (int i = 0; i < MTW; ++i) a[p][i] = T::load8(Ap + i * tstride + (size_t)(kb + PF) * 512);
         }
       }
     }
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         const size_t xo = (size_t)(i - g.n_prev) * g.N + n;
         const float xn = xcur_q[xo] + g.dt * out;  // x_{k+1} = x_k + dt * v  (fixed-grid Euler)
         xcur_q[xo] = xn;
-        g.xin16[fmt_pack_off(q * g.ntok + i, n, g.ldx)] = T::from_float(xn);
+        reinterpret_cast<E*>(g.xin16)[fmt_pack_off(q * g.ntok + i, n, g.ldx)] = T::from_float(xn);
       }
     }
   } else {
@@ -215,18 +217,18 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
         *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
       } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16 || EPI == EPI_GELUERF_P16) {
-        uint4 u;
-        u16* e = reinterpret_cast<u16*>(&u);
+        P8 u;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           float x = v[i];
           if constexpr (EPI == EPI_SILU_P16) x = fh_silu(x);
           if constexpr (EPI == EPI_GELU_P16) x = fh_gelu_tanh(x);
           if constexpr (EPI == EPI_GELUERF_P16) x = fh_gelu_erf(x);
-          e[i] = T::from_float(x);
+          T::set(u, i, x);
         }
-        if constexpr (EPI == EPI_T16) *reinterpret_cast<uint4*>(g.out16 + (size_t)row * g.ldo16 + nb) = u;
-        else *reinterpret_cast<uint4*>(g.out16 + fmt_pack_off(row, nb, g.ldo16)) = u;
+        E* const o16 = reinterpret_cast<E*>(g.out16);
+        if constexpr (EPI == EPI_T16) T::store8(o16 + (size_t)row * g.ldo16 + nb, u);
+        else T::store8(o16 + fmt_pack_off(row, nb, g.ldo16), u);
       } else if constexpr (EPI == EPI_GATE_RES) {
         float* o = g.out_f32 + (size_t)row * g.ldo + nb;
         const float* gt = g.gate + (size_t)row * g.ldg + nb;
@@ -499,12 +501,9 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
-    ushort4 o;
-    o.x = T::from_float((v[i].x - mu) * rstd * (1.f + b[i].x) + a[i].x);
-    o.y = T::from_float((v[i].y - mu) * rstd * (1.f + b[i].y) + a[i].y);
-    o.z = T::from_float((v[i].z - mu) * rstd * (1.f + b[i].z) + a[i].z);
-    o.w = T::from_float((v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w);
-    *reinterpret_cast<ushort4*>(out + fmt_pack_off(orow, c, D / 32)) = o;
+    T::store4(reinterpret_cast<typename T::elem*>(out) + fmt_pack_off(orow, c, D / 32),
+              (v[i].x - mu) * rstd * (1.f + b[i].x) + a[i].x, (v[i].y - mu) * rstd * (1.f + b[i].y) + a[i].y,
+              (v[i].z - mu) * rstd * (1.f + b[i].z) + a[i].z, (v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w);
   }
   if (touch) fmt_touch_retire(touched);
 }
@@ -541,25 +540,25 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
   const int b = row_ / ntok, qi = row_ - b * ntok;
   const int d0 = h * HD + part * PD;
   const float scale = rsqrtf((float)HD);
-  const u16* base = qkv + (size_t)(b * ntok) * ld + d0;
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  const E* base = reinterpret_cast<const E*>(qkv) + (size_t)(b * ntok) * ld + d0;
   float qf[PD], o[PD];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const uint4 uu = *reinterpret_cast<const uint4*>(base + (size_t)qi * ld + u * 8);
-    const u16* e = reinterpret_cast<const u16*>(&uu);
+    const P8 uu = T::load8(base + (size_t)qi * ld + u * 8);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf[u * 8 + j] = T::to_float(e[j]) * scale;
+    for (int j = 0; j < 8; ++j) qf[u * 8 + j] = T::get(uu, j) * scale;
   }
 #pragma unroll
   for (int i = 0; i < PD; ++i) o[i] = 0.f;
   float m = -INFINITY, l = 0.f;
-  auto fold = [&](const uint4* k, const uint4* v, bool valid) {
+  auto fold = [&](const P8* k, const P8* v, bool valid) {
     float dot = 0.f;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const u16* ke = reinterpret_cast<const u16*>(&k[u]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dot += qf[u * 8 + j] * T::to_float(ke[j]);
+      for (int j = 0; j < 8; ++j) dot += qf[u * 8 + j] * T::get(k[u], j);
     }
 #pragma unroll
     for (int d = 1; d < LPQ; d <<= 1) dot += __shfl_xor(dot, d, 64);
@@ -570,21 +569,20 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
     m = mn;
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      const u16* ve = reinterpret_cast<const u16*>(&v[u]);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[u * 8 + j] = o[u * 8 + j] * alpha + p * T::to_float(ve[j]);
+      for (int j = 0; j < 8; ++j) o[u * 8 + j] = o[u * 8 + j] * alpha + p * T::get(v[u], j);
     }
   };
   if (window <= 2) {
-    uint4 kk[5][NU], vv[5][NU];
+    P8 kk[5][NU], vv[5][NU];
 #pragma unroll
     for (int t = 0; t < 5; ++t) {
       const int kj = min(max(qi + t - 2, 0), ntok - 1);
-      const u16* kp = base + (size_t)kj * ld + D;
+      const E* kp = base + (size_t)kj * ld + D;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        kk[t][u] = *reinterpret_cast<const uint4*>(kp + u * 8);
-        vv[t][u] = *reinterpret_cast<const uint4*>(kp + D + u * 8);
+        kk[t][u] = T::load8(kp + u * 8);
+        vv[t][u] = T::load8(kp + D + u * 8);
       }
     }
     touch();
@@ -598,12 +596,12 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
     touch();
     for (int kj = qi - window; kj <= qi + window; ++kj) {
       const int kc = min(max(kj, 0), ntok - 1);
-      const u16* kp = base + (size_t)kc * ld + D;
-      uint4 k[NU], v[NU];
+      const E* kp = base + (size_t)kc * ld + D;
+      P8 k[NU], v[NU];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        k[u] = *reinterpret_cast<const uint4*>(kp + u * 8);
-        v[u] = *reinterpret_cast<const uint4*>(kp + D + u * 8);
+        k[u] = T::load8(kp + u * 8);
+        v[u] = T::load8(kp + D + u * 8);
       }
       fold(k, v, kj >= 0 && kj < ntok);
     }
@@ -612,11 +610,10 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
   const int row = b * ntok + qi;
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    uint4 uo;
-    u16* e = reinterpret_cast<u16*>(&uo);
+    P8 uo;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) e[j] = T::from_float(o[u * 8 + j] * inv);
-    *reinterpret_cast<uint4*>(out + fmt_pack_off(row, d0 + u * 8, D / 32)) = uo;
+    for (int j = 0; j < 8; ++j) T::set(uo, j, o[u * 8 + j] * inv);
+    T::store8(reinterpret_cast<E*>(out) + fmt_pack_off(row, d0 + u * 8, D / 32), uo);
   }
   if constexpr (TOUCH) fmt_touch_retire(touched);
 }
@@ -656,7 +653,7 @@ __global__ void fmt_build_cond_kernel(u16* __restrict__ out, int ld, int bc, int
         else v = (i < n_prev) ? prev_we[i * dim_e + k] : we[(i - n_prev) * dim_e + k];
       }
     }
-    out[fmt_pack_off(row, c, ld / 32)] = T::from_float(v);
+    reinterpret_cast<typename T::elem*>(out)[fmt_pack_off(row, c, ld / 32)] = T::from_float(v);
   }
 }
 
@@ -688,7 +685,7 @@ __global__ void fmt_tsin_kernel(u16* __restrict__ out, const float* __restrict__
   (void)c0;
   const int k = threadIdx.x;  // 0..255
   const float arg = t * freqs[k & 127];
-  out[fmt_pack_off(s, k, 8)] = T::from_float(k < 128 ? cosf(arg) : sinf(arg));
+  reinterpret_cast<typename T::elem*>(out)[fmt_pack_off(s, k, 8)] = T::from_float(k < 128 ? cosf(arg) : sinf(arg));
 }
 
 // sc16[row] = T(silu(t_emb + c_cond[row]))   (c = t + c_embedder(.), FMT.py:335; SiLU of FMT.py:164,187)
@@ -700,20 +697,19 @@ __global__ void fmt_silu_c_kernel(u16* __restrict__ out, const float* __restrict
   const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (idx >= M * D) return;
   const int row = idx / D, c = idx % D;
-  out += (size_t)blockIdx.y * step_stride;
+  typename T::elem* const o = reinterpret_cast<typename T::elem*>(out) + (size_t)blockIdx.y * step_stride;
   temb += (size_t)blockIdx.y * D;
-  uint4 u;
-  u16* e = reinterpret_cast<u16*>(&u);
+  typename T::pack8 u;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const float4 a = *reinterpret_cast<const float4*>(ccond + idx + 4 * h);
     const float4 t = *reinterpret_cast<const float4*>(temb + c + 4 * h);
-    e[4 * h + 0] = T::from_float(fh_silu(a.x + t.x));
-    e[4 * h + 1] = T::from_float(fh_silu(a.y + t.y));
-    e[4 * h + 2] = T::from_float(fh_silu(a.z + t.z));
-    e[4 * h + 3] = T::from_float(fh_silu(a.w + t.w));
+    T::set(u, 4 * h + 0, fh_silu(a.x + t.x));
+    T::set(u, 4 * h + 1, fh_silu(a.y + t.y));
+    T::set(u, 4 * h + 2, fh_silu(a.z + t.z));
+    T::set(u, 4 * h + 3, fh_silu(a.w + t.w));
   }
-  *reinterpret_cast<uint4*>(out + fmt_pack_off(row, c, D / 32)) = u;
+  T::store8(o + fmt_pack_off(row, c, D / 32), u);
 }
 
 // Euler state and x_embedder input rows for a new window, per clip q: xcur[q] = x0[q]; xin16 rows q * ntok + i = [prev_x[q] ; x0[q]].
@@ -732,7 +728,7 @@ __global__ void fmt_init_x_kernel(float* __restrict__ xcur, u16* __restrict__ xi
     v = x0[((size_t)q * n_cur + (i - n_prev)) * dim_w + c];
     xcur[((size_t)q * n_cur + (i - n_prev)) * dim_w + c] = v;
   }
-  xin16[fmt_pack_off(q * ntok + i, c, ldx)] = T::from_float(v);
+  reinterpret_cast<typename T::elem*>(xin16)[fmt_pack_off(q * ntok + i, c, ldx)] = T::from_float(v);
 }
 
 // Explicit Runge-Kutta glue for the non-Euler fixed-grid solvers: y = xcur + sum_m coef[m] * k_m over the
@@ -751,7 +747,7 @@ __global__ void fmt_rk_combine_kernel(float* __restrict__ xcur, const float* __r
   float y = xcur[idx];
   for (int m = 0; m < nk; ++m) y += cf[m] * kbuf[(size_t)m * kstride + ((size_t)q * ntok + n_prev + i) * W + c];
   if (final) xcur[idx] = y;
-  xin16[fmt_pack_off(q * ntok + n_prev + i, c, ldx)] = T::from_float(y);
+  reinterpret_cast<typename T::elem*>(xin16)[fmt_pack_off(q * ntok + n_prev + i, c, ldx)] = T::from_float(y);
 }
 
 // Window slice with replicate padding along time (FLOAT.py:224-227), per clip: dst[q][i] = src[q][min(t0+i, T-1)].
@@ -777,12 +773,12 @@ __global__ void fmt_tail_kernel(float* __restrict__ dst, const float* __restrict
 template <class T>
 __global__ void fmt_dbg_to16_kernel(u16* __restrict__ dst, const float* __restrict__ src, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) dst[i] = T::from_float(src[i]);
+  if (i < n) reinterpret_cast<typename T::elem*>(dst)[i] = T::from_float(src[i]);
 }
 template <class T>
 __global__ void fmt_dbg_unpack_kernel(float* __restrict__ dst, const u16* __restrict__ src, int rows, int D) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= rows * D) return;
   const int r = i / D, c = i - r * D;
-  dst[i] = T::to_float(src[fmt_pack_off(r, c, D / 32)]);
+  dst[i] = T::to_float(reinterpret_cast<const typename T::elem*>(src)[fmt_pack_off(r, c, D / 32)]);
 }

@@ -8,9 +8,10 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfloat_hip.so")
 
-FLOAT_DT_BF16, FLOAT_DT_FP16 = 0, 1
+FLOAT_DT_BF16, FLOAT_DT_FP16, FLOAT_DT_FP32 = 0, 1, 2
 ODE_METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "heun2": 3, "heun3": 4}
-DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16}
+DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16,
+          "fp32": FLOAT_DT_FP32, "float32": FLOAT_DT_FP32}  # fp32: the FMT operator's verification mode only
 
 
 class NativeLibraryError(RuntimeError):

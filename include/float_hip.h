@@ -41,7 +41,10 @@ enum {
   FLOAT_E_NOMEM = 4
 };
 
-enum { FLOAT_DT_BF16 = 0, FLOAT_DT_FP16 = 1 }; /* 16-bit MFMA operand type; accumulation is fp32 */
+/* MFMA operand type; accumulation, statistics, softmax, residual stream and ODE state are fp32 in every mode.
+ * FLOAT_DT_FP32 (FMT only): the verification mode - fp32 operands on v_mfma_f32_16x16x4_f32, the same launch chain, held to
+ * the reference goldens at 1e-4 (tests/test_fmt_fp32_gpu.py); 1/16 of the 16-bit MFMA rate, no tuned tilings. */
+enum { FLOAT_DT_BF16 = 0, FLOAT_DT_FP16 = 1, FLOAT_DT_FP32 = 2 };
 
 /* One checkpoint tensor, named with the reference's state-dict key (prefix stripped):
  * e.g. "blocks.0.attn.qkv.weight" (FMT) or "convs.3.conv.weight" (decoder).  `data` is a HOST

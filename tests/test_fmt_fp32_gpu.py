@@ -1,0 +1,85 @@
+"""The HIP chain's LOGIC held to the reference at 1e-4 (SURVEY 8d's fp32 tolerance): the FMT operator in its fp32
+verification mode (FLOAT_DT_FP32: the same launch chain - cond build, hoisted adaLN projection, LayerNorm + modulate, banded
+attention, split-K fc2 folded into the next LayerNorm, token-blocked CFG head, Euler / Runge-Kutta updates, AR hand-off - with
+fp32 operands on v_mfma_f32_16x16x4_f32) against the goldens the REFERENCE produced.  With 16-bit operands the same tests can
+only be held to 5e-4 (fp16) / 4e-3 (bf16), where a wrong mask row, modulation chunk, hand-off frame or grid value could hide;
+two 16-bit computations of a net this deep also diverge from each other by about half their rounding error (an operand-rounded
+oracle was tried as the comparison and sits at 2e-4..4e-4 from the kernels), so reference precision is the way to 1e-4."""
+import pytest
+import torch
+
+from oracle import float_oracle as O
+from tests.util import golden, load_pkg, rel_l2, sample_inputs
+
+pkg = load_pkg()
+W, C = pkg.weights, pkg.config
+pytestmark = pytest.mark.gpu
+TOL = 2e-5  # SURVEY 8d asks for 1e-4; measured <= 2.6e-6 on every case below
+
+
+def _fmt(cfg, seed, **kw):
+    sd = W.synth_fmt_state(cfg, seed)
+    return sd, pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", "fp32", **kw)
+
+
+@pytest.mark.parametrize("tag", ["small", "full"])
+def test_eval_goldens_fp32(tag):
+    g = golden("fmt_eval_" + tag)
+    cfg = C.small_fmt_config() if tag == "small" else C.FmtConfig()
+    sd, fmt = _fmt(cfg, g["seed"])
+    for case in ("nocfg", "cfg3", "cfg4", "cfg3dyn"):
+        a, r, e, rc = [float(v) for v in g[case + "_scales"]]
+        out = fmt.forward_with_cfv(g["t"], g[case + "_x"], g[case + "_wa"], g[case + "_wr"], g[case + "_we"], g[case + "_prev_x"],
+                                   g[case + "_prev_wa"], g.get(case + "_prev_we"), a_cfg_scale=a, r_cfg_scale=r, e_cfg_scale=e,
+                                   include_r_cfg=bool(rc)).cpu()
+        err = rel_l2(out, g[case + "_out"])
+        print(tag, case, "fp32 rel-L2 %.2e" % err)
+        assert err < TOL, (case, err)
+
+
+@pytest.mark.parametrize("tag", ["small_static", "small_dynamic", "full_static"])
+def test_sample_goldens_fp32(tag):
+    g = golden("fmt_sample_" + tag)
+    cfg = C.FmtConfig() if tag.startswith("full") else C.small_fmt_config()
+    for use_graph in (0, 2):
+        sd, fmt = _fmt(cfg, g["seed"], use_graph=use_graph)
+        r_d = fmt.sample(g["r_s"], g["wa"], g["we"], g["noise"], g["nfe"], g["a"], 1.0, g["e"]).cpu()
+        err = rel_l2(r_d, g["r_d"])
+        print(tag, "graph" if use_graph else "eager", "fp32 rel-L2 %.2e" % err)
+        assert err < TOL
+
+
+@pytest.mark.parametrize("tag", ["config2", "config5"])
+def test_full_length_configs_fp32(tag):
+    """BASELINE configs[1] / configs[4] at full length (250 / 750 evaluations of the AR chain) at reference precision."""
+    g = golden("fmt_sample_" + tag)
+    cfg = C.FmtConfig()
+    inp = sample_inputs(cfg, g["seed"], g["T"], bool(g["dynamic"]), g["noise_seed"])
+    sd, fmt = _fmt(cfg, g["seed"])
+    r_d = fmt.sample(inp["r_s"], inp["wa"], inp["we"], inp["noise"], g["nfe"], g["a"], 1.0, g["e"]).cpu()
+    per_window = [rel_l2(r_d[:, k:k + 50], g["r_d"][:, k:k + 50]) for k in range(0, g["T"], 50)]
+    print(tag, "fp32 per-window rel-L2:", " ".join("%.1e" % v for v in per_window))
+    assert max(per_window) < TOL
+
+
+def test_batched_and_runge_kutta_fp32():
+    """The stacked-clip chain (float_fmt_sample_batch) and a Runge-Kutta solver against the oracle at 1e-4: 70 frames = two
+    windows with replicate pad, 4-way CFG for one clip set."""
+    cfg = C.FmtConfig()
+    sd, fmt = _fmt(cfg, 91, max_batch=2)
+    cs = [pkg.pipeline.synth_conditions(cfg, 70, seed=80 + q) for q in range(2)]
+    noise = pkg.fmt.draw_noise(2, 2, cfg, seed=15)
+    cat = lambda k: torch.cat([c[k] for c in cs])  # noqa: E731
+    got = fmt.sample(cat("r_s"), cat("wa"), cat("we"), noise, 4, 2.0, 1.5, 1.2, include_r_cfg=True).cpu()
+    for q in range(2):
+        ref = O.sample_rd(sd, cfg, cs[q]["r_s"], cs[q]["wa"], cs[q]["we"], noise[:, q:q + 1], 4, 2.0, 1.5, 1.2, include_r_cfg=True)
+        assert rel_l2(got[q:q + 1], ref) < TOL
+    fmt.set_method("rk4")
+    got = fmt.sample(cs[0]["r_s"], cs[0]["wa"], cs[0]["we"], noise[:, :1], 3).cpu()
+    ref = O.sample_rd(sd, cfg, cs[0]["r_s"], cs[0]["wa"], cs[0]["we"], noise[:, :1], 3, 2.0, 1.0, 1.0, method="rk4")
+    assert rel_l2(got, ref) < TOL
+
+
+def test_other_operators_refuse_fp32():
+    with pytest.raises(ValueError):
+        pkg.decoder.SynthesisHIP(W.synth_decoder_state(64, seed=1), 64, 512, "cuda:0", dtype="fp32")

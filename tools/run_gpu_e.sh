@@ -1,5 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/r2_e; mkdir -p $O
-MODE=inorder python tools/probes/e2e_phases.py 2>&1 | grep -v amdgpu.ids | head -3
-python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json | cut -c1-1400
-python -m pytest tests/test_dec_gpu.py tests/test_pipeline_gpu.py tests/test_nodes_gpu.py tests/test_nodes_va_gpu.py tests/test_variants_gpu.py -m gpu -x -q 2>&1 | tail -3
+python -m pytest tests/test_fmt_fp32_gpu.py -m gpu -x -q -s 2>&1 | grep -v "^$" | tail -30
+python -m pytest tests/test_fmt_gpu.py tests/test_fmt_tables.py tests/test_aud_gpu.py -m gpu -x -q 2>&1 | tail -3
