@@ -15,7 +15,7 @@ def _hot_path(size=64, max_frames=8, graph=True):
     cfg = pkg.config.FmtConfig()
     fmt_sd = pkg.weights.synth_fmt_state(cfg, seed=21)
     dec_sd = pkg.weights.synth_decoder_state(size, seed=21)
-    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, "cuda:0", size, "bf16", "fp16", max_frames, use_graph=graph)
+    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, "cuda:0", size, "fp16", "fp16", max_frames, use_graph=graph)
     feats = pkg.weights.synth_feats(size, seed=21)
     return cfg, fmt_sd, dec_sd, hp, feats
 
@@ -48,7 +48,7 @@ def test_end_to_end_vs_oracle_short_clip():
     mse = float(((frames.cpu() - ref) ** 2).mean())
     print("e2e: r_d rel-L2 %.3e, frames mean|d| %.3e, PSNR %.1f dB" % (
         e_rd, float((frames.cpu() - ref).abs().mean()), -10 * torch.log10(torch.tensor(mse))))
-    assert e_rd < 2e-2 and mse < 1e-4  # PSNR >= 40 dB
+    assert e_rd < 4e-3 and mse < 1e-4  # fp16 operands (the default): r_d <= 4e-3, PSNR >= 40 dB
 
 
 @pytest.mark.parametrize("fmt_dtype,min_psnr", [("bf16", 30.0), ("fp16", 45.0)])
@@ -56,7 +56,10 @@ def test_config1_golden_end_to_end(fmt_dtype, min_psnr):
     """BASELINE configs[0] through the HIP path against what the reference itself produced on CPU.
     The decoder amplifies latent error (a 0.3 % perturbation of r_d moves the flow-warped sampling
     positions: with these synthetic weights it costs ~25 dB), so the end-to-end frame tolerance is set by
-    the FMT operand type: bf16 operands >= 30 dB, fp16 operands >= 45 dB; r_d itself <= 2e-2 / 4e-3 rel."""
+    the FMT operand type: fp16 operands - the default of bench.py, the nodes and every mirror - >= 45 dB (measured 48.6),
+    above the 40 dB of SURVEY 8d; bf16 operands (BASELINE.json's wording for configs[1], kept as an option at the same speed)
+    reach 34.2 dB and are held to >= 30 dB: 8 mantissa bits put r_d at 2.9e-3, which the warp turns into ~15 dB.
+    r_d itself <= 4e-3 / 2e-2 rel."""
     from tests.util import golden
     g = golden("e2e_config1")
     cfg = pkg.config.FmtConfig()
