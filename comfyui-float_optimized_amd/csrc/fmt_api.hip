@@ -372,7 +372,9 @@ int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
 // 2 attention -> proj, 4 fc1 -> fc2, 8 qkv -> proj, 16 proj -> fc1, 32 fc2 -> the next block's qkv / the head.
 // Default 2 + 4 + 32 + 128 (r01, ms per 250 evaluations, same box: none 90.8, 2+4 87.6, 4+32 86.0-86.7, 2+4+32 83.2-83.5 after the
 // head change, + LN1 -> qkv 82.5; touching fc1's weights - from LayerNorm, proj or qkv - never paid).
-int g_fmt_touch = 166;
+// Round 2, with the adaLN weights out of the step (105 MB less cycling through the Infinity Cache per evaluation): LN2 -> fc1
+// now pays too: 230 = 166 + 64 gives 83.6 vs 84.9 ms (proj -> fc1 instead: 85.8; attention or qkv as extra pullers: 85.2-86.0).
+int g_fmt_touch = 230;
 TouchSpec make_touch(const Lin& L, int M, int ksplit, unsigned lanes, unsigned per_lane, int force_nt = 0) {
   TouchSpec t{};
   Tiling tl = ksplit ? pick_tiling(M, L.N * ksplit, L.K / ksplit, false) : pick_tiling(M, L.N, L.K, false);

@@ -16,7 +16,7 @@ def test_library_exports_header_symbols():
     L = pkg.native.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.float_hip_abi_version() == 1
+    assert L.float_hip_abi_version() == 2  # v2: float_fmt_cfg_t.max_batch, FLOAT_DT_FP32, batch / host hand-over / reserve / debug entries
 
 
 def test_product_does_not_import_oracle():
