@@ -54,3 +54,41 @@ def test_full_length_frames_vs_reference(tag):
     mean_err = float((frames.mean(dim=(1, 2, 3)) - f["mean"]).abs().max())
     print("%s frames %s: PSNR %s dB, band mean|d| %.2e, frame-mean err %.2e" % (tag, pick, " ".join("%.1f" % p for p in psnr), band, mean_err))
     assert min(psnr) >= 40.0 and band <= 2.0 / 255 and mean_err < 2e-3
+
+
+def test_sixty_second_clip_full_size():
+    """BASELINE configs[2] at its size on one GPU: 60 s = 1500 frames = 30 AR windows x 50 Euler evaluations, 512x512.
+    The AR chain is causal and the input generators are sequential, so the first 250 frames of this clip ARE config2's:
+    they must equal the HIP 250-frame run bit for bit and the reference's r_d (fmt_sample_config2.npz) within tolerance,
+    frames 0 / 124 / 249 must match the reference's frames, and a frame shard of the long clip must equal the same frames
+    of the whole (what `bench.py --mode shard` relies on across GPUs)."""
+    g = golden("fmt_sample_config2")
+    short = sample_inputs(CFG, g["seed"], 250, False, g["noise_seed"])
+    long = sample_inputs(CFG, g["seed"], 1500, False, g["noise_seed"])
+    assert torch.equal(long["wa"][:, :250], short["wa"]) and torch.equal(long["noise"][:5], short["noise"])
+    sd = pkg.weights.synth_fmt_state(CFG, g["seed"])
+    fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", "fp16")
+    r_long = fmt.sample(long["r_s"], long["wa"], long["we"], long["noise"], g["nfe"], g["a"], 1.0, g["e"])
+    r_short = fmt.sample(short["r_s"], short["wa"], short["we"], short["noise"], g["nfe"], g["a"], 1.0, g["e"])
+    assert r_long.shape == (1, 1500, CFG.dim_w) and torch.isfinite(r_long).all()
+    assert torch.equal(r_long[:, :250], r_short)
+    assert rel_l2(r_long[:, :250].cpu(), g["r_d"]) < LIMIT["fp16"]
+    # windows 6..30 have no reference run (75 s of CPU each 10 s); their statistics must look like the first five's
+    rms = r_long.reshape(30, 50, -1).pow(2).mean(dim=(1, 2)).sqrt()
+    assert float(rms.max() / rms.min()) < 1.5, rms
+    f = golden("frames_config2")
+    pick = [int(i) for i in f["pick"]]
+    from tests.util import seeded_normal
+    dec = pkg.decoder.SynthesisHIP(pkg.weights.synth_decoder_state(512, seed=f["seed"]), 512, 512, "cuda:0", "fp16", max_frames=32)
+    dec.set_feats(pkg.weights.synth_feats(512, seed=f["seed"]))
+    s_r = seeded_normal(f["seed"] + 4, 1, 512)
+    frames = dec.decode_latent_into_processed_images(s_r, r_long[:, :250])
+    d = frames[pick].cpu()[:, ::7, ::5] - f["lattice"]
+    psnr = [float(-10 * torch.log10((d[i] ** 2).mean())) for i in range(len(pick))]
+    assert min(psnr) >= 40.0, psnr
+    t0, t1 = pkg.distributed.frame_shard(1500, 8, 7)  # the last of 8 ranks
+    shard = dec.decode_latent_into_processed_images(s_r, r_long[:, t0:t1])
+    whole_tail = dec.decode_latent_into_processed_images(s_r, r_long[:, 1250:1500])
+    assert (t0, t1) == (1313, 1500) and torch.equal(shard, whole_tail[t0 - 1250:])
+    print("60 s clip: prefix == 10 s clip bitwise; frames %s PSNR %s dB; window rms %.3f..%.3f" % (
+        pick, " ".join("%.1f" % p for p in psnr), float(rms.min()), float(rms.max())))
