@@ -220,6 +220,11 @@ int create_impl(float_aud* h, const TensorTable& tt) {
   return FLOAT_OK;
 }
 
+// One row of attention scores per wave lives in LDS: 4 waves x (64 + Tn) floats <= 160 KiB (gfx950) -> 10 000 frames per call
+// = 400 s of audio conditioning at 25 fps, 200 s for the 50 Hz speech-emotion model (round 1 stopped at the 64 KiB default:
+// 3900 frames).
+constexpr int kAudMaxFrames = 10000;
+
 // float_aud_reserve: the only place the operator allocates after create.  Run-time calls check the capacity and refuse.
 int ensure_workspace(float_aud* h, int n_samples, int Tn, hipStream_t st) {
   if ((size_t)n_samples <= h->cap_samples && Tn <= h->cap_T) return FLOAT_OK;
@@ -294,7 +299,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   const int Lfeat = feature_len(c, n_samples);
   FH_REQUIRE(Lfeat >= 1, "audio too short for the feature extractor (%d samples)", n_samples);
   if (Tn <= 0) Tn = Lfeat;
-  FH_REQUIRE(Tn <= 3900, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit 3900 frames per call)", Tn);
+  FH_REQUIRE(Tn <= kAudMaxFrames, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit %d frames per call)", Tn, kAudMaxFrames);
   FH_REQUIRE((size_t)n_samples <= h->cap_samples && Tn <= h->cap_T,
              "clip of %d samples / %d frames exceeds the reserved workspace (%zu samples / %d frames): call float_aud_reserve "
              "first (run-time calls do not allocate)", n_samples, Tn, h->cap_samples, h->cap_T);
@@ -395,6 +400,14 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     }
     {
       const size_t smem = (size_t)4 * (64 + Tn) * sizeof(float);
+      if (smem > 48 * 1024) {  // beyond the default dynamic-LDS limit: once per process and operand type
+        static bool raised = false;
+        if (!raised) {
+          FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aud_attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024));
+          raised = true;
+        }
+      }
       hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), smem, st, h->qkv16, Tn, D, c.heads, h->att16);
     }
     {
@@ -508,7 +521,7 @@ int float_aud_reserve(float_aud_t* h, int32_t n_samples, int32_t seq_len, void* 
   FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
   const int Lfeat = feature_len(h->cfg, n_samples);
   const int Tn = seq_len > 0 ? seq_len : Lfeat;
-  FH_REQUIRE(Tn >= 1 && Tn <= 3900, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit 3900 frames per call)", Tn);
+  FH_REQUIRE(Tn >= 1 && Tn <= kAudMaxFrames, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit %d frames per call)", Tn, kAudMaxFrames);
   return ensure_workspace(h, n_samples, Tn, (hipStream_t)stream);
 }
 

@@ -122,3 +122,23 @@ def test_run_time_calls_do_not_allocate():
     assert torch.equal(wa, out)
     longer = enc.inference(W.synth_waveform(2.0, seed=2).cuda(), 50)  # the mirror grows the reservation itself
     assert longer.shape == (1, 50, cfg.dim_w) and torch.isfinite(longer).all()
+
+
+def test_long_audio_beyond_the_round1_frame_limit():
+    """More than 3900 transformer frames per call (round 1's limit: one score row per wave in 64 KiB of LDS; now 160 KiB,
+    10 000 frames): 84 s through the 50 Hz speech-emotion model (4199 frames) and 170 s of audio conditioning at 25 fps
+    (4250 frames), small configs, against the oracle; one frame more than the limit is refused with a ValueError."""
+    cfg = C.small_emotion_config()
+    sd = W.synth_audio_state(cfg, seed=43)
+    ser = pkg.audio.Audio2EmotionHIP(sd, cfg, "cuda:0", "fp16")
+    a = W.synth_waveform(84.0, seed=5)
+    got, ref = ser.predict_emotion(a).cpu(), O.audio2emotion_predict(sd, cfg, a)
+    assert float((got - ref).abs().max()) < 2e-3
+    acfg = C.small_audio_config()
+    asd = W.synth_audio_state(acfg, seed=44)
+    enc = pkg.audio.AudioEncoderHIP(asd, acfg, "cuda:0", "fp16")
+    a = W.synth_waveform(170.0, seed=6)
+    wa = enc.inference(a, 4250).cpu()
+    assert rel_l2(wa, O.audio_encoder_inference(asd, acfg, a, 4250)) < 3e-3
+    with pytest.raises(ValueError, match="10000"):
+        enc.inference(W.synth_waveform(8.0, seed=7), 10001)
