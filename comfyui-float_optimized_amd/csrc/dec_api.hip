@@ -314,6 +314,7 @@ static double ride_weight(int R, int kind) {
   if (equal) return 1.0;
   static const double w[4][3] = {{211, 210, 99}, {184, 224, 99}, {268, 295, 354}, {393, 328, 508}};
   const int li = R == 64 ? 0 : R == 128 ? 1 : R == 256 ? 2 : R == 512 ? 3 : -1;
+  if (kind == 3) return li < 0 ? 400.0 : 0.8 * (w[li][1] + w[li][2]);  // conv2 + flow in one launch
   return li < 0 ? 250.0 : w[li][kind];
 }
 
@@ -344,7 +345,7 @@ static CopyTail take_ride(float_dec* h, int R, int kind) {
 template <class T>
 int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, int ntaps, const int* dy, const int* dx,
                 u16* Y, int Ho, int Wo, int OH, int OW, int sy, int sx, int py, int px, int F, const float* demod, int ldd,
-                const float* bias, int act, const float* snext, int lds, hipStream_t st) {
+                const float* bias, int act, const float* snext, int lds, hipStream_t st, const FlowArgs* fuse = nullptr) {
   ConvArgs g;
   memset(&g, 0, sizeof(g));
   g.X = X;
@@ -399,7 +400,10 @@ int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, con
   static const int bn_hi = getenv("FLOAT_DEC_CONV_BN") ? atoi(getenv("FLOAT_DEC_CONV_BN")) : 32;
   static const int bn_lo = getenv("FLOAT_DEC_CONV_BN_LO") ? atoi(getenv("FLOAT_DEC_CONV_BN_LO")) : 32;
   const bool tile16 = tdim == 16;
-  const int bn = (s.cout >= 64 && (tile16 ? bn_hi : bn_lo) == 64) ? 64 : 32;
+  // fused conv2 + flow (dec_flow_from_regs): one workgroup must hold every output channel of its pixels
+  const int bn = fuse ? s.cout : ((s.cout >= 64 && (tile16 ? bn_hi : bn_lo) == 64) ? 64 : 32);
+  FH_REQUIRE(!fuse || (tile16 && (s.cout == 32 || s.cout == 64) && ntaps == 9 && Ho % 16 == 0 && Wo % 16 == 0 && sy == 1 && sx == 1),
+             "conv2 + flow fusion needs a 3x3 conv of 32 or 64 output channels on whole 16x16 tiles");
   FH_REQUIRE(s.cout % bn == 0 && s.cin % 32 == 0, "conv channels (%d -> %d) not tileable", s.cin, s.cout);
   const int ty_taps = dymax - dymin + 1, tx_taps = dxmax - dxmin + 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -409,13 +413,29 @@ int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, con
     const int total = g.tiles_x * g.tiles_y * F;
     static const int tpw_env = getenv("FLOAT_DEC_TPW") ? atoi(getenv("FLOAT_DEC_TPW")) : 0;  // tuning aid
     g.tpw = tpw_env ? tpw_env : (total >= 16384 ? 4 : (total >= 4096 ? 2 : 1));
-    const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64;
-    if (h) g.ct = take_ride(h, Ho, 1);
+    const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64 + (fuse ? (size_t)256 * bn * 2 + (size_t)7 * bn * 4 : 0);
+    if (h) g.ct = take_ride(h, Ho, fuse ? 3 : 1);
     dim3 grid((total + g.tpw - 1) / g.tpw + g.ct.nwg, s.cout / bn);
+    FlowArgs fg;
+    memset(&fg, 0, sizeof(fg));
+    if (fuse) {
+      fg = *fuse;
+#define CONV16F(NTv)                                                                                                     \
+  if (bn == NTv * 16) {                                                                                                   \
+    auto kern = dec_conv16_kernel<T, NTv, 3, 3, true>;                                                                    \
+    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
+    if (prof) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, st, e0, e1, 0, g, fg);                                   \
+    else hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g, fg);                                                      \
+  }
+      CONV16F(2) CONV16F(4)
+#undef CONV16F
+      FH_CHECK_HIP(hipGetLastError());
+      return FLOAT_OK;
+    }
 #define CONV16(NTv, TYv, TXv)                                                                                    \
   if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv) {                                                       \
-    if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
-    else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);                  \
+    if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g, fg); \
+    else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g, fg);                  \
   }
     CONV16(4, 3, 3) CONV16(2, 3, 3) CONV16(4, 2, 2) CONV16(2, 2, 2) CONV16(4, 2, 1) CONV16(2, 2, 1) CONV16(4, 1, 2)
     CONV16(2, 1, 2) CONV16(4, 1, 1) CONV16(2, 1, 1)
@@ -517,11 +537,7 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
                        styles + c2.style_off, h->Stot);
   }
   }  // unfused path
-  // conv2 (plain 3x3); its unscaled output feeds ToFlow
-  if ((rc = launch_conv<T>(h, U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
-                           c2.abias, 1, nullptr, 0, st)))
-    return rc;
-  // ToFlow + warp + blend + ToRGB
+  // ToFlow + warp + blend + ToRGB operands (the launch itself follows conv2, or rides in conv2's epilogue)
   const bool last = (li == h->n_levels - 1);
   FlowArgs g;
   memset(&g, 0, sizeof(g));
@@ -547,6 +563,20 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   g.R = R;
   g.C = L.C;
   g.ld_s = h->Stot;
+  // conv2 (plain 3x3); its unscaled output feeds ToFlow.  Where one workgroup of the conv holds every channel of its pixels
+  // (C <= FLOAT_DEC_FUSE_FLOW: 32 = the 512-px level, 64 = also 256 px) the flow phase CAN run in the conv's epilogue (the
+  // conv2 tile goes through LDS instead of memory: -33.6 MB per frame at 512 px); xnext must not alias the conv's input then
+  // (it is read as halo by other workgroups while this one already writes): U is the z buffer on this path, xnext the
+  // callers' ping buffer.  Built, bitwise equal to the separate launches, and OFF by default: measured 30.5-30.9 ms per 250
+  // frames against 26.2 - a workgroup then alternates an MFMA phase and a gather phase behind two barriers at 2 workgroups
+  // per CU (the gather phase alone wants 168-230 VGPRs), which hides less latency than two launches that each fill the chip.
+  static const int fuse_c = getenv("FLOAT_DEC_FUSE_FLOW") ? atoi(getenv("FLOAT_DEC_FUSE_FLOW")) : 0;
+  const bool fuse = L.C <= fuse_c && (L.C == 32 || L.C == 64) && c2.cout == L.C && R % 16 == 0 && R >= 16;
+  FH_REQUIRE(!fuse || g.xnext != U, "fused conv2 + flow: the next level's input buffer aliases the conv's input");
+  if ((rc = launch_conv<T>(h, U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
+                           c2.abias, 1, nullptr, 0, st, fuse ? &g : nullptr)))
+    return rc;
+  if (fuse) return FLOAT_OK;
   // Grid: ~2048 workgroups in total (8 per CU) so that every lane group runs many pixel iterations and
   // the per-workgroup prologue (56 per-lane weight values) is amortised; one row of workgroups per frame.
   const int lpp = L.C / 8, gpb = 256 / lpp;

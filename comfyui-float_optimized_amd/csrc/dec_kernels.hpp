@@ -166,6 +166,216 @@ __device__ unsigned long long g_dec_stamps[4];
   DEC_STAMP_MIN(2);                                                 \
   const unsigned BID = blockIdx.x - (g).ct.nwg;
 
+// C/8 lanes share one pixel (8 channels each); `warp` never leaves registers.
+struct FlowArgs {
+  const u16* x;        // [F][R][R][C] conv2 output (unscaled)
+  const u16* feat;     // [R][R][C]
+  const float* pflow;  // [F][R/2][R/2][4] (3 channels + pad: one 16-byte load per tap) or nullptr
+  const float* prgb;   // [F][R/2][R/2][4] or nullptr
+  const float* wflow;  // [3][C], already * 1/sqrt(C)
+  const float* sflow;  // [F][ld_s] style of the ToFlow conv (offset applied)
+  const float* bflow;  // [3]
+  const float* wrgb;   // [3][C], already * 1/sqrt(C)
+  const float* b1;     // [3] FusedLeakyReLU bias
+  const float* b2;     // [3] ToRGB bias
+  const float* snext;  // [F][ld_s] or nullptr
+  u16* xnext;          // [F][R][R][C] or nullptr (last level)
+  float* flow_out;     // [F][R][R][4]
+  float* rgb_out;      // [F][R][R][4]
+  const float* lin;    // [R] identity grid: np.linspace(-1, 1, R) (float64) cast to float32
+  float* final_out;    // last level: frames
+  int final_mode;      // 0: none, 1: HWC clamp(-1,1)*0.5+0.5 (FLOAT.py:149-152), 2: raw CHW
+  int write_pyr;       // store flow_out / rgb_out (0 on the last level: nobody reads them)
+  int F, R, C, ld_s;
+  int nbands, band_pix;  // the image is cut into nbands runs of band_pix consecutive pixels (multiple of gpb*PIX)
+  CopyTail ct;           // copy that rides along (nwg == 0: none)
+};
+
+__device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, int Rp, int Y, int X, float out[3]) {
+  // Upsample([1,3,3,1]) of a 3-channel map (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR
+  // gain 4 -> per axis: even 2m: .25*p[m-1] + .75*p[m];  odd 2m+1: .75*p[m] + .25*p[m+1].
+  // The map is stored with 4 floats per pixel, so a tap is ONE 16-byte load for all three channels (the 4-byte-per-lane
+  // version issued 32 scattered load instructions per 4 pixels and cost 5 of the decoder's 34 ms).
+  const int my = Y >> 1, mx = X >> 1;
+  const int y0 = (Y & 1) ? my : my - 1, x0 = (X & 1) ? mx : mx - 1;
+  const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
+  float4 t[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int yy = y0 + a, xx = x0 + b;
+      const bool in = yy >= 0 && yy < Rp && xx >= 0 && xx < Rp;
+      t[a * 2 + b] = in ? *reinterpret_cast<const float4*>(prev + ((size_t)(f * Rp + yy) * Rp + xx) * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    }
+  out[0] = out[1] = out[2] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float wgt = (a ? 1.f - wy0 : wy0) * (b ? 1.f - wx0 : wx0);
+      out[0] += wgt * t[a * 2 + b].x;
+      out[1] += wgt * t[a * 2 + b].y;
+      out[2] += wgt * t[a * 2 + b].z;
+    }
+}
+
+__device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x}); saturates cleanly at +-1
+  return 1.f - 2.f / (1.f + __expf(2.f * x));
+}
+
+// One run of PIX consecutive pixels of a row (first pixel p0 = Y * R + X0 of frame f) for one lane group: ToFlow (1x1
+// modulated conv + up-sampled previous flow -> tanh / sigmoid), grid_sample of the skip features, blend, ToRGB, the pyramids,
+// the next level's input, the final frame.  xu[k] = this lane's 8 channels (c0 ..) of conv2's output at pixel k, 16-bit.
+// Shared by dec_flow_kernel (xu from memory) and the fused conv2 + flow epilogue of dec_conv16_kernel (xu from LDS).
+template <class T, int PIX>
+__device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* __restrict__ sw, int f, int p0, int sub, int lpp,
+                                                const uint4 (&xu)[PIX]) {
+  const int C = g.C, c0 = sub * 8;
+  const bool owner = sub < PIX;
+  const float bf0 = g.bflow[0], bf1 = g.bflow[1], bf2 = g.bflow[2];
+  const float b10 = g.b1[0], b11 = g.b1[1], b12 = g.b1[2], b20 = g.b2[0], b21 = g.b2[1], b22 = g.b2[2];
+  const int R = g.R, npix = R * R, Rp = R >> 1;
+  const float fR = (float)R;
+  {
+    const int Y = p0 / R, X0 = p0 - Y * R;  // R % PIX == 0: the PIX pixels share a row
+    const size_t po0 = (size_t)f * npix + p0;
+    float upf[3] = {0.f, 0.f, 0.f};  // up-sampled previous flow of THIS lane's pixel
+    if (g.pflow && owner) up2_tap3(g.pflow, f, Rp, Y, X0 + sub, upf);
+    const float gy = g.lin[Y];
+    float o[PIX][3];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) o[k][0] = o[k][1] = o[k][2] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const float4 w0 = *reinterpret_cast<const float4*>(sw + j * C + c0);
+      const float4 w1 = *reinterpret_cast<const float4*>(sw + j * C + c0 + 4);
+      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+#pragma unroll
+      for (int k = 0; k < PIX; ++k) {
+        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += wv[i] * T::to_float(xe[i]);
+        o[k][j] = a;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) {
+      // bias + up-sampled previous flow enter the sum once, in the lane that owns the pixel
+      const bool mine = sub == k;
+      o[k][0] += mine ? upf[0] + bf0 : 0.f;
+      o[k][1] += mine ? upf[1] + bf1 : 0.f;
+      o[k][2] += mine ? upf[2] + bf2 : 0.f;
+    }
+    for (int d = 1; d < lpp; d <<= 1) {
+#pragma unroll
+      for (int k = 0; k < PIX; ++k) {
+        o[k][0] += __shfl_xor(o[k][0], d, 64);
+        o[k][1] += __shfl_xor(o[k][1], d, 64);
+        o[k][2] += __shfl_xor(o[k][2], d, 64);
+      }
+    }
+    float mask[PIX], ax[PIX], ay[PIX];
+    uint4 fu[PIX][4];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) {
+      const float sx = fh_tanh_fast(o[k][0]) + g.lin[X0 + k], sy = fh_tanh_fast(o[k][1]) + gy;
+      mask[k] = fh_sigmoid(o[k][2]);
+      // grid_sample, align_corners=False: pixel = ((coord + 1) * size - 1) / 2
+      const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;
+      const float fx0 = floorf(ix), fy0 = floorf(iy);
+      const int x0 = (int)fx0, y0 = (int)fy0;  // |ix| <= R + 1: tanh bounds the sample position
+      ax[k] = ix - fx0;
+      ay[k] = iy - fy0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const int yy = y0 + a, xx = x0 + b;
+          const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
+          fu[k][a * 2 + b] = in ? *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * C + c0) : uint4{0u, 0u, 0u, 0u};
+        }
+    }
+    float upr[3] = {0.f, 0.f, 0.f};
+    if (g.prgb && owner) up2_tap3(g.prgb, f, Rp, Y, X0 + sub, upr);
+    float rgb[PIX][3];
+#pragma unroll
+    for (int k = 0; k < PIX; ++k) {
+      float fw[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) fw[i] = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]) * mask[k];
+          const u16* fe = reinterpret_cast<const u16*>(&fu[k][a * 2 + b]);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) fw[i] += wgt * T::to_float(fe[i]);
+        }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float4 w0 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0);
+        const float4 w1 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0 + 4);
+        rgb[k][j] = w0.x * fw[0] + w0.y * fw[1] + w0.z * fw[2] + w0.w * fw[3] + w1.x * fw[4] + w1.y * fw[5] + w1.z * fw[6] + w1.w * fw[7];
+      }
+      if (g.xnext) {
+        const float4 n0 = *reinterpret_cast<const float4*>(sw + 6 * C + c0);
+        const float4 n1 = *reinterpret_cast<const float4*>(sw + 6 * C + c0 + 4);
+        const float sn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
+        const float om = 1.f - mask[k];
+        uint4 ou;
+        u16* oe = reinterpret_cast<u16*>(&ou);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + T::to_float(xe[i]) * om) * sn[i]);
+        *reinterpret_cast<uint4*>(g.xnext + (po0 + k) * C + c0) = ou;
+      }
+    }
+    for (int d = 1; d < lpp; d <<= 1) {
+#pragma unroll
+      for (int k = 0; k < PIX; ++k) {
+        rgb[k][0] += __shfl_xor(rgb[k][0], d, 64);
+        rgb[k][1] += __shfl_xor(rgb[k][1], d, 64);
+        rgb[k][2] += __shfl_xor(rgb[k][2], d, 64);
+      }
+    }
+    if (owner) {
+      // this lane's pixel: select its sums out of the unrolled arrays
+      float r0 = rgb[0][0], r1 = rgb[0][1], r2 = rgb[0][2], f0 = o[0][0], f1 = o[0][1], f2 = o[0][2];
+#pragma unroll
+      for (int k = 1; k < PIX; ++k)
+        if (sub == k) {
+          r0 = rgb[k][0];
+          r1 = rgb[k][1];
+          r2 = rgb[k][2];
+          f0 = o[k][0];
+          f1 = o[k][1];
+          f2 = o[k][2];
+        }
+      const float v0 = fh_lrelu_s2(r0 + b10) + b20 + upr[0], v1 = fh_lrelu_s2(r1 + b11) + b21 + upr[1],
+                  v2 = fh_lrelu_s2(r2 + b12) + b22 + upr[2];
+      const size_t po = po0 + sub;
+      if (g.write_pyr) {  // the pyramids are only read by the next level
+        *reinterpret_cast<float4*>(g.flow_out + po * 4) = float4{f0, f1, f2, 0.f};
+        *reinterpret_cast<float4*>(g.rgb_out + po * 4) = float4{v0, v1, v2, 0.f};
+      }
+      if (g.final_mode == 1) {
+        float* fo = g.final_out + po * 3;
+        fo[0] = fminf(fmaxf(v0, -1.f), 1.f) * 0.5f + 0.5f;
+        fo[1] = fminf(fmaxf(v1, -1.f), 1.f) * 0.5f + 0.5f;
+        fo[2] = fminf(fmaxf(v2, -1.f), 1.f) * 0.5f + 0.5f;
+      } else if (g.final_mode == 2) {
+        float* fo = g.final_out + (size_t)f * 3 * npix + p0 + sub;
+        fo[0] = v0;
+        fo[npix] = v1;
+        fo[2 * (size_t)npix] = v2;
+      }
+    }
+  }
+}
+
 struct ConvArgs {
   const u16* X;   // [F][Hi][Wi][Cin], already multiplied by the layer's style
   const u16* Wt;  // [ntaps][Cout][Cin]
@@ -329,14 +539,23 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
 //     lane groups, tools/probes/lds_swizzle.py);
 //   * a workgroup walks `tpw` consecutive tiles and all K chunks as one item stream, and the global
 //     loads of item i+1 are issued into registers before the MFMAs of item i (single LDS buffer).
-template <class T, int NT, int TY, int TX>
-__global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
+#ifndef FUSE_PIX
+#define FUSE_PIX 2  // pixels per lane group and pass of the fused flow phase (1: 14 spilled VGPRs, 2: 67, 4: 99)
+#endif
+template <class T, int NT, int TY, int TX, bool FUSE = false>
+__global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs fg) {
   DEC_COPY_PROLOGUE(g, bid)
   constexpr int BN = NT * 16, HH = 15 + TY, HW = 15 + TX, NPIX = HH * HW, NTAPS = TY * TX;
+  static_assert(!FUSE || NT == 2 || NT == 4, "the fused flow phase takes 32 or 64 channels");
   constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sA = smem;              // [NPIX][64 B], chunk-swizzled
   unsigned char* sB = smem + NPIX * 64;  // [NTAPS][BN][64 B], chunk-swizzled
+  // FUSE: conv2's output tile [256 pixels][BN] 16-bit (what dec_flow_kernel would have read from memory) and the flow
+  // phase's folded per-frame weights [7][BN]
+  unsigned char* const sV = smem + NPIX * 64 + NTAPS * BN * 64;
+  float* const sw = reinterpret_cast<float*>(sV + 256 * BN * 2);
+  int sw_frame = -1;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
 
@@ -419,6 +638,8 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
       }
     }
     __syncthreads();
+    // the next item's loads fly while this item computes; the fused form issues them behind its flow phase instead (their
+    // 44 staging registers would otherwise be live across it: 85 spilled VGPRs)
     if (item + 1 < nitems) issue(item + 1);  // in flight while this item computes
     const int chunk = item % nchunks;
     if (chunk == 0) {
@@ -469,6 +690,62 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g) {
         }
       }
       const bool act = g.act != 0;
+      if constexpr (FUSE) {
+        // folded per-frame weights of the flow phase: rebuilt when the workgroup's tile stream enters another frame
+        if (f != sw_frame) {
+          __syncthreads();  // nobody still reads the previous frame's weights
+          for (int c = tid; c < BN; c += 256) {
+            const float s = fg.sflow[(size_t)f * fg.ld_s + c];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+              sw[j * BN + c] = fg.wflow[j * BN + c] * s;
+              sw[(3 + j) * BN + c] = fg.wrgb[j * BN + c];
+            }
+            sw[6 * BN + c] = fg.snext ? fg.snext[(size_t)f * fg.ld_s + c] : 0.f;
+          }
+          sw_frame = f;
+          __syncthreads();
+        }
+        // conv2's own epilogue into the LDS tile (the previous tile's flow phase finished reading it before this item's first
+        // barrier), then the flow phase of dec_flow_kernel on it: lane group = BN / 8 lanes per pixel, runs of consecutive pixels
+        // of a tile row per group
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+          const int pix = (w * 4 + mt) * 16 + r16;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            float v[4] = {acc[mt][j][0] * ed[j].x + eb[j].x, acc[mt][j][1] * ed[j].y + eb[j].y, acc[mt][j][2] * ed[j].z + eb[j].z,
+                          acc[mt][j][3] * ed[j].w + eb[j].w};
+            if (act) {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.2f * v[r]);
+            }
+            ushort4 o;
+            o.x = T::from_float(v[0] * es[j].x);
+            o.y = T::from_float(v[1] * es[j].y);
+            o.z = T::from_float(v[2] * es[j].z);
+            o.w = T::from_float(v[3] * es[j].w);
+            *reinterpret_cast<ushort4*>(sV + pix * (BN * 2) + (j * 16 + q * 4) * 2) = o;
+          }
+        }
+        __syncthreads();
+        {
+          // 2 pixels per lane group and pass: the 4-pixel form of dec_flow_kernel holds 230 VGPRs, which do not fit beside the
+          // conv's staging registers (99 spilled VGPRs); 2 pixels hold 168
+          constexpr int LPP = BN / 8, GPB = 256 / LPP, PIXF = FUSE_PIX, RPR = 16 / PIXF, PASSES = 256 / (GPB * PIXF);
+          const int sub = tid % LPP, grp = tid / LPP;
+#pragma unroll 1
+          for (int ps = 0; ps < PASSES; ++ps) {
+            const int run = ps * GPB + grp;            // run of PIXF consecutive pixels of a tile row
+            const int trow = run / RPR, tcol = (run % RPR) * PIXF;
+            uint4 xu[PIXF];
+#pragma unroll
+            for (int k = 0; k < PIXF; ++k) xu[k] = *reinterpret_cast<const uint4*>(sV + (trow * 16 + tcol + k) * (BN * 2) + sub * 16);
+            dec_flow_pixels<T, PIXF>(fg, sw, f, (ty * 16 + trow) * fg.R + tx * 16 + tcol, sub, LPP, xu);
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int m = (w * 4 + mt) * 16 + r16;
@@ -932,64 +1209,6 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
 //   warp   = grid_sample(feat, grid, bilinear, zeros, align_corners=False) * mask
 //   xnext  = (warp + x * (1 - mask)) * style_of_next_conv                       -> next level
 //   rgb    = lrelu(conv1x1(warp)/sqrt(C) + b1)*sqrt2 + b2 (+ Upsample(prev rgb))
-// C/8 lanes share one pixel (8 channels each); `warp` never leaves registers.
-struct FlowArgs {
-  const u16* x;        // [F][R][R][C] conv2 output (unscaled)
-  const u16* feat;     // [R][R][C]
-  const float* pflow;  // [F][R/2][R/2][4] (3 channels + pad: one 16-byte load per tap) or nullptr
-  const float* prgb;   // [F][R/2][R/2][4] or nullptr
-  const float* wflow;  // [3][C], already * 1/sqrt(C)
-  const float* sflow;  // [F][ld_s] style of the ToFlow conv (offset applied)
-  const float* bflow;  // [3]
-  const float* wrgb;   // [3][C], already * 1/sqrt(C)
-  const float* b1;     // [3] FusedLeakyReLU bias
-  const float* b2;     // [3] ToRGB bias
-  const float* snext;  // [F][ld_s] or nullptr
-  u16* xnext;          // [F][R][R][C] or nullptr (last level)
-  float* flow_out;     // [F][R][R][4]
-  float* rgb_out;      // [F][R][R][4]
-  const float* lin;    // [R] identity grid: np.linspace(-1, 1, R) (float64) cast to float32
-  float* final_out;    // last level: frames
-  int final_mode;      // 0: none, 1: HWC clamp(-1,1)*0.5+0.5 (FLOAT.py:149-152), 2: raw CHW
-  int write_pyr;       // store flow_out / rgb_out (0 on the last level: nobody reads them)
-  int F, R, C, ld_s;
-  int nbands, band_pix;  // the image is cut into nbands runs of band_pix consecutive pixels (multiple of gpb*PIX)
-  CopyTail ct;           // copy that rides along (nwg == 0: none)
-};
-
-__device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, int Rp, int Y, int X, float out[3]) {
-  // Upsample([1,3,3,1]) of a 3-channel map (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR
-  // gain 4 -> per axis: even 2m: .25*p[m-1] + .75*p[m];  odd 2m+1: .75*p[m] + .25*p[m+1].
-  // The map is stored with 4 floats per pixel, so a tap is ONE 16-byte load for all three channels (the 4-byte-per-lane
-  // version issued 32 scattered load instructions per 4 pixels and cost 5 of the decoder's 34 ms).
-  const int my = Y >> 1, mx = X >> 1;
-  const int y0 = (Y & 1) ? my : my - 1, x0 = (X & 1) ? mx : mx - 1;
-  const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
-  float4 t[4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int yy = y0 + a, xx = x0 + b;
-      const bool in = yy >= 0 && yy < Rp && xx >= 0 && xx < Rp;
-      t[a * 2 + b] = in ? *reinterpret_cast<const float4*>(prev + ((size_t)(f * Rp + yy) * Rp + xx) * 4) : float4{0.f, 0.f, 0.f, 0.f};
-    }
-  out[0] = out[1] = out[2] = 0.f;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float wgt = (a ? 1.f - wy0 : wy0) * (b ? 1.f - wx0 : wx0);
-      out[0] += wgt * t[a * 2 + b].x;
-      out[1] += wgt * t[a * 2 + b].y;
-      out[2] += wgt * t[a * 2 + b].z;
-    }
-}
-
-__device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x}); saturates cleanly at +-1
-  return 1.f - 2.f / (1.f + __expf(2.f * x));
-}
-
 // PIX consecutive pixels of a row per lane group and iteration: every x load of the iteration is
 // issued before the first flow is reduced, and every feature gather before the first blend.  The
 // per-frame folded weights (flow conv * style, rgb conv, next style: 7 x C floats) live in LDS, not in
@@ -1030,153 +1249,14 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     sw[6 * C + c] = g.snext ? g.snext[(size_t)f * g.ld_s + c] : 0.f;
   }
   __syncthreads();
-  // lane `sub` < PIX owns PIXEL `sub` of the iteration's run for the 3-channel maps (bias, pyramid taps, stores); C >= 32
-  // means at least 4 lanes per pixel group, so every pixel of the run has an owner
-  const bool owner = sub < PIX;
-  const float bf0 = g.bflow[0], bf1 = g.bflow[1], bf2 = g.bflow[2];
-  const float b10 = g.b1[0], b11 = g.b1[1], b12 = g.b1[2], b20 = g.b2[0], b21 = g.b2[1], b22 = g.b2[2];
-  const int R = g.R, npix = R * R, Rp = R >> 1;
-  const float fR = (float)R;
+  const int npix = g.R * g.R;
   const int pend = min(npix, (band + 1) * g.band_pix);
   for (int p0 = band * g.band_pix + grp * PIX; p0 < pend; p0 += gpb * PIX) {
-    const int Y = p0 / R, X0 = p0 - Y * R;  // R % PIX == 0: the PIX pixels share a row
     const size_t po0 = (size_t)f * npix + p0;
     uint4 xu[PIX];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) xu[k] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(g.x + (po0 + k) * C + c0)));  // read once: leave L2 to the features
-    float upf[3] = {0.f, 0.f, 0.f};  // up-sampled previous flow of THIS lane's pixel
-    if (g.pflow && owner) up2_tap3(g.pflow, f, Rp, Y, X0 + sub, upf);
-    const float gy = g.lin[Y];
-    float o[PIX][3];
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) o[k][0] = o[k][1] = o[k][2] = 0.f;
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const float4 w0 = *reinterpret_cast<const float4*>(sw + j * C + c0);
-      const float4 w1 = *reinterpret_cast<const float4*>(sw + j * C + c0 + 4);
-      const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
-#pragma unroll
-      for (int k = 0; k < PIX; ++k) {
-        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
-        float a = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a += wv[i] * T::to_float(xe[i]);
-        o[k][j] = a;
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) {
-      // bias + up-sampled previous flow enter the sum once, in the lane that owns the pixel
-      const bool mine = sub == k;
-      o[k][0] += mine ? upf[0] + bf0 : 0.f;
-      o[k][1] += mine ? upf[1] + bf1 : 0.f;
-      o[k][2] += mine ? upf[2] + bf2 : 0.f;
-    }
-    for (int d = 1; d < lpp; d <<= 1) {
-#pragma unroll
-      for (int k = 0; k < PIX; ++k) {
-        o[k][0] += __shfl_xor(o[k][0], d, 64);
-        o[k][1] += __shfl_xor(o[k][1], d, 64);
-        o[k][2] += __shfl_xor(o[k][2], d, 64);
-      }
-    }
-    float mask[PIX], ax[PIX], ay[PIX];
-    uint4 fu[PIX][4];
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) {
-      const float sx = fh_tanh_fast(o[k][0]) + g.lin[X0 + k], sy = fh_tanh_fast(o[k][1]) + gy;
-      mask[k] = fh_sigmoid(o[k][2]);
-      // grid_sample, align_corners=False: pixel = ((coord + 1) * size - 1) / 2
-      const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;
-      const float fx0 = floorf(ix), fy0 = floorf(iy);
-      const int x0 = (int)fx0, y0 = (int)fy0;  // |ix| <= R + 1: tanh bounds the sample position
-      ax[k] = ix - fx0;
-      ay[k] = iy - fy0;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const int yy = y0 + a, xx = x0 + b;
-          const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
-          fu[k][a * 2 + b] = in ? *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * C + c0) : uint4{0u, 0u, 0u, 0u};
-        }
-    }
-    float upr[3] = {0.f, 0.f, 0.f};
-    if (g.prgb && owner) up2_tap3(g.prgb, f, Rp, Y, X0 + sub, upr);
-    float rgb[PIX][3];
-#pragma unroll
-    for (int k = 0; k < PIX; ++k) {
-      float fw[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) fw[i] = 0.f;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]) * mask[k];
-          const u16* fe = reinterpret_cast<const u16*>(&fu[k][a * 2 + b]);
-#pragma unroll
-          for (int i = 0; i < 8; ++i) fw[i] += wgt * T::to_float(fe[i]);
-        }
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float4 w0 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0);
-        const float4 w1 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0 + 4);
-        rgb[k][j] = w0.x * fw[0] + w0.y * fw[1] + w0.z * fw[2] + w0.w * fw[3] + w1.x * fw[4] + w1.y * fw[5] + w1.z * fw[6] + w1.w * fw[7];
-      }
-      if (g.xnext) {
-        const float4 n0 = *reinterpret_cast<const float4*>(sw + 6 * C + c0);
-        const float4 n1 = *reinterpret_cast<const float4*>(sw + 6 * C + c0 + 4);
-        const float sn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
-        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
-        const float om = 1.f - mask[k];
-        uint4 ou;
-        u16* oe = reinterpret_cast<u16*>(&ou);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + T::to_float(xe[i]) * om) * sn[i]);
-        *reinterpret_cast<uint4*>(g.xnext + (po0 + k) * C + c0) = ou;
-      }
-    }
-    for (int d = 1; d < lpp; d <<= 1) {
-#pragma unroll
-      for (int k = 0; k < PIX; ++k) {
-        rgb[k][0] += __shfl_xor(rgb[k][0], d, 64);
-        rgb[k][1] += __shfl_xor(rgb[k][1], d, 64);
-        rgb[k][2] += __shfl_xor(rgb[k][2], d, 64);
-      }
-    }
-    if (owner) {
-      // this lane's pixel: select its sums out of the unrolled arrays
-      float r0 = rgb[0][0], r1 = rgb[0][1], r2 = rgb[0][2], f0 = o[0][0], f1 = o[0][1], f2 = o[0][2];
-#pragma unroll
-      for (int k = 1; k < PIX; ++k)
-        if (sub == k) {
-          r0 = rgb[k][0];
-          r1 = rgb[k][1];
-          r2 = rgb[k][2];
-          f0 = o[k][0];
-          f1 = o[k][1];
-          f2 = o[k][2];
-        }
-      const float v0 = fh_lrelu_s2(r0 + b10) + b20 + upr[0], v1 = fh_lrelu_s2(r1 + b11) + b21 + upr[1],
-                  v2 = fh_lrelu_s2(r2 + b12) + b22 + upr[2];
-      const size_t po = po0 + sub;
-      if (g.write_pyr) {  // the pyramids are only read by the next level
-        *reinterpret_cast<float4*>(g.flow_out + po * 4) = float4{f0, f1, f2, 0.f};
-        *reinterpret_cast<float4*>(g.rgb_out + po * 4) = float4{v0, v1, v2, 0.f};
-      }
-      if (g.final_mode == 1) {
-        float* fo = g.final_out + po * 3;
-        fo[0] = fminf(fmaxf(v0, -1.f), 1.f) * 0.5f + 0.5f;
-        fo[1] = fminf(fmaxf(v1, -1.f), 1.f) * 0.5f + 0.5f;
-        fo[2] = fminf(fmaxf(v2, -1.f), 1.f) * 0.5f + 0.5f;
-      } else if (g.final_mode == 2) {
-        float* fo = g.final_out + (size_t)f * 3 * npix + p0 + sub;
-        fo[0] = v0;
-        fo[npix] = v1;
-        fo[2 * (size_t)npix] = v2;
-      }
-    }
+    dec_flow_pixels<T, PIX>(g, sw, f, p0, sub, lpp, xu);
   }
   DEC_STAMP_MAX(3);
 }

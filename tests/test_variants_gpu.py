@@ -66,6 +66,17 @@ def test_fmt_touch_and_token_blocked_head_are_bitwise_neutral(tmp_path):
         assert torch.equal(base[k], grouped[k]), k
 
 
+def test_conv2_flow_fusion_matches_the_separate_launches(tmp_path):
+    """FLOAT_DEC_FUSE_FLOW=32 / 64 (off by default: slower): the flow phase in conv2's epilogue (512-px / also 256-px level) runs
+    dec_flow_kernel's code on the same 16-bit conv2 values, through LDS instead of memory and 2 pixels per lane group instead of
+    4, so the fp32 sums are scheduled differently: frames agree like the other fused variant (>= 72 dB), not bitwise."""
+    sep = run_child(tmp_path, "dec", "nofuse", {"FLOAT_DEC_FUSE_FLOW": "0"})["frames"]
+    for c in ("32", "64"):
+        fused = run_child(tmp_path, "dec", "fuse" + c, {"FLOAT_DEC_FUSE_FLOW": c})["frames"]
+        psnr = float(-10 * torch.log10(((fused - sep) ** 2).mean()))
+        assert psnr > 72.0 and float((fused - sep).abs().max()) < 0.05, (c, psnr)
+
+
 def test_fused_upsample_matches_separate_kernels(tmp_path):
     sep = run_child(tmp_path, "dec", "separate", {"FLOAT_DEC_ZBLUR_MIN": "9999"})["frames"]
     fused = run_child(tmp_path, "dec", "fused", {})["frames"]
