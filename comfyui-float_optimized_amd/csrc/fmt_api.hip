@@ -67,6 +67,18 @@ namespace {
 
 int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Stream-ordered device copies as kernel launches (see fmt_copy_kernel: memcpy / memset nodes of a caller's capture did not
+// replay reproducibly).
+int dev_copy2d(float* dst, size_t dpitch, const float* src, size_t spitch, int width, int rows, hipStream_t s) {
+  if (width <= 0 || rows <= 0) return FLOAT_OK;
+  hipLaunchKernelGGL(fmt_copy_kernel, dim3((unsigned)(((size_t)rows * width + 255) / 256)), dim3(256), 0, s, dst, dpitch, src, spitch, width, rows);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+int dev_copy(float* dst, const float* src, size_t n, hipStream_t s) { return dev_copy2d(dst, n, src, n, (int)n, 1, s); }
+int dev_zero(float* dst, size_t n, hipStream_t s) { return dev_copy2d(dst, n, nullptr, n, (int)n, 1, s); }
+
+
 template <class T>
 int pack_linear_pool(DevicePool* pool, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
                      Lin* out) {
@@ -865,8 +877,7 @@ int eval_impl(float_fmt* h, float t, const float* x, const float* wa, const floa
   if ((rc = stage_window<T>(h, m, x, wa, wr, we, we_len, prev_x, prev_wa, prev_we, s))) return rc;
   if ((rc = run_mod_all<T>(h, m.bc * h->ntok, 0, 1, s))) return rc;
   if ((rc = run_blocks<T>(h, 1, m.bc, h->modall, false, 0.f, a, r, e, s))) return rc;
-  FH_CHECK_HIP(hipMemcpyAsync(out, h->vout, (size_t)h->ntok * h->cfg.dim_w * sizeof(float), hipMemcpyDeviceToDevice, s));
-  return FLOAT_OK;
+  return dev_copy(out, h->vout, (size_t)h->ntok * h->cfg.dim_w, s);
 }
 
 // One window of the auto-regressive loop (FLOAT.py:214-251; nodes_adv.py:605-688).
@@ -881,9 +892,9 @@ int sample_window(float_fmt* h, int k, hipStream_t s) {
   if (k == 0) {
     if ((rc = prepare_time<T>(h, time_spec(h->method, J.nfe), std::max(1, n_evals(h->method, J.nfe)), s))) return rc;
     // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
-    FH_CHECK_HIP(hipMemsetAsync(h->prev_x, 0, (size_t)B * P * c.dim_w * sizeof(float), s));
-    FH_CHECK_HIP(hipMemsetAsync(h->prev_wa, 0, (size_t)B * P * c.dim_a * sizeof(float), s));
-    FH_CHECK_HIP(hipMemsetAsync(h->prev_we, 0, (size_t)B * P * c.dim_e * sizeof(float), s));
+    if ((rc = dev_zero(h->prev_x, (size_t)B * P * c.dim_w, s))) return rc;
+    if ((rc = dev_zero(h->prev_wa, (size_t)B * P * c.dim_a, s))) return rc;
+    if ((rc = dev_zero(h->prev_we, (size_t)B * P * c.dim_e, s))) return rc;
   } else if (P > 0) {
     // AR hand-off: last P frames of the previous final sample / (padded) wa window / we window, per clip
     hipLaunchKernelGGL(fmt_tail_kernel, blocks(B * P * c.dim_w), dim3(256), 0, s, h->prev_x, h->xcur, P, L, c.dim_w, B);
@@ -893,16 +904,12 @@ int sample_window(float_fmt* h, int k, hipStream_t s) {
   hipLaunchKernelGGL(fmt_slice_pad_kernel, blocks(B * L * c.dim_a), dim3(256), 0, s, h->wa_c, J.wa, k * L, Tn, L, c.dim_a, B);
   if (dynamic) hipLaunchKernelGGL(fmt_slice_pad_kernel, blocks(B * L * c.dim_e), dim3(256), 0, s, h->we_c, J.we, k * L, Tn, L, c.dim_e, B);
   // x0 is copied into the workspace so the window chain only ever sees handle-owned pointers; noise is (windows, clips, L, dim_w)
-  FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, J.noise + (size_t)k * B * L * c.dim_w, (size_t)B * L * c.dim_w * sizeof(float),
-                              hipMemcpyDeviceToDevice, s));
+  if ((rc = dev_copy(h->x0_c, J.noise + (size_t)k * B * L * c.dim_w, (size_t)B * L * c.dim_w, s))) return rc;
   rc = window_impl<T>(h, h->x0_c, h->wa_c, J.wr, dynamic ? h->we_c : J.we, dynamic ? L : 1, h->prev_x, h->prev_wa,
                       dynamic ? h->prev_we : nullptr, J.nfe, J.ts, J.a, J.r, J.e, J.include_r, s, B);
   if (rc) return rc;
   const int rows = (k == J.n_chunks - 1) ? (Tn - k * L) : L;  // trim to T (FLOAT.py:252)
-  FH_CHECK_HIP(hipMemcpy2DAsync(J.r_d + (size_t)k * L * c.dim_w, (size_t)Tn * c.dim_w * sizeof(float), h->xcur,
-                                (size_t)L * c.dim_w * sizeof(float), (size_t)rows * c.dim_w * sizeof(float), (size_t)B,
-                                hipMemcpyDeviceToDevice, s));
-  return FLOAT_OK;
+  return dev_copy2d(J.r_d + (size_t)k * L * c.dim_w, (size_t)Tn * c.dim_w, h->xcur, (size_t)L * c.dim_w, rows * c.dim_w, B, s);
 }
 
 template <class T>
@@ -1006,8 +1013,7 @@ template <class T>
 static int debug_impl(float_fmt* h, int what, const float* in, float* out, hipStream_t s) {
   const int D = h->D, ntok = h->ntok;
   if (what == 0) {
-    FH_CHECK_HIP(hipMemcpyAsync(out, h->pos, (size_t)ntok * D * sizeof(float), hipMemcpyDeviceToDevice, s));
-    return FLOAT_OK;
+    return dev_copy(out, h->pos, (size_t)ntok * D, s);
   }
   FH_REQUIRE(what == 1 && in != nullptr, "float_fmt_debug: unknown request %d (or null input)", what);
   const int n = ntok * 3 * D;
@@ -1154,13 +1160,13 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
   linspace01(nfe, &ts);
   const float_fmt_cfg_t& c = h->cfg;
   // stage caller tensors into handle-owned buffers (the graph path needs stable addresses)
-  FH_CHECK_HIP(hipMemcpyAsync(h->x0_c, x0, (size_t)c.n_cur * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
-  FH_CHECK_HIP(hipMemcpyAsync(h->wa_c, wa, (size_t)c.n_cur * c.dim_a * 4, hipMemcpyDeviceToDevice, s));
-  FH_CHECK_HIP(hipMemcpyAsync(h->prev_x, prev_x, (size_t)c.n_prev * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
-  FH_CHECK_HIP(hipMemcpyAsync(h->prev_wa, prev_wa, (size_t)c.n_prev * c.dim_a * 4, hipMemcpyDeviceToDevice, s));
+  if ((rc = dev_copy(h->x0_c, x0, (size_t)c.n_cur * c.dim_w, s))) return rc;
+  if ((rc = dev_copy(h->wa_c, wa, (size_t)c.n_cur * c.dim_a, s))) return rc;
+  if ((rc = dev_copy(h->prev_x, prev_x, (size_t)c.n_prev * c.dim_w, s))) return rc;
+  if ((rc = dev_copy(h->prev_wa, prev_wa, (size_t)c.n_prev * c.dim_a, s))) return rc;
   if (we_len > 1) {
-    FH_CHECK_HIP(hipMemcpyAsync(h->we_c, we, (size_t)c.n_cur * c.dim_e * 4, hipMemcpyDeviceToDevice, s));
-    FH_CHECK_HIP(hipMemcpyAsync(h->prev_we, prev_we, (size_t)c.n_prev * c.dim_e * 4, hipMemcpyDeviceToDevice, s));
+    if ((rc = dev_copy(h->we_c, we, (size_t)c.n_cur * c.dim_e, s))) return rc;
+    if ((rc = dev_copy(h->prev_we, prev_we, (size_t)c.n_prev * c.dim_e, s))) return rc;
   }
   const float* we_p = we_len > 1 ? h->we_c : we;
   const float* pwe_p = we_len > 1 ? h->prev_we : nullptr;
@@ -1177,8 +1183,7 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
   else FMT_CHUNK(FP32);
 #undef FMT_CHUNK
   if (rc) return rc;
-  FH_CHECK_HIP(hipMemcpyAsync(out, h->xcur, (size_t)c.n_cur * c.dim_w * 4, hipMemcpyDeviceToDevice, s));
-  return FLOAT_OK;
+  return dev_copy(out, h->xcur, (size_t)c.n_cur * c.dim_w, s);
 }
 
 int float_fmt_debug(float_fmt_t* h, int32_t what, const float* in, float* out, void* stream) {

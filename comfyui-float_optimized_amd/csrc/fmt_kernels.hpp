@@ -782,3 +782,14 @@ __global__ void fmt_dbg_unpack_kernel(float* __restrict__ dst, const u16* __rest
   const int r = i / D, c = i - r * D;
   dst[i] = T::to_float(reinterpret_cast<const typename T::elem*>(src)[fmt_pack_off(r, c, D / 32)]);
 }
+
+// Device-side copies / fills of the sampling calls.  Kernels, not hipMemcpyAsync / hipMemsetAsync: when the caller captures the
+// stream those become memcpy / memset NODES, and replays of such a graph were not reproducible on ROCm 7.2 (the r_d copy of
+// window k raced with window k+1's writes to the Euler state: the first 16 frames of a window differed from replay to replay);
+// kernel nodes of one captured stream keep their order.  rows x width floats, pitches in floats; src == nullptr fills zeros.
+__global__ void fmt_copy_kernel(float* __restrict__ dst, size_t dpitch, const float* __restrict__ src, size_t spitch, int width, int rows) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * width) return;
+  const int r = idx / width, c = idx - r * width;
+  dst[(size_t)r * dpitch + c] = src ? src[(size_t)r * spitch + c] : 0.f;
+}

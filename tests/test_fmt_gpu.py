@@ -95,3 +95,55 @@ def test_error_behaviour():
     del bad["blocks.0.attn.qkv.weight"]
     with pytest.raises(KeyError):
         pkg.fmt.FlowMatchingTransformerHIP(bad, cfg, "cuda:0")
+
+
+def test_sample_is_capturable_by_the_caller():
+    """include/float_hip.h: run-time calls may be issued while the caller captures `stream` - the chain is launched straight
+    into that capture (no nested graph launch, no host memory read by the stream: evaluation times are formed on the device).
+    A torch CUDA graph around `sample` must replay to the bits of the plain call, also after the inputs changed in place."""
+    cfg = C.small_fmt_config()
+    sd, fmt = _fmt(cfg, 9, "fp16")
+    T = 70
+    c = pkg.pipeline.synth_conditions(cfg, T, seed=4, device="cuda:0")
+    # small config: dim_w = dim_a = 128
+    g = torch.Generator().manual_seed(0)
+    r_s = torch.randn(1, cfg.dim_w, generator=g).cuda()
+    wa = torch.randn(1, T, cfg.dim_a, generator=g).cuda()
+    we = c["we"]
+    noise = pkg.fmt.draw_noise(2, 1, cfg, seed=15).cuda()
+    plain = fmt.sample(r_s, wa, we, noise, 5, 2.0, 1.0, 1.0).clone()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fmt.sample(r_s, wa, we, noise, 5, 2.0, 1.0, 1.0)  # warm-up on the capture stream
+        torch.cuda.current_stream().synchronize()
+        with torch.cuda.graph(graph, stream=side):
+            captured = fmt.sample(r_s, wa, we, noise, 5, 2.0, 1.0, 1.0)
+    torch.cuda.current_stream().wait_stream(side)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(captured, plain)
+    wa.mul_(0.5)  # same buffers, new contents: the replay must follow
+    want = fmt.sample(r_s, wa, we, noise, 5, 2.0, 1.0, 1.0).clone()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(want, plain)
+    d = (captured - want).abs().amax(dim=(0, 2))
+    assert torch.equal(captured, want), ("frames that differ", torch.nonzero(d).flatten().tolist()[:10], float(d.max()),
+                                         "captured == old result" if torch.equal(captured, plain) else "")
+
+
+def test_graph_cache_is_bounded():
+    """At most 8 window graphs per handle (least recently used evicted): sweeping a CFG scale neither leaks executables nor
+    changes results when an evicted key comes back."""
+    cfg = C.small_fmt_config()
+    sd, fmt = _fmt(cfg, 10, "fp16")
+    g = torch.Generator().manual_seed(1)
+    r_s, wa = torch.randn(1, cfg.dim_w, generator=g), torch.randn(1, 50, cfg.dim_a, generator=g)
+    we = torch.softmax(torch.randn(1, 1, cfg.dim_e, generator=g), -1)
+    noise = pkg.fmt.draw_noise(1, 1, cfg, seed=15)
+    first = fmt.sample(r_s, wa, we, noise, 4, 1.5, 1.0, 1.0).cpu()
+    for i in range(12):
+        assert torch.isfinite(fmt.sample(r_s, wa, we, noise, 4, 2.0 + 0.1 * i, 1.0, 1.0)).all()
+    assert torch.equal(fmt.sample(r_s, wa, we, noise, 4, 1.5, 1.0, 1.0).cpu(), first)
