@@ -16,9 +16,14 @@
  *     (the reference's tensors are fp32 everywhere); `stream` is a hipStream_t passed as void*.
  *     All work is enqueued on that stream; nothing synchronises the device.
  *   - batch size is 1 at this level, exactly like the reference decode loop (FLOAT.py:140);
- *     the host mirror loops over batch items as FloatProcess does (nodes.py:189-209).
+ *     the host mirror loops over batch items as FloatProcess does (nodes.py:189-209).  The one
+ *     batched entry is float_fmt_sample_batch (the reference's samplers take a batch).
  *   - a handle owns its packed weights and a fixed workspace allocated at create time; no
- *     allocation happens inside the run-time calls (they are hipGraph-capturable).
+ *     allocation happens inside the run-time calls (float_aud_reserve is the explicit exception).
+ *     Capture by the caller (hipStreamBeginCapture on `stream`) is supported and tested for the
+ *     float_fmt_* run-time calls, which enqueue kernels only; the decoder / encoder calls also use
+ *     hipMemcpyAsync, whose nodes in a caller's graph did not replay reproducibly on ROCm 7.2 in the
+ *     FMT (replaced by kernels there): capture them at your own risk.
  *   - calls on one handle must be serialised by the caller; different handles are independent.
  */
 #ifndef FLOAT_HIP_H
