@@ -157,3 +157,24 @@ def test_batched_sampling_runge_kutta():
     for q in range(2):
         alone = one.sample(cs[q]["r_s"], cs[q]["wa"], cs[q]["we"], noise[:, q:q + 1], 3).cpu()
         assert rel_l2(got[q:q + 1], alone) < 1e-3
+
+
+@pytest.mark.parametrize("method,nfe", [("euler", 131), ("rk4", 20), ("euler", 66)])
+def test_long_grids_cross_the_modulation_batch(method, nfe):
+    """More than 64 evaluations per window: the hoisted adaLN projection then runs in several batches of 64 evaluations
+    (130 = 64 + 64 + 2; rk4 at nfe 20 = 76; 65 = 64 + 1), each reusing the modulation slab.  Small model, fp32 operands against
+    the oracle at 1e-4, and fp16 at its own tolerance; the per-evaluation projection (FLOAT_FMT_HOIST=0) is covered bitwise
+    by tests/test_variants_gpu.py."""
+    cfg = C.small_fmt_config()
+    sd = W.synth_fmt_state(cfg, seed=51)
+    g = torch.Generator().manual_seed(3)
+    T = 60
+    r_s, wa = torch.randn(1, cfg.dim_w, generator=g), torch.randn(1, T, cfg.dim_a, generator=g)
+    we = torch.softmax(torch.randn(1, 1, cfg.dim_e, generator=g), -1)
+    noise = pkg.fmt.draw_noise(2, 1, cfg, seed=15)
+    ref = O.sample_rd(sd, cfg, r_s, wa, we, noise, nfe, 2.0, 1.0, 1.0, method=method)
+    for dtype, tol in (("fp32", 1e-4), ("fp16", 4e-3)):
+        m = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", dtype)
+        m.set_method(method)
+        got = m.sample(r_s, wa, we, noise, nfe, 2.0, 1.0, 1.0).cpu()
+        assert rel_l2(got, ref) < tol, (dtype, rel_l2(got, ref))
