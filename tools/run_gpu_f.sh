@@ -1,2 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_edge_cases_gpu.py -m gpu -x -q -k long_grids 2>&1 | tail -5
+mkdir -p gpurun_out/r02_final
+python bench.py > gpurun_out/r02_final/bench.json 2> gpurun_out/r02_final/bench.err
+python -c "
+import json; d=json.load(open('gpurun_out/r02_final/bench.json')); print(d['value'], d['ms_per_step']); print(d['roofline']); print(d.get('warnings'))"
