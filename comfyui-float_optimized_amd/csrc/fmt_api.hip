@@ -126,10 +126,10 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
 
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
 int g_fmt_wide_variant = 2;  // FLOAT_FMT_WIDE_VARIANT: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2 (measured best: all 180 rows in one workgroup, weights read once), 3 = 192 x 4
-template <class T, int MTW, int KCH>
+template <class T, int MTW, int KCH, int NWV = 4>
 int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   constexpr int smem = 2 * MTW * KCH * 1024;
-  auto kern = fmt_gemm_wide_kernel<T, MTW, KCH>;
+  auto kern = fmt_gemm_wide_kernel<T, MTW, KCH, NWV>;
   if (prime) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       (void)hipGetLastError();
@@ -139,8 +139,8 @@ int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   g.mblk = (mt_total + MTW - 1) / MTW;
   const dim3 grid((g.N / 128) * g.mblk * (g.zcount > 1 ? g.zcount : 1));
   hipEvent_t e0, e1;
-  if (fh_prof_pair(2, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, s, e0, e1, 0, g);
-  else hipLaunchKernelGGL(kern, grid, dim3(256), smem, s, g);
+  if (fh_prof_pair(2, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, e0, e1, 0, g);
+  else hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -154,17 +154,21 @@ int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
     (void)launch_wide_t<T, 6, 2>(g, true, s);
     (void)launch_wide_t<T, 12, 2>(g, true, s);
     (void)launch_wide_t<T, 12, 4>(g, true, s);
+    (void)launch_wide_t<T, 12, 2, 8>(g, true, s);
+    (void)launch_wide_t<T, 12, 4, 8>(g, true, s);
     return FLOAT_OK;
   }
   if (mt <= 4) return launch_wide_t<T, 4, 4>(g, false, s);
   // 192-row blocks also for the stacked clips of a batch (mt > 12): the last block reads up to 11 row tiles past the batch (the
   // operand buffers are padded for it, the rows are never stored); 80-row blocks ran the batched projection at 240 TFLOP/s
   // against 700 for 192-row ones
-  if (mt <= 12 || g_fmt_wide_variant == 2) {
+  if (mt <= 12 || g_fmt_wide_variant == 2 || g_fmt_wide_variant >= 4) {
     switch (g_fmt_wide_variant) {
       case 1: return launch_wide_t<T, 6, 2>(g, false, s);
       case 2: return launch_wide_t<T, 12, 2>(g, false, s);
       case 3: return launch_wide_t<T, 12, 4>(g, false, s);
+      case 4: return launch_wide_t<T, 12, 2, 8>(g, false, s);  // two waves per SIMD, rows split over the wave pairs
+      case 5: return launch_wide_t<T, 12, 4, 8>(g, false, s);
       default: return launch_wide_t<T, 6, 4>(g, false, s);
     }
   }

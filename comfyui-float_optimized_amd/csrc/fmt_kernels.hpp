@@ -274,12 +274,16 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
 //     straight to registers, non-temporal;
 //   * operands are swapped (D = W_tile * A_tile^T) so a lane holds 4 consecutive columns of one row and
 //     the fp32 result is stored as float4.
-template <class T, int MTW, int KCH /* k-blocks (of 32) per LDS chunk */>
-__global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
+// NWV = 8: two waves per SIMD - waves 0..3 own the upper half of the row tiles, waves 4..7 the lower half, both halves the
+// same four 32-column slices (each weight fragment is then loaded by two waves, from L2; the LDS reads per MFMA do not change).
+template <class T, int MTW, int KCH /* k-blocks (of 32) per LDS chunk */, int NWV = 4>
+__global__ __launch_bounds__(NWV * 64) void fmt_gemm_wide_kernel(GemmArgs g) {
   constexpr int NF = MTW * KCH;            // 1-KiB A fragments per chunk
-  constexpr int NFW = (NF + 3) / 4;        // fragments staged by one wave
+  constexpr int NFW = (NF + NWV - 1) / NWV;  // fragments staged by one wave
+  constexpr int WR = NWV / 4, MTR = MTW / WR;  // row halves, row tiles per wave
+  static_assert(MTW % WR == 0, "row tiles must split evenly over the wave rows");
   extern __shared__ __attribute__((aligned(16))) unsigned char sA[];  // [2][MTW][KCH][1 KiB]
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wc = w & 3, wr = w >> 2;
   const int r16 = lane & 15, q = lane >> 4;
   const int nbx = g.N >> 7;
   int bx, by, bz = 0;
@@ -317,7 +321,7 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
     }
   }
   const int mt0 = by * MTW;
-  const int nb0 = bx * 8 + w * 2;  // this wave's two 16-column tiles
+  const int nb0 = bx * 8 + wc * 2;  // this wave's two 16-column tiles
   const int KB = g.K >> 5;
   const int nchunk = KB / KCH;
   const size_t tstride = (size_t)KB * 512;
@@ -325,9 +329,9 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
   const u16* Ag = g.A + (size_t)bz * g.a_zstride + (size_t)mt0 * tstride + lane * 8;
   float* const outz = g.out_f32 + (size_t)bz * g.o_zstride;
 
-  f32x4 acc[MTW][2];
+  f32x4 acc[MTR][2];
 #pragma unroll
-  for (int i = 0; i < MTW; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < MTR; ++i) acc[i][0] = acc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // Register-staged software pipeline (all ordinary loads, so hipcc's counted vmcnt waits keep the next
   // chunk in flight): while chunk c is multiplied out of LDS buffer c&1 and the b registers, the A
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
     const int kc = c * KCH;
 #pragma unroll
     for (int f = 0; f < NFW; ++f) {
-      const int fi = f * 4 + w;
+      const int fi = f * NWV + w;
       if (fi < NF) {
         const int i = fi / KCH, kk = fi % KCH;
         an[f] = *reinterpret_cast<const u32x4*>(Ag + i * tstride + (size_t)(kc + kk) * 512);
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
   auto commit = [&](int buf) {  // registers -> LDS buffer `buf`, weights -> current set
 #pragma unroll
     for (int f = 0; f < NFW; ++f) {
-      const int fi = f * 4 + w;
+      const int fi = f * NWV + w;
       if (fi < NF) *reinterpret_cast<u32x4*>(sA + (buf * NF + fi) * 1024 + lane * 16) = an[f];
     }
 #pragma unroll
@@ -370,8 +374,8 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
 #pragma unroll
     for (int kk = 0; kk < KCH; ++kk) {
 #pragma unroll
-      for (int i = 0; i < MTW; ++i) {
-        const u32x4 a = *reinterpret_cast<const u32x4*>(sA + (buf * NF + i * KCH + kk) * 1024 + lane * 16);
+      for (int i = 0; i < MTR; ++i) {
+        const u32x4 a = *reinterpret_cast<const u32x4*>(sA + (buf * NF + (wr * MTR + i) * KCH + kk) * 1024 + lane * 16);
         acc[i][0] = T::mfma(bc[kk][0], a, acc[i][0]);
         acc[i][1] = T::mfma(bc[kk][1], a, acc[i][1]);
       }
@@ -383,8 +387,8 @@ __global__ __launch_bounds__(256) void fmt_gemm_wide_kernel(GemmArgs g) {
   }
   // D[n = q*4 + reg][m = r16]: lane -> row m0 + i*16 + r16, columns n0 + j*16 + q*4 .. +3
 #pragma unroll
-  for (int i = 0; i < MTW; ++i) {
-    const int row = (mt0 + i) * 16 + r16;
+  for (int i = 0; i < MTR; ++i) {
+    const int row = (mt0 + wr * MTR + i) * 16 + r16;
     if (row >= g.M) continue;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
