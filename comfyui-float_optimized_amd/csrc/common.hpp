@@ -236,6 +236,10 @@ struct DevicePool {
   }
 };
 
+// Stream-ordered device-to-device copy of `bytes` bytes (a multiple of 4) as a KERNEL: memcpy nodes of a caller's stream
+// capture did not replay reproducibly on ROCm 7.2 (fmt_copy_kernel), kernel nodes do.  misc.hip.
+int fh_copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s);
+
 // Direction (styledecoder.py:428-444) helpers shared by the encoder and the decoder operators (enc_api.hip):
 // Q of the Householder QR of (W + 1e-8) with LAPACK sign conventions, and y = alpha * W x + b in fp32.
 void fh_direction_q(const float* w, int dim, int dim_motion, std::vector<float>* Q);

@@ -839,7 +839,8 @@ int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_
   hipStream_t st = (hipStream_t)stream;
   for (int li = 0; li < h->n_levels; ++li) {
     const Level& L = h->levels[li];
-    FH_CHECK_HIP(hipMemcpyAsync(L.feat, feats16[li], (size_t)L.R * L.R * L.C * sizeof(u16), hipMemcpyDeviceToDevice, st));
+    int rc = fh_copy_d2d(L.feat, feats16[li], (size_t)L.R * L.R * L.C * sizeof(u16), st);
+    if (rc) return rc;
   }
   h->feats_set = true;
   return FLOAT_OK;

@@ -271,7 +271,7 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
   }
   // EqualConv2d(C, dim, 4): 4x4 -> 1x1 = s_r (encoder.py:219, 231)
   if ((rc = launch_conv<T>(h->last, h->res[nb], 4, 4, 1, 0, nullptr, h->s_r, nullptr, st))) return rc;
-  if (s_r) FH_CHECK_HIP(hipMemcpyAsync(s_r, h->s_r, (size_t)c.dim * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (s_r && (rc = fh_copy_d2d(s_r, h->s_r, (size_t)c.dim * sizeof(float), st))) return rc;
   // Encoder.fc: EqualLinear chain without activation (encoder.py:242-247, 101-143)
   const float* cur = h->s_r;
   float* pp[2] = {h->fcA, h->fcB};
@@ -281,7 +281,7 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
     hipLaunchKernelGGL(enc_linear_kernel, dim3((L.n + 3) / 4), dim3(256), 0, st, cur, L.W, L.b, 1.0f / sqrtf((float)L.k), dst, L.n, L.k);
     cur = dst;
   }
-  if (lam) FH_CHECK_HIP(hipMemcpyAsync(lam, cur, (size_t)c.dim_motion * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (lam && (rc = fh_copy_d2d(lam, cur, (size_t)c.dim_motion * sizeof(float), st))) return rc;
   if (r_s) {
     FH_REQUIRE(h->Q != nullptr, "r_s requested but the encoder was created without 'direction.weight'");
     hipLaunchKernelGGL(enc_linear_kernel, dim3((c.dim + 3) / 4), dim3(256), 0, st, cur, h->Q, (const float*)nullptr, 1.0f, r_s, c.dim,

@@ -63,6 +63,20 @@ void fh_prof_end(int which, hipStream_t st) {
   s.open = nullptr;
 }
 
+__global__ void fh_copy_words_kernel(unsigned* __restrict__ dst, const unsigned* __restrict__ src, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+
+int fh_copy_d2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  FH_REQUIRE(bytes % 4 == 0, "fh_copy_d2d: %zu bytes is not a multiple of 4", bytes);
+  if (!bytes) return FLOAT_OK;
+  const size_t n = bytes / 4;
+  hipLaunchKernelGGL(fh_copy_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (unsigned*)dst, (const unsigned*)src, n);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
 extern "C" {
 
 int float_hip_abi_version(void) { return FLOAT_HIP_ABI_VERSION; }

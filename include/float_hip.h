@@ -20,10 +20,10 @@
  *     batched entry is float_fmt_sample_batch (the reference's samplers take a batch).
  *   - a handle owns its packed weights and a fixed workspace allocated at create time; no
  *     allocation happens inside the run-time calls (float_aud_reserve is the explicit exception).
- *     Capture by the caller (hipStreamBeginCapture on `stream`) is supported and tested for the
- *     float_fmt_* run-time calls, which enqueue kernels only; the decoder / encoder calls also use
- *     hipMemcpyAsync, whose nodes in a caller's graph did not replay reproducibly on ROCm 7.2 in the
- *     FMT (replaced by kernels there): capture them at your own risk.
+ *     Every run-time call enqueues kernels only (device-to-device moves included: memcpy / memset
+ *     nodes of a caller's stream capture did not replay reproducibly on ROCm 7.2), except
+ *     float_dec_frames_host, whose last batch goes to the host by hipMemcpyAsync.  Capture by the
+ *     caller (hipStreamBeginCapture on `stream`) is tested for the float_fmt_* calls.
  *   - calls on one handle must be serialised by the caller; different handles are independent.
  */
 #ifndef FLOAT_HIP_H
