@@ -346,14 +346,28 @@ Tiling pick_tiling32(int M) {
   return {mt <= 5 ? mt : (mt <= 12 ? 3 : 5), 1, 4};
 }
 
+// Per-layer tiling overrides of the one-clip chain (tuning aid): FLOAT_FMT_PLAN_QKV / _PROJ / _FC1 / _FC2 = "mtw,nt,nw".
+struct LayerPlan {
+  int v[3] = {0, 0, 0};
+  explicit LayerPlan(const char* env) {
+    if (const char* e = getenv(env)) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]);
+  }
+  bool on() const { return v[0] > 0; }
+};
+
 template <class T, int EPI>
-int run_gemm(const GemmArgs& g, hipStream_t s, bool need_full_rows = false) {
+int run_gemm(const GemmArgs& g, hipStream_t s, bool need_full_rows = false, const LayerPlan* plan = nullptr) {
   if constexpr (T::is32) {
     FH_REQUIRE(!need_full_rows, "the fp32 mode has no all-rows CFG epilogue tiling (token-blocked head only)");
     const Tiling t = pick_tiling32(g.M);
     GemmArgs g2 = g;
     g2.touch.W = nullptr;
     return launch_gemm<T, EPI>(g2, t.mtw, t.nt, t.nw, false, s);
+  }
+  if (plan && plan->on() && (g.M + 15) / 16 <= 15) {
+    GemmArgs g2 = g;
+    g2.touch.W = nullptr;  // the touch descriptors follow the default block decode
+    return launch_gemm<T, EPI>(g2, plan->v[0], plan->v[1], plan->v[2], false, s);
   }
   const Tiling t = pick_tiling(g.M, g.N, g.K, need_full_rows);
   return launch_gemm<T, EPI>(g, t.mtw, t.nt, t.nw, false, s);
@@ -370,11 +384,15 @@ struct PendingRed {
 };
 
 template <class T>
-int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s) {
+int run_gemm_partial(float_fmt* h, GemmArgs g, int ksplit, hipStream_t s, const LayerPlan* plan = nullptr) {
   g.ksplit = ksplit;
   g.out_f32 = h->slab;
   g.ldo = g.N;
   g.slab_stride = (size_t)h->Mpad * g.N;
+  if (plan && plan->on() && !T::is32 && (g.M + 15) / 16 <= 15) {
+    g.touch.W = nullptr;
+    return launch_gemm<T, EPI_PARTIAL>(g, plan->v[0], plan->v[1], plan->v[2], false, s);
+  }
   Tiling t = T::is32 ? pick_tiling32(g.M) : pick_tiling(g.M, g.N * ksplit, g.K / ksplit, false);
   while (t.nt > 1 && g.N % (t.nt * 16)) t.nt >>= 1;
   if (T::is32) g.touch.W = nullptr;
@@ -562,7 +580,8 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       g.out16 = h->qkv16;
       g.ldo16 = 3 * D;
       if ((g_fmt_touch & 8) && !split_ok(g_fmt_proj_split, B.proj)) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
-      if ((rc = run_gemm<T, EPI_T16>(g, s))) return rc;
+      static const LayerPlan plan("FLOAT_FMT_PLAN_QKV");
+      if ((rc = run_gemm<T, EPI_T16>(g, s, false, &plan))) return rc;
     }
     launch_attn<T>(h, M, (g_fmt_touch & 2) && !split_ok(g_fmt_proj_split, B.proj) ? &B.proj : nullptr, s);
     if (split_ok(g_fmt_proj_split, B.proj)) {
@@ -576,7 +595,8 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       g.gate = mod + 2 * D;
       g.ldg = h->Ntot;
       if (g_fmt_touch & 16) g.touch = make_touch(B.fc1, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
-      if ((rc = run_gemm<T, EPI_GATE_RES>(g, s))) return rc;
+      static const LayerPlan plan("FLOAT_FMT_PLAN_PROJ");
+      if ((rc = run_gemm<T, EPI_GATE_RES>(g, s, false, &plan))) return rc;
     }
     if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, &B.fc1, nullptr, 0, 64))) return rc;
     {
@@ -585,7 +605,8 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       g.ldo16 = B.fc2.K / 32;  // packed for fc2
       if (g_fmt_touch & 4)
         g.touch = make_touch(B.fc2, M, split_ok(g_fmt_fc2_split, B.fc2) ? g_fmt_fc2_split : 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
-      if ((rc = run_gemm<T, EPI_GELU_P16>(g, s))) return rc;
+      static const LayerPlan plan("FLOAT_FMT_PLAN_FC1");
+      if ((rc = run_gemm<T, EPI_GELU_P16>(g, s, false, &plan))) return rc;
     }
     if (split_ok(g_fmt_fc2_split, B.fc2)) {
       GemmArgs g = base_args(h->hid16, B.fc2, M);
@@ -594,7 +615,8 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
         if (b + 1 < c.depth) g.touch = make_touch(h->blk[b + 1].qkv, M, 0, lanes, 2);
         else g.touch = make_touch(h->final_lin, M, 0, lanes, 2, 1);  // the head GEMM runs 16-column workgroups
       }
-      if ((rc = run_gemm_partial<T>(h, g, g_fmt_fc2_split, s))) return rc;
+      static const LayerPlan plan("FLOAT_FMT_PLAN_FC2");
+      if ((rc = run_gemm_partial<T>(h, g, g_fmt_fc2_split, s, &plan))) return rc;
       pend.ks = g_fmt_fc2_split;
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.fc2.b, mod + 5 * D};
     } else {
