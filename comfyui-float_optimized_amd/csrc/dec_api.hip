@@ -342,6 +342,9 @@ static CopyTail take_ride(float_dec* h, int R, int kind) {
   return ct;
 }
 
+// FLOAT_DEC_CB_ORDER=0: output-channel blocks as grid.y (the round-1 order; A/B switch of dec_group_cb)
+static const bool g_dec_cb_order = !(getenv("FLOAT_DEC_CB_ORDER") && atoi(getenv("FLOAT_DEC_CB_ORDER")) == 0);
+
 template <class T>
 int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, int ntaps, const int* dy, const int* dx,
                 u16* Y, int Ho, int Wo, int OH, int OW, int sy, int sx, int py, int px, int F, const float* demod, int ldd,
@@ -416,6 +419,11 @@ int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, con
     const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64 + (fuse ? (size_t)256 * bn * 2 + (size_t)7 * bn * 4 : 0);
     if (h) g.ct = take_ride(h, Ho, fuse ? 3 : 1);
     dim3 grid((total + g.tpw - 1) / g.tpw + g.ct.nwg, s.cout / bn);
+    if (g_dec_cb_order && s.cout / bn > 1) {  // channel blocks of a tile group side by side on one XCD (dec_group_cb)
+      g.ngroups = (unsigned)((total + g.tpw - 1) / g.tpw);
+      g.ncb = (unsigned)(s.cout / bn);
+      grid = dim3(g.ngroups * g.ncb + g.ct.nwg, 1);
+    }
     FlowArgs fg;
     memset(&fg, 0, sizeof(fg));
     if (fuse) {
@@ -495,6 +503,11 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
     const bool prof = fh_prof_pair(1, &e0, &e1);
     z.ct = take_ride(h, R, 0);
     dim3 grid(z.tiles_x * z.tiles_y * n + z.ct.nwg, up.cout / 32);
+    if (g_dec_cb_order && up.cout / 32 > 1) {
+      z.ngroups = (unsigned)(z.tiles_x * z.tiles_y * n);
+      z.ncb = (unsigned)(up.cout / 32);
+      grid = dim3(z.ngroups * z.ncb + z.ct.nwg, 1);
+    }
     const size_t smem = 32 * 32 * 64;
     if (prof) hipExtLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, e0, e1, 0, z);
     else hipLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, z);

@@ -394,7 +394,28 @@ struct ConvArgs {
   int tpw;                          // dec_conv16_kernel: consecutive tiles per workgroup
   signed char dy[9], dx[9];
   CopyTail ct;                      // dec_conv16_kernel / dec_zblur_kernel: copy that rides along (nwg == 0: none)
+  // dec_conv16_kernel / dec_zblur_kernel, ncb > 0: 1-D grid of ngroups x ncb compute workgroups, decoded by dec_group_cb
+  // (ncb == 0: the output-channel block is blockIdx.y)
+  unsigned ncb, ngroups;
 };
+
+// (tile group, output-channel block) of compute workgroup `bid`.  A layer with more than 32 output channels runs ncb workgroups
+// per tile group that all stage the same input halo; as grid.y they were a whole batch apart (at 256 px: 268 MB of input per
+// 32-frame batch between the first and the second read - every re-read came from HBM).  Here they are ncb consecutive slots of
+// ONE XCD (ids congruent mod 8 share an L2 under round-robin placement: a speed assumption only), so the halo is fetched
+// once and re-read from that L2 while it is hot.  The groups past the last multiple of 8 use the plain order.
+__device__ __forceinline__ void dec_group_cb(unsigned bid, unsigned ngroups, unsigned ncb, unsigned& grp, unsigned& cb) {
+  const unsigned g8 = ngroups & ~7u, cut = g8 * ncb;
+  if (bid < cut) {
+    const unsigned slot = bid >> 3;
+    cb = slot % ncb;
+    grp = (slot / ncb) * 8 + (bid & 7);
+  } else {
+    const unsigned r = bid - cut;
+    cb = r % ncb;
+    grp = g8 + r / ncb;
+  }
+}
 
 template <class T, int NT>
 __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
@@ -583,10 +604,12 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
   const int tiles_pf = g.tiles_x * g.tiles_y;
   const int total = tiles_pf * g.F;
   const int nchunks = g.Cin >> 5;
-  const int tile0 = bid * g.tpw;
+  unsigned grp = bid, cb = blockIdx.y;
+  if (g.ncb) dec_group_cb(bid, g.ngroups, g.ncb, grp, cb);
+  const int tile0 = grp * g.tpw;
   const int ntile = min(g.tpw, total - tile0);
   const int nitems = ntile * nchunks;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = cb * BN;
 
   u32x4 ra[NA], rb[NB];
   auto issue = [&](int item) {
@@ -946,10 +969,12 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
   }
   const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);
   const int tiles_pf = g.tiles_x * g.tiles_y;
-  const int tile = bid;
+  unsigned grp = bid, cb = blockIdx.y;
+  if (g.ncb) dec_group_cb(bid, g.ngroups, g.ncb, grp, cb);
+  const int tile = grp;
   const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
   const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = cb * BN;
   const int nchunks = g.Cin >> 5;
   const int iy0 = ty * 14 - 2, ix0 = tx * 14 - 2;
 

@@ -276,7 +276,13 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
 //     the fp32 result is stored as float4.
 // NWV = 8: two waves per SIMD - waves 0..3 own the upper half of the row tiles, waves 4..7 the lower half, both halves the
 // same four 32-column slices (each weight fragment is then loaded by two waves, from L2; the LDS reads per MFMA do not change).
-template <class T, int MTW, int KCH /* k-blocks (of 32) per LDS chunk */, int NWV = 4>
+//
+// EPI != EPI_F32: the same body as a GEMM of the step chain when clips are stacked (float_fmt_sample_batch, >= 360 rows): there
+// the 48 x 64 tiles of fmt_gemm_kernel re-read both operands from L2 per workgroup (229 KB for 3072 outputs), here a workgroup
+// reads 384 + 256 KB per K = 1024 for 24 576 outputs.  EPI_T16 / EPI_GELU_P16 write 4 consecutive 16-bit columns per lane
+// (row-major / the packed order of the consuming GEMM); EPI_PARTIAL cuts K into g.ksplit slices, one per workgroup, with the
+// slice <-> XCD affinity of fmt_gemm_kernel, and leaves the sum to the LayerNorm that follows.
+template <class T, int MTW, int KCH /* k-blocks (of 32) per LDS chunk */, int NWV = 4, int EPI = EPI_F32>
 __global__ __launch_bounds__(NWV * 64) void fmt_gemm_wide_kernel(GemmArgs g) {
   constexpr int NF = MTW * KCH;            // 1-KiB A fragments per chunk
   constexpr int NFW = (NF + NWV - 1) / NWV;  // fragments staged by one wave
@@ -285,8 +291,9 @@ __global__ __launch_bounds__(NWV * 64) void fmt_gemm_wide_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sA[];  // [2][MTW][KCH][1 KiB]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wc = w & 3, wr = w >> 2;
   const int r16 = lane & 15, q = lane >> 4;
-  const int nbx = g.N >> 7;
-  int bx, by, bz = 0;
+  const int nbn = g.N >> 7;
+  const int nbx = (EPI == EPI_PARTIAL) ? nbn * g.ksplit : nbn;  // (column block, K slice) pairs
+  int bx, by, bz = 0, ks = 0;
   {
     const int id = blockIdx.x;
     const int nz = g.zcount > 1 ? g.zcount : 1;
@@ -319,15 +326,26 @@ __global__ __launch_bounds__(NWV * 64) void fmt_gemm_wide_kernel(GemmArgs g) {
       bz = zy / g.mblk;
       by = zy - bz * g.mblk;
     }
+    if constexpr (EPI == EPI_PARTIAL) {
+      if ((nbx & 7) == 0 && (8 % g.ksplit) == 0) {
+        const int P = 8 / g.ksplit, x = bx & 7;
+        ks = x / P;
+        bx = (bx >> 3) * P + (x % P);
+      } else {
+        ks = bx / nbn;
+        bx = bx % nbn;
+      }
+    }
   }
   const int mt0 = by * MTW;
   const int nb0 = bx * 8 + wc * 2;  // this wave's two 16-column tiles
   const int KB = g.K >> 5;
-  const int nchunk = KB / KCH;
+  const int KBs = (EPI == EPI_PARTIAL) ? KB / g.ksplit : KB;  // k-blocks of this workgroup's K slice
+  const int nchunk = KBs / KCH;
   const size_t tstride = (size_t)KB * 512;
-  const u16* Wp = g.W + (size_t)nb0 * tstride + lane * 8;
-  const u16* Ag = g.A + (size_t)bz * g.a_zstride + (size_t)mt0 * tstride + lane * 8;
-  float* const outz = g.out_f32 + (size_t)bz * g.o_zstride;
+  const u16* Wp = g.W + (size_t)nb0 * tstride + (size_t)ks * KBs * 512 + lane * 8;
+  const u16* Ag = g.A + (size_t)bz * g.a_zstride + (size_t)mt0 * tstride + (size_t)ks * KBs * 512 + lane * 8;
+  float* const outz = g.out_f32 + (size_t)bz * g.o_zstride + (size_t)ks * g.slab_stride;
 
   f32x4 acc[MTR][2];
 #pragma unroll
@@ -393,13 +411,22 @@ __global__ __launch_bounds__(NWV * 64) void fmt_gemm_wide_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = (nb0 + j) * 16 + q * 4;
-      const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
-      float4 o;
-      o.x = acc[i][j][0] + bb.x;
-      o.y = acc[i][j][1] + bb.y;
-      o.z = acc[i][j][2] + bb.z;
-      o.w = acc[i][j][3] + bb.w;
-      *reinterpret_cast<float4*>(outz + (size_t)row * g.ldo + n) = o;
+      float4 o = float4{acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if constexpr (EPI != EPI_PARTIAL) {
+        const float4 bb = *reinterpret_cast<const float4*>(g.bias + n);
+        o.x += bb.x;
+        o.y += bb.y;
+        o.z += bb.z;
+        o.w += bb.w;
+      }
+      if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) {
+        *reinterpret_cast<float4*>(outz + (size_t)row * g.ldo + n) = o;
+      } else if constexpr (EPI == EPI_T16) {
+        T::store4(g.out16 + (size_t)row * g.ldo16 + n, o.x, o.y, o.z, o.w);
+      } else {
+        static_assert(EPI == EPI_GELU_P16, "epilogue not built for the wide GEMM");
+        T::store4(g.out16 + fmt_pack_off(row, n, g.ldo16), fh_gelu_tanh(o.x), fh_gelu_tanh(o.y), fh_gelu_tanh(o.z), fh_gelu_tanh(o.w));
+      }
     }
   }
 }
