@@ -3,7 +3,8 @@ in its own child process and the results are compared here.
   * FMT: weight touch (FLOAT_FMT_TOUCH), the token-blocked head GEMM (FLOAT_FMT_NO_TOKBLK) and the hoisting of the adaLN
     projection out of the Euler step (FLOAT_FMT_HOIST, FLOAT_FMT_ZGROUP) only change WHERE and WHEN work is done - every output element is produced by the same arithmetic in the same order, so r_d must be bitwise identical.
   * decoder: the fused transposed-conv + blur kernel (FLOAT_DEC_ZBLUR_MIN) filters the same fp16-rounded z values as the separate
-    kernels; the fp32 filter sums are contracted differently (packed fma), so frames agree to ~80 dB, not bitwise."""
+    kernels; the fp32 filter sums are contracted differently (packed fma), so frames agree to ~80 dB, not bitwise.
+  * decoder grid order (FLOAT_DEC_CB_ORDER): bitwise; large-tile chain GEMMs for stacked clips (FLOAT_FMT_BIG_ROWS): fp16 rounding."""
 import os
 import subprocess
 import sys
@@ -30,6 +31,14 @@ if what == "fmt":
     r3 = fmt.sample(cond["r_s"], cond["wa"], cond["we"], noise, 6, 2.0, 1.0, 1.0).cpu()
     r4 = fmt.sample(cond["r_s"], cond["wa"], cond["we"], noise, 6, 2.0, 1.5, 1.0, include_r_cfg=True).cpu()
     torch.save({"r3": r3, "r4": r4}, out)
+elif what == "fmtbatch":
+    cfg = pkg.config.FmtConfig()
+    sd = pkg.weights.synth_fmt_state(cfg, seed=3)
+    fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", "fp16", max_batch=2)
+    cs = [pkg.pipeline.synth_conditions(cfg, 75, seed=q, device="cuda:0") for q in range(2)]
+    cat = lambda k: torch.cat([c[k] for c in cs])
+    noise = pkg.fmt.draw_noise(2, 2, cfg, 15).cuda()
+    torch.save({"r": fmt.sample(cat("r_s"), cat("wa"), cat("we"), noise, 6, 2.0, 1.0, 1.0).cpu()}, out)
 else:
     sd = pkg.weights.synth_decoder_state(512, seed=1)
     dec = pkg.decoder.SynthesisHIP(sd, 512, 512, "cuda:0", "fp16", max_frames=4)
@@ -89,3 +98,24 @@ def test_fused_upsample_matches_separate_kernels(tmp_path):
         d = (got - sep).abs()
         psnr = float(-10 * torch.log10(((got - sep) ** 2).mean()))
         assert psnr > 72.0 and float(d.mean()) < 2e-4 and float(d.max()) < 0.05, (psnr, float(d.mean()), float(d.max()))
+
+
+def test_channel_block_order_is_bitwise_neutral(tmp_path):
+    """dec_group_cb (the output-channel blocks of a tile as consecutive slots of one XCD) against the round-1 order (grid.y):
+    which workgroup computes a tile does not change a single operation."""
+    new = run_child(tmp_path, "dec", "cbnew", {})["frames"]
+    old = run_child(tmp_path, "dec", "cbold", {"FLOAT_DEC_CB_ORDER": "0"})["frames"]
+    assert torch.equal(new, old)
+
+
+def test_large_tile_chain_for_stacked_clips(tmp_path):
+    """FLOAT_FMT_BIG_ROWS (off by default: slower): the chain's GEMMs of two stacked clips (360 rows) on the LDS-staged 96-/192-row
+    tile with split-K slabs for proj as well.  Other summation order than the 48 x 64 tiling (no K split across waves, proj through
+    slabs), so the samples agree to fp16 rounding propagated through 2 x 5 evaluations, not bitwise."""
+    base = run_child(tmp_path, "fmtbatch", "small", {})["r"]
+    for plan in ("6,1 6,4", "12,1 12,2"):
+        qf, pf = plan.split()
+        big = run_child(tmp_path, "fmtbatch", "big" + qf[:2].strip(","), {"FLOAT_FMT_BIG_ROWS": "320", "FLOAT_FMT_BIG_QKV": qf,
+                        "FLOAT_FMT_BIG_FC1": qf, "FLOAT_FMT_BIG_PROJ": pf, "FLOAT_FMT_BIG_FC2": pf})["r"]
+        e = float((big - base).norm() / base.norm())
+        assert torch.isfinite(big).all() and 0.0 < e < 2e-3, (plan, e)

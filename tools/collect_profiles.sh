@@ -3,7 +3,7 @@
 #   sh tools/collect_profiles.sh r02_prof r02
 set -e
 S=gpurun_out/$1; P=profiles/$2
-cp $S/bench.json ${P}_bench.json
+if [ -s $S/bench_final.json ]; then cp $S/bench_final.json ${P}_bench.json; else cp $S/bench.json ${P}_bench.json; fi
 cp $S/stats/bench_kernel_stats.csv ${P}_bench_kernel_stats.csv
 cp $S/pmc_mfma.json ${P}_pmc_mfma.json
 cp $S/pmc_traffic.json ${P}_pmc_traffic.json

@@ -14,4 +14,8 @@ for w in fmt dec; do
 done
 python tools/make_mfma_json.py $O/pmc_sq_fmt,$O/pmc_sq_dec $O/pmc_mfma.json
 python tools/make_traffic_json.py $O/pmc_FETCH_SIZE_fmt,$O/pmc_FETCH_SIZE_dec $O/pmc_WRITE_SIZE_fmt,$O/pmc_WRITE_SIZE_dec $O/pmc_traffic.json
+# the bench line that goes to profiles/: run with THIS round's counter files in place, so its counter-derived fields are live
+P=profiles/${2:-r02}
+cp $O/pmc_mfma.json ${P}_pmc_mfma.json; cp $O/pmc_traffic.json ${P}_pmc_traffic.json
+python bench.py > $O/bench_final.json 2> $O/bench_final.err; cut -c1-300 $O/bench_final.json
 du -sh $O
