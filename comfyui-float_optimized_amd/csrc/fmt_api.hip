@@ -125,7 +125,7 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
 }
 
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
-int g_fmt_wide_variant = 2;  // FLOAT_FMT_WIDE_VARIANT: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2 (measured best: all 180 rows in one workgroup, weights read once), 3 = 192 x 4
+int g_fmt_wide_variant = 6;  // FLOAT_FMT_WIDE_VARIANT: 6 = LDS-DMA 192 x 320 tile where the shape allows (else 2); register-staged 192 x 128 family: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2, 3 = 192 x 4, 4 / 5 = 8 waves
 template <class T, int MTW, int KCH, int NWV = 4, int EPI = EPI_F32>
 int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   constexpr int smem = 2 * MTW * KCH * 1024;
@@ -146,10 +146,35 @@ int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
+// 192 x 320 tiles with both operands by LDS-DMA (fmt_gemm_dma_kernel): 8 waves, ring of 4 stages, one workgroup per CU; N in
+// blocks of 320 columns and an even number (>= 4) of k-blocks.  FLOAT_FMT_WIDE_VARIANT = 6 (the default); measured per launch of
+// the hoisted projection (50 x 180 rows): 1150 us against 1376 for the register-staged 192 x 128 tile (variant 2), bitwise the
+// same numbers.  The 4-wave / 160-column / ring-of-3 form (two workgroups per CU) took 1458, spreading the fragment reads
+// between the MFMA rows 1172, a staggered start of the first workgroup generation and non-temporal stores changed nothing.
+template <class T, int NWC, int NS>
+int launch_dma_t(GemmArgs g, bool prime, hipStream_t s) {
+  constexpr int smem = NS * (12 + 5 * NWC) * 1024, BN = 80 * NWC;
+  auto kern = fmt_gemm_dma_kernel<T, NWC, NS>;
+  if (prime) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      (void)hipGetLastError();
+    return FLOAT_OK;
+  }
+  g.mblk = ((g.M + 15) / 16 + 11) / 12;
+  const dim3 grid((g.N / BN) * g.mblk * (g.zcount > 1 ? g.zcount : 1));
+  hipEvent_t e0, e1;
+  if (fh_prof_pair(2, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(NWC * 128), smem, s, e0, e1, 0, g);
+  else hipLaunchKernelGGL(kern, grid, dim3(NWC * 128), smem, s, g);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+bool dma_shape_ok(const GemmArgs& g, int bn) { return g.N % bn == 0 && g.K % 64 == 0 && g.K >= 128; }
+
 template <class T>
 int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
   const int mt = (g.M + 15) / 16;
   if (prime) {
+    (void)launch_dma_t<T, 4, 4>(g, true, s);
     (void)launch_wide_t<T, 4, 4>(g, true, s);
     (void)launch_wide_t<T, 5, 4>(g, true, s);
     (void)launch_wide_t<T, 6, 4>(g, true, s);
@@ -160,12 +185,14 @@ int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
     (void)launch_wide_t<T, 12, 4, 8>(g, true, s);
     return FLOAT_OK;
   }
+  if (g_fmt_wide_variant == 6 && mt > 4 && dma_shape_ok(g, 320)) return launch_dma_t<T, 4, 4>(g, false, s);
   if (mt <= 4) return launch_wide_t<T, 4, 4>(g, false, s);
   // 192-row blocks also for the stacked clips of a batch (mt > 12): the last block reads up to 11 row tiles past the batch (the
   // operand buffers are padded for it, the rows are never stored); 80-row blocks ran the batched projection at 240 TFLOP/s
   // against 700 for 192-row ones
-  if (mt <= 12 || g_fmt_wide_variant == 2 || g_fmt_wide_variant >= 4) {
-    switch (g_fmt_wide_variant) {
+  const int variant = g_fmt_wide_variant == 6 ? 2 : g_fmt_wide_variant;  // shapes the LDS-DMA tile does not take
+  if (mt <= 12 || variant == 2 || variant >= 4) {
+    switch (variant) {
       case 1: return launch_wide_t<T, 6, 2>(g, false, s);
       case 2: return launch_wide_t<T, 12, 2>(g, false, s);
       case 3: return launch_wide_t<T, 12, 4>(g, false, s);

@@ -431,6 +431,181 @@ __global__ __launch_bounds__(NWV * 64) void fmt_gemm_wide_kernel(GemmArgs g) {
   }
 }
 
+// The hoisted adaLN projection on a 192 x 320 tile, 8 waves, both operands by LDS-DMA (fmt_gemm_dma_kernel).
+// fmt_gemm_wide_kernel above tops out near 680 TFLOP/s: four waves with 2 column tiles each read one LDS fragment per two
+// MFMAs (LDS-read-bound), stage through registers, and need 2-3 co-resident workgroups to hide their own barriers.  Here:
+//   * the tile is 12 row tiles x 20 column tiles (51 200 = 160 x 320), waves laid out 2 x 4, each 6 x 5 tiles: 11 fragment
+//     reads per 30 MFMAs; 12 + 20 = 32 fragments of 1 KiB per k-block, i.e. exactly 4 LDS-DMA instructions per wave and stage
+//     (the fragment-major HBM images are lane-linear, so the LDS image needs no swizzle and every ds_read_b128 is conflict-free);
+//   * a ring of 4 stages (128 KiB), three k-blocks in flight behind a COUNTED vmcnt and ONE raw s_barrier per k-block; the
+//     fragments of k-block s+1 are read into a second register set while the MFMAs of k-block s run (LDS reads by inline asm:
+//     hipcc would otherwise drain the DMA queue before every ds_read).
+// Hazards: stage s+4 overwrites the buffer of stage s, whose fragments every wave has in registers (lgkmcnt(0)) before it
+// arrives at the barrier of step s; a stage is read one barrier after the wait that retires this wave's share of it.
+template <int OFF>
+__device__ __forceinline__ u32x4 fh_ds_read128(unsigned addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void fh_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <class T, int NWC /* wave columns: 4 -> 8 waves, 320-column tile (2 -> 4 waves, 160 columns) */, int NS /* ring stages */>
+__global__ __launch_bounds__(NWC * 128) void fmt_gemm_dma_kernel(GemmArgs g) {
+  constexpr int RT = 12, CT = 5 * NWC, NF = RT + CT, NW = 2 * NWC, STAGE = NF * 1024;
+  constexpr int IMAX = (NF + NW - 1) / NW, ILO = NF / NW, NHI = NF % NW;  // DMA instructions per wave and stage: IMAX for waves < NHI
+  static_assert(NS >= 3 && NS <= 4, "ring of 3 or 4 stages");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];  // [NS][NF fragments][1 KiB]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, wr = w / NWC, wc = w % NWC;
+  const int r16 = lane & 15, q = lane >> 4;
+  const int nbx = g.N / (CT * 16);
+  int bx, by, bz;
+  {
+    // same walk as fmt_gemm_wide_kernel: an XCD (ids congruent mod 8) takes groups of `zgroup` column blocks, the step slowest
+    const int id = blockIdx.x, nz = g.zcount > 1 ? g.zcount : 1;
+    if ((nbx & 7) == 0 && g.zgroup > 1) {
+      const int slot = id >> 3, G = g.zgroup, ncx = nbx >> 3, rows = g.mblk * nz;
+      const int full = ncx / G, per_grp = G * rows;
+      int grp = slot / per_grp, rem = slot - grp * per_grp, gw = G;
+      if (grp >= full) {
+        grp = full;
+        rem = slot - full * per_grp;
+        gw = ncx - full * G;
+      }
+      const int zy = rem / gw;
+      bz = zy / g.mblk;
+      by = zy - bz * g.mblk;
+      bx = (grp * G + (rem - zy * gw)) * 8 + (id & 7);
+    } else {
+      bx = id % nbx;
+      const int zy = id / nbx;
+      bz = zy / g.mblk;
+      by = zy - bz * g.mblk;
+    }
+  }
+  const int KB = g.K >> 5;
+  const size_t tstride = (size_t)KB * 512;
+  // this wave's fragments of a stage: fi = w + NW * i; fi < 12: row tile fi of A, else column tile fi - 12 of W
+  const u16* src[IMAX];
+#pragma unroll
+  for (int i = 0; i < IMAX; ++i) {
+    const int fi = min(w + NW * i, NF - 1);
+    src[i] = (fi < RT ? g.A + (size_t)bz * g.a_zstride + (size_t)(by * RT + fi) * tstride
+                      : g.W + (size_t)(bx * CT + fi - RT) * tstride) + lane * 8;
+  }
+  auto issue = [&](int s) {
+    unsigned char* dst = ring + (s % NS) * STAGE + w * 1024;
+#pragma unroll
+    for (int i = 0; i < IMAX; ++i)
+      if (i < ILO || w < NHI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)s * 512),
+                                         (__attribute__((address_space(3))) void*)(dst + i * NW * 1024), 16, 0, 0);
+  };
+  // wait until at most K of this wave's stages are still in flight (waves < NHI issue one more instruction per stage)
+#define DMA_WAIT(K)                                   \
+  do {                                                \
+    if (NHI == 0 || w < NHI) fh_wait_vmcnt<(K)*IMAX>(); \
+    else fh_wait_vmcnt<(K)*ILO>();                    \
+  } while (0)
+  const unsigned abase = (unsigned)(lane * 16 + wr * 6 * 1024), bbase = (unsigned)(lane * 16 + (RT + wc * 5) * 1024);
+
+  f32x4 acc[6][5];
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  u32x4 a0[6], b0[5], a1[6], b1[5];
+
+#define DMA_READ(S, AR, BR)                                        \
+  do {                                                             \
+    const unsigned so = (unsigned)(((S) % NS) * STAGE);            \
+    AR[0] = fh_ds_read128<0>(abase + so);                          \
+    AR[1] = fh_ds_read128<1024>(abase + so);                       \
+    AR[2] = fh_ds_read128<2048>(abase + so);                       \
+    AR[3] = fh_ds_read128<3072>(abase + so);                       \
+    AR[4] = fh_ds_read128<4096>(abase + so);                       \
+    AR[5] = fh_ds_read128<5120>(abase + so);                       \
+    BR[0] = fh_ds_read128<0>(bbase + so);                          \
+    BR[1] = fh_ds_read128<1024>(bbase + so);                       \
+    BR[2] = fh_ds_read128<2048>(bbase + so);                       \
+    BR[3] = fh_ds_read128<3072>(bbase + so);                       \
+    BR[4] = fh_ds_read128<4096>(bbase + so);                       \
+  } while (0)
+  // step s: stage s+1 has landed everywhere after the barrier; stage s+NS goes into the buffer of stage s, whose fragments every
+  // wave holds in registers since before it arrived at this barrier; the reads of s+1 fly under the MFMAs of s
+#define DMA_STEP(S, AC, BC, AN, BN)                                                            \
+  do {                                                                                         \
+    const int s_ = (S);                                                                        \
+    if (s_ + 1 < KB) {                                                                         \
+      const int rem = KB - 2 - s_; /* stages issued beyond s+1 */                              \
+      if (NS == 4 && rem >= 2) DMA_WAIT(2);                                                    \
+      else if (rem >= 1) DMA_WAIT(1);                                                          \
+      else DMA_WAIT(0);                                                                        \
+    }                                                                                          \
+    __builtin_amdgcn_s_barrier();                                                              \
+    if (s_ + NS < KB) issue(s_ + NS);                                                          \
+    if (s_ + 1 < KB) DMA_READ(s_ + 1, AN, BN);                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                              \
+      _Pragma("unroll") for (int j = 0; j < 5; ++j) acc[i][j] = T::mfma(BC[j], AC[i], acc[i][j]); \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+
+#pragma unroll
+  for (int s = 0; s < NS; ++s) issue(s);
+  DMA_WAIT(NS - 1);
+  __builtin_amdgcn_s_barrier();
+  DMA_READ(0, a0, b0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  for (int s = 0; s < KB; s += 2) {
+    DMA_STEP(s, a0, b0, a1, b1);
+    DMA_STEP(s + 1, a1, b1, a0, b0);
+  }
+#undef DMA_STEP
+#undef DMA_READ
+#undef DMA_WAIT
+  // D[n = q*4 + reg][m = r16]: lane -> one row, 4 consecutive columns per (i, j)
+  float* const outz = g.out_f32 + (size_t)bz * g.o_zstride;
+  // Through LDS (the ring is idle: nobody reads it after the barrier of the last step), 96 rows per pass, so that a store
+  // instruction writes 1 KiB of one output row - 8 whole lines - instead of 16 half lines 205 KB apart (straight from the
+  // accumulators the launch took 1260 us instead of 1150).  Row stride OW + 4
+  // floats: the 16 rows of a lane group then fall on the 16 different 16-byte bank slots.
+  constexpr int OW = CT * 16, OSTR = OW + 4, C4 = OW / 4, NTHR = NW * 64;
+  static_assert(96 * OSTR * 4 <= NS * STAGE, "output staging does not fit the ring");
+  float* const so = reinterpret_cast<float*>(ring);
+  float4 bb[5];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) bb[j] = *reinterpret_cast<const float4*>(g.bias + (bx * CT + wc * 5 + j) * 16 + q * 4);
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    if (wr == p) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+          *reinterpret_cast<float4*>(so + (i * 16 + r16) * OSTR + (wc * 5 + j) * 16 + q * 4) =
+              float4{acc[i][j][0] + bb[j].x, acc[i][j][1] + bb[j].y, acc[i][j][2] + bb[j].z, acc[i][j][3] + bb[j].w};
+    }
+    __syncthreads();
+    {
+#pragma unroll
+      for (int k = 0; k < (96 * C4) / NTHR; ++k) {
+        const int idx = k * NTHR + threadIdx.x, rl = idx / C4, c4 = idx - rl * C4;
+        const int row = by * (RT * 16) + p * 96 + rl;
+        if (row < g.M)
+          *reinterpret_cast<float4*>(outz + (size_t)row * g.ldo + bx * OW + c4 * 4) = *reinterpret_cast<const float4*>(so + rl * OSTR + c4 * 4);
+      }
+    }
+    if (p == 0) __syncthreads();
+  }
+}
+
 // LayerNorm (no affine, biased variance, eps 1e-6) + framewise modulate, one wave per token row
 // (FMT.py:157,168-169,174-175,197).  out = T( (x-mu)*rstd * (1 + scale[row]) + shift[row] ), written in
 // the packed A-operand order of the consuming GEMM (K = D).

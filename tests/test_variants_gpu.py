@@ -67,12 +67,15 @@ def test_fmt_touch_and_token_blocked_head_are_bitwise_neutral(tmp_path):
     # kernel on the same operands; and other XCD groupings of the batched launch
     per_step = run_child(tmp_path, "fmt", "perstep", {"FLOAT_FMT_HOIST": "0"})
     grouped = run_child(tmp_path, "fmt", "zgroup", {"FLOAT_FMT_ZGROUP": "3"})
+    # the register-staged 192 x 128 tile instead of the LDS-DMA 192 x 320 one: same k order, one accumulator per output
+    regstage = run_child(tmp_path, "fmt", "wide2", {"FLOAT_FMT_WIDE_VARIANT": "2"})
     for k in ("r3", "r4"):
         assert torch.isfinite(base[k]).all()
         assert torch.equal(base[k], tuned[k]), k
         assert torch.equal(base[k], every[k]), k
         assert torch.equal(base[k], per_step[k]), k
         assert torch.equal(base[k], grouped[k]), k
+        assert torch.equal(base[k], regstage[k]), k
 
 
 def test_conv2_flow_fusion_matches_the_separate_launches(tmp_path):

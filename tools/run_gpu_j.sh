@@ -1,5 +1,3 @@
 #!/bin/sh
-python tools/probes/overlap_probe.py 2>&1 | grep "fmt "
-FLOAT_DEC_TPW=64 FLOAT_DEC_FLOW_WGS=256 python tools/probes/overlap_probe.py 2>&1 | grep "fmt "
-FLOAT_DEC_TPW=256 FLOAT_DEC_FLOW_WGS=128 python tools/probes/overlap_probe.py 2>&1 | grep "fmt "
-FLOAT_DEC_TPW=256 FLOAT_DEC_FLOW_WGS=128 FLOAT_DEC_ZBLUR_MIN=4096 python tools/probes/overlap_probe.py 2>&1 | grep "fmt "
+python -m pytest tests/test_variants_gpu.py tests/test_fmt_gpu.py tests/test_edge_cases_gpu.py tests/test_configs_gpu.py -x -q -m gpu 2>&1 | tail -4
+for v in 2 6; do FLOAT_FMT_WIDE_VARIANT=$v BATCHES=1,2,4 python tools/probes/fmtbatch.py 2>&1 | grep "B="; done
