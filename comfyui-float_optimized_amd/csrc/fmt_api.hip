@@ -125,7 +125,7 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
 }
 
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
-int g_fmt_wide_variant = 6;  // FLOAT_FMT_WIDE_VARIANT: 6 = LDS-DMA 192 x 320 tile where the shape allows (else 2); register-staged 192 x 128 family: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2, 3 = 192 x 4, 4 / 5 = 8 waves
+int g_fmt_wide_variant = 7;  // FLOAT_FMT_WIDE_VARIANT: 6 / 7 = LDS-DMA 192 x 320 tile where the shape allows (else 2): lock step / wave rows half a step apart; register-staged 192 x 128 family: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2, 3 = 192 x 4, 4 / 5 = 8 waves
 template <class T, int MTW, int KCH, int NWV = 4, int EPI = EPI_F32>
 int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   constexpr int smem = 2 * MTW * KCH * 1024;
@@ -147,14 +147,21 @@ int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   return FLOAT_OK;
 }
 // 192 x 320 tiles with both operands by LDS-DMA (fmt_gemm_dma_kernel): 8 waves, ring of 4 stages, one workgroup per CU; N in
-// blocks of 320 columns and an even number (>= 4) of k-blocks.  FLOAT_FMT_WIDE_VARIANT = 6 (the default); measured per launch of
-// the hoisted projection (50 x 180 rows): 1150 us against 1376 for the register-staged 192 x 128 tile (variant 2), bitwise the
-// same numbers.  The 4-wave / 160-column / ring-of-3 form (two workgroups per CU) took 1458, spreading the fragment reads
-// between the MFMA rows 1172, a staggered start of the first workgroup generation and non-temporal stores changed nothing.
-template <class T, int NWC, int NS>
+// blocks of 320 columns and an even number (>= 4) of k-blocks.  Measured per launch of the hoisted projection (50 x 180 rows,
+// 0.944 TFLOP), rocprofv3, bitwise the same numbers in every form:
+//   register-staged 192 x 128 tile (variant 2)                                   1376 us  (686 TFLOP/s)
+//   LDS-DMA tile, waves in lock step, stores straight from the accumulators      1260
+//   + output through LDS (whole lines per store)                                 1150
+//   + 2 column blocks per XCD group instead of 4 (FLOAT_FMT_ZGROUP)              1045     (variant 6)
+//   + wave rows half a step apart (variant 7, the default)                       1021     (924 TFLOP/s, 37 % of the MFMA peak)
+//   the same with the DMA pieces issued between the MFMA rows                    1115
+// Not faster: 4 waves / 160 columns / ring of 3 with two workgroups per CU (1458), fragment reads spread between the MFMA rows
+// (1172), a staggered start of the first workgroup generation, non-temporal stores.  In-kernel clocks (s_memtime /
+// s_memrealtime) put a 32-step tile at ~49 000 clocks at 2.1 GHz, of which the bare barrier skeleton is a third.
+template <class T, int NWC, int NS, int STG>
 int launch_dma_t(GemmArgs g, bool prime, hipStream_t s) {
   constexpr int smem = NS * (12 + 5 * NWC) * 1024, BN = 80 * NWC;
-  auto kern = fmt_gemm_dma_kernel<T, NWC, NS>;
+  auto kern = fmt_gemm_dma_kernel<T, NWC, NS, STG>;
   if (prime) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       (void)hipGetLastError();
@@ -174,7 +181,8 @@ template <class T>
 int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
   const int mt = (g.M + 15) / 16;
   if (prime) {
-    (void)launch_dma_t<T, 4, 4>(g, true, s);
+    (void)launch_dma_t<T, 4, 4, 0>(g, true, s);
+    (void)launch_dma_t<T, 4, 4, 1>(g, true, s);
     (void)launch_wide_t<T, 4, 4>(g, true, s);
     (void)launch_wide_t<T, 5, 4>(g, true, s);
     (void)launch_wide_t<T, 6, 4>(g, true, s);
@@ -185,12 +193,13 @@ int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
     (void)launch_wide_t<T, 12, 4, 8>(g, true, s);
     return FLOAT_OK;
   }
-  if (g_fmt_wide_variant == 6 && mt > 4 && dma_shape_ok(g, 320)) return launch_dma_t<T, 4, 4>(g, false, s);
+  if (g_fmt_wide_variant == 6 && mt > 4 && dma_shape_ok(g, 320)) return launch_dma_t<T, 4, 4, 0>(g, false, s);
+  if (g_fmt_wide_variant == 7 && mt > 4 && dma_shape_ok(g, 320)) return launch_dma_t<T, 4, 4, 1>(g, false, s);
   if (mt <= 4) return launch_wide_t<T, 4, 4>(g, false, s);
   // 192-row blocks also for the stacked clips of a batch (mt > 12): the last block reads up to 11 row tiles past the batch (the
   // operand buffers are padded for it, the rows are never stored); 80-row blocks ran the batched projection at 240 TFLOP/s
   // against 700 for 192-row ones
-  const int variant = g_fmt_wide_variant == 6 ? 2 : g_fmt_wide_variant;  // shapes the LDS-DMA tile does not take
+  const int variant = (g_fmt_wide_variant == 6 || g_fmt_wide_variant == 7) ? 2 : g_fmt_wide_variant;  // shapes the LDS-DMA tile does not take
   if (mt <= 12 || variant == 2 || variant >= 4) {
     switch (variant) {
       case 1: return launch_wide_t<T, 6, 2>(g, false, s);
@@ -577,7 +586,7 @@ void launch_attn(float_fmt* h, int M, const Lin* pull, hipStream_t s) {
 // (bitwise the same numbers; the A/B switch of the measurement).
 constexpr int kScSteps = 64;  // evaluations per modulation batch; longer grids run in batches of this many
 int g_fmt_hoist = 1;
-int g_fmt_zgroup = 4;  // FLOAT_FMT_ZGROUP: column blocks of an XCD that share activation tiles through L2 (fmt_gemm_wide_kernel)
+int g_fmt_zgroup = 0;  // FLOAT_FMT_ZGROUP: column blocks of an XCD that share activation tiles through L2; 0 = per kernel: 4 (fmt_gemm_wide_kernel), 2 (fmt_gemm_dma_kernel)
 
 template <class T>
 int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
@@ -589,7 +598,8 @@ int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
   g.out_f32 = h->modall;
   g.ldo = h->Ntot;
   g.zcount = n;
-  g.zgroup = g_fmt_zgroup;
+  const bool dma = (g_fmt_wide_variant == 6 || g_fmt_wide_variant == 7) && (M + 15) / 16 > 4 && dma_shape_ok(g, 320);
+  g.zgroup = g_fmt_zgroup > 0 ? g_fmt_zgroup : (dma ? 2 : 4);
   g.a_zstride = (size_t)h->Mpad * D;
   g.o_zstride = (size_t)h->Mmod * h->Ntot;
   if constexpr (!T::is32) {
@@ -1169,7 +1179,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_HOIST")) g_fmt_hoist = atoi(v) != 0;
-  if (const char* v = getenv("FLOAT_FMT_ZGROUP")) g_fmt_zgroup = std::max(1, atoi(v));
+  if (const char* v = getenv("FLOAT_FMT_ZGROUP")) g_fmt_zgroup = std::max(0, atoi(v));
   if (const char* v = getenv("FLOAT_FMT_BIG_ROWS")) g_fmt_big_rows = atoi(v);
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
     sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],

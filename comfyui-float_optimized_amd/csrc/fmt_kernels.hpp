@@ -453,7 +453,8 @@ __device__ __forceinline__ void fh_wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <class T, int NWC /* wave columns: 4 -> 8 waves, 320-column tile (2 -> 4 waves, 160 columns) */, int NS /* ring stages */>
+template <class T, int NWC /* wave columns: 4 -> 8 waves, 320-column tile (2 -> 4 waves, 160 columns) */, int NS /* ring stages */,
+          int STG /* 1: the two wave rows run half a step apart (see DMA_STEP_STG) */>
 __global__ __launch_bounds__(NWC * 128) void fmt_gemm_dma_kernel(GemmArgs g) {
   constexpr int RT = 12, CT = 5 * NWC, NF = RT + CT, NW = 2 * NWC, STAGE = NF * 1024;
   constexpr int IMAX = (NF + NW - 1) / NW, ILO = NF / NW, NHI = NF % NW;  // DMA instructions per wave and stage: IMAX for waves < NHI
@@ -556,17 +557,73 @@ __global__ __launch_bounds__(NWC * 128) void fmt_gemm_dma_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);                                                         \
   } while (0)
 
+  // Staggered form (STG = 1; 1021 vs 1045 us per launch of the hoisted projection).  In lock step all 8 waves read fragments at
+  // the same time and multiply at the same time, and ablation builds showed the LDS time and the MFMA time of a step adding up
+  // rather than overlapping.  Here the wave rows run half a step apart: a step is [barrier A | DMA issue + fragment reads of s+1, waited for |
+  // barrier B | MFMAs of s], and row 1 executes one extra barrier first - while row 0 multiplies, row 1 (the other wave of
+  // each SIMD) reads, and vice versa.  Row 0 reads stage s+1 one barrier before row 1 does, so a wave of row 0 waits for its
+  // share of stage s+1 before its barrier A, a wave of row 1 for its share of stage s+2 before its barrier B (the same global
+  // barrier).  Stage s+NS is issued after both rows have read stage s.  Row 0 runs one extra barrier at the end: every wave
+  // executes 2 KB + 2 barriers.
+#define DMA_WAIT_UPTO(K)                      \
+  do {                                        \
+    const int k_ = (K);                       \
+    if (NS == 4 && k_ >= 2) DMA_WAIT(2);      \
+    else if (k_ >= 1) DMA_WAIT(1);            \
+    else DMA_WAIT(0);                         \
+  } while (0)
+#define DMA_STEP_STG(S, AC, BC, AN, BN)                                                        \
+  do {                                                                                         \
+    const int s_ = (S);                                                                        \
+    if (!g1 && s_ + 1 < KB) DMA_WAIT_UPTO(KB - 2 - s_);                                        \
+    __builtin_amdgcn_s_barrier();                                                              \
+    if (s_ + NS < KB) issue(s_ + NS);                                                          \
+    if (s_ + 1 < KB) DMA_READ(s_ + 1, AN, BN);                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    if (g1 && s_ + 2 < KB) {                                                                   \
+      DMA_WAIT_UPTO(KB - 3 - s_);                                                              \
+    }                                                                                          \
+    __builtin_amdgcn_s_barrier();                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+    _Pragma("unroll") for (int i = 0; i < 6; ++i)                                              \
+      _Pragma("unroll") for (int j = 0; j < 5; ++j) acc[i][j] = T::mfma(BC[j], AC[i], acc[i][j]); \
+    __builtin_amdgcn_sched_barrier(0);                                                         \
+  } while (0)
+
+  const bool g1 = wr == 1;
+#ifdef DMA_CLK
+  const unsigned long long c0 = clock64(), w0 = wall_clock64();
+#endif
 #pragma unroll
   for (int s = 0; s < NS; ++s) issue(s);
-  DMA_WAIT(NS - 1);
+  if constexpr (STG) DMA_WAIT(NS - 2);  // stages 0 and 1: row 0 reads stage 1 right after the first barrier of the loop
+  else DMA_WAIT(NS - 1);
   __builtin_amdgcn_s_barrier();
   DMA_READ(0, a0, b0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
-  for (int s = 0; s < KB; s += 2) {
-    DMA_STEP(s, a0, b0, a1, b1);
-    DMA_STEP(s + 1, a1, b1, a0, b0);
+  if constexpr (STG) {
+    if (g1) __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < KB; s += 2) {
+      DMA_STEP_STG(s, a0, b0, a1, b1);
+      DMA_STEP_STG(s + 1, a1, b1, a0, b0);
+    }
+    if (!g1) __builtin_amdgcn_s_barrier();
+  } else {
+    for (int s = 0; s < KB; s += 2) {
+      DMA_STEP(s, a0, b0, a1, b1);
+      DMA_STEP(s + 1, a1, b1, a0, b0);
+    }
   }
+#ifdef DMA_CLK
+  if ((blockIdx.x == 3000 || blockIdx.x == 6001) && threadIdx.x == 0) {
+    const unsigned long long c1 = clock64(), w1 = wall_clock64();
+    printf("tile loop: %llu core clocks, %llu wall ticks\n", c1 - c0, w1 - w0);
+  }
+#endif
+#undef DMA_STEP_STG
+#undef DMA_WAIT_UPTO
 #undef DMA_STEP
 #undef DMA_READ
 #undef DMA_WAIT
