@@ -38,8 +38,41 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 
+// Write-through (sc1) stores for what a kernel of the FMT step chain hands to the next launch.  A kernel ends with an
+// agent-scope release that writes its dirty L2 lines back before the next dispatch may start; lines stored write-through are
+// already on their way while the kernel still runs.  Relaxed agent-scope atomic stores are how HIP spells "store with sc1"
+// (8 bytes at most per instruction).  Which store sites gain was measured by swapping libraries on one box, ms per 250
+// evaluations (results bitwise the same): none 82.4-82.8; LayerNorm (1) 81.0-81.5; + attention (2) 81.0-81.3; + the 16-bit GEMM
+// epilogues (8: qkv, fc1) 80.0-80.2 - the default, FMT_WT = 11; the fp32 epilogues do NOT gain: split-K slabs (4) 83.5-86.1,
+// gate * residual (16) and x-embed (32) neutral; a 16-byte `global_store_dwordx4 ... sc1` by inline asm instead of two
+// 8-byte stores 80.7-81.0.
+#ifndef FMT_WT
+#define FMT_WT 11  // bit mask of the store sites that write through: 1 LayerNorm, 2 attention, 4 / 16 / 32 fp32 GEMM epilogues (slabs / gate * residual / x-embed), 8 16-bit GEMM epilogues
+#endif
+typedef __attribute__((address_space(1))) unsigned long long fh_gu64;
+template <int SITE>
+__device__ __forceinline__ void fh_store8_wt(void* p, unsigned long long v) {
+  if constexpr ((FMT_WT & SITE) != 0) __hip_atomic_store((fh_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else *reinterpret_cast<unsigned long long*>(p) = v;
+}
+template <int SITE>
+__device__ __forceinline__ void fh_store16_wt(void* p, const u32x4& v) {
+  if constexpr ((FMT_WT & SITE) != 0) {
+    fh_store8_wt<SITE>(p, ((unsigned long long)v[1] << 32) | v[0]);
+    fh_store8_wt<SITE>(reinterpret_cast<char*>(p) + 8, ((unsigned long long)v[3] << 32) | v[2]);
+  } else {
+    *reinterpret_cast<u32x4*>(p) = v;
+  }
+}
+template <int SITE>
+__device__ __forceinline__ void fh_store_f4_wt(float* p, const float4& v) {
+  if constexpr ((FMT_WT & SITE) != 0)
+    fh_store16_wt<SITE>(p, u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
+  else *reinterpret_cast<float4*>(p) = v;
+}
+
 // Every operand type T gives: elem (storage element), pack8 (8 consecutive elements = one lane's share of an MFMA fragment
-// and the unit of the packed epilogue stores), load8 / load8_nt / store8 / store4, get / set of one element as float, mfma.
+// and the unit of the packed epilogue stores), load8 / load8_nt / store8 / store4 (+ _wt forms), get / set of one element as float, mfma.
 #define FH_PACK16_HELPERS                                                                                                   \
   typedef u16 elem;                                                                                                         \
   typedef u32x4 pack8;                                                                                                      \
@@ -58,6 +91,15 @@ typedef unsigned short u16;
     o.z = from_float(c);                                                                                                    \
     o.w = from_float(d);                                                                                                    \
     *reinterpret_cast<ushort4*>(p) = o;                                                                                     \
+  }                                                                                                                         \
+  template <int SITE>                                                                                                       \
+  static __device__ __forceinline__ void store8_wt(elem* p, const pack8& v) { fh_store16_wt<SITE>(p, v); }                  \
+  template <int SITE>                                                                                                       \
+  static __device__ __forceinline__ void store4_wt(elem* p, float a, float b, float c, float d) {                           \
+    if constexpr ((FMT_WT & SITE) != 0)                                                                                     \
+      fh_store8_wt<SITE>(p, (unsigned long long)from_float(a) | ((unsigned long long)from_float(b) << 16) |                 \
+                                ((unsigned long long)from_float(c) << 32) | ((unsigned long long)from_float(d) << 48));     \
+    else store4(p, a, b, c, d);                                                                                             \
   }
 
 struct BF16 {
@@ -155,6 +197,10 @@ struct FP32 {
   static __device__ __forceinline__ void store4(elem* p, float a, float b, float c, float d) {
     *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
   }
+  template <int SITE>
+  static __device__ __forceinline__ void store8_wt(elem* p, const pack8& v) { store8(p, v); }  // verification mode: plain stores
+  template <int SITE>
+  static __device__ __forceinline__ void store4_wt(elem* p, float a, float b, float c, float d) { store4(p, a, b, c, d); }
   static __device__ __forceinline__ f32x4 mfma(const pack8& a, const pack8& b, f32x4 c) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.lo[j], b.lo[j], c, 0, 0, 0);

@@ -214,8 +214,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
       }
       if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) {
         float* o = g.out_f32 + (size_t)ks * g.slab_stride + (size_t)row * g.ldo + nb;
-        *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
+        fh_store_f4_wt<4>(o, float4{v[0], v[1], v[2], v[3]});
+        fh_store_f4_wt<4>(o + 4, float4{v[4], v[5], v[6], v[7]});
       } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16 || EPI == EPI_GELUERF_P16) {
         P8 u;
 #pragma unroll
@@ -227,8 +227,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
           T::set(u, i, x);
         }
         E* const o16 = reinterpret_cast<E*>(g.out16);
-        if constexpr (EPI == EPI_T16) T::store8(o16 + (size_t)row * g.ldo16 + nb, u);
-        else T::store8(o16 + fmt_pack_off(row, nb, g.ldo16), u);
+        if constexpr (EPI == EPI_T16) T::template store8_wt<8>(o16 + (size_t)row * g.ldo16 + nb, u);
+        else T::template store8_wt<8>(o16 + fmt_pack_off(row, nb, g.ldo16), u);
       } else if constexpr (EPI == EPI_GATE_RES) {
         float* o = g.out_f32 + (size_t)row * g.ldo + nb;
         const float* gt = g.gate + (size_t)row * g.ldg + nb;
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
           x.y += gg.y * v[e + 1];
           x.z += gg.z * v[e + 2];
           x.w += gg.w * v[e + 3];
-          *reinterpret_cast<float4*>(o + e) = x;
+          fh_store_f4_wt<16>(o + e, x);
         }
       } else if constexpr (EPI == EPI_XEMBED) {
         // input row = clip * ntok + token (the CFG rows of a clip share x); output rows (clip * bc + b2) * ntok + token
@@ -256,8 +256,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 8; ++i) v[i] += ps[i];
         for (int b2 = 0; b2 < g.bc; ++b2) {
           float* o = g.out_f32 + (size_t)((q * g.bc + b2) * g.ntok + tok) * g.ldo + nb;
-          *reinterpret_cast<float4*>(o) = float4{v[0], v[1], v[2], v[3]};
-          *reinterpret_cast<float4*>(o + 4) = float4{v[4], v[5], v[6], v[7]};
+          fh_store_f4_wt<32>(o, float4{v[0], v[1], v[2], v[3]});
+          fh_store_f4_wt<32>(o + 4, float4{v[4], v[5], v[6], v[7]});
         }
       }
     }
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
       v[i].y += gt[i].y * (t.y + bi[i].y);
       v[i].z += gt[i].z * (t.z + bi[i].z);
       v[i].w += gt[i].w * (t.w + bi[i].w);
-      *reinterpret_cast<float4*>(xr + i * 256 + lane * 4) = v[i];
+      fh_store_f4_wt<1>(xr + i * 256 + lane * 4, v[i]);
     }
   }
 #pragma unroll
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
-    T::store4(reinterpret_cast<typename T::elem*>(out) + fmt_pack_off(orow, c, D / 32),
+    T::template store4_wt<1>(reinterpret_cast<typename T::elem*>(out) + fmt_pack_off(orow, c, D / 32),
               (v[i].x - mu) * rstd * (1.f + b[i].x) + a[i].x, (v[i].y - mu) * rstd * (1.f + b[i].y) + a[i].y,
               (v[i].z - mu) * rstd * (1.f + b[i].z) + a[i].z, (v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w);
   }
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
     P8 uo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) T::set(uo, j, o[u * 8 + j] * inv);
-    T::store8(reinterpret_cast<E*>(out) + fmt_pack_off(row, d0 + u * 8, D / 32), uo);
+    T::template store8_wt<2>(reinterpret_cast<E*>(out) + fmt_pack_off(row, d0 + u * 8, D / 32), uo);
   }
   if constexpr (TOUCH) fmt_touch_retire(touched);
 }
