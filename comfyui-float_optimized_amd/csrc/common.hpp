@@ -49,25 +49,29 @@ typedef unsigned short u16;
 #ifndef FMT_WT
 #define FMT_WT 11  // bit mask of the store sites that write through: 1 LayerNorm, 2 attention, 4 / 16 / 32 fp32 GEMM epilogues (slabs / gate * residual / x-embed), 8 16-bit GEMM epilogues
 #endif
+// ON: per instantiation.  Stacked clips do not gain (720 rows: 176.0 ms per 250 evaluations with write-through everywhere,
+// 170.9 without: four times the bytes in 8-byte pieces), so only the single-clip forms of the kernels pass ON = true: the
+// LayerNorm / attention launches of at most 256 rows and the GEMM tilings with 8 or 16 K-splitting waves (stacked clips run
+// 4).  A per-launch run-time switch instead cost the whole gain (both store paths in every epilogue: 83.6 vs 80.6 ms).
 typedef __attribute__((address_space(1))) unsigned long long fh_gu64;
-template <int SITE>
+template <int SITE, bool ON>
 __device__ __forceinline__ void fh_store8_wt(void* p, unsigned long long v) {
-  if constexpr ((FMT_WT & SITE) != 0) __hip_atomic_store((fh_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (ON && (FMT_WT & SITE) != 0) __hip_atomic_store((fh_gu64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else *reinterpret_cast<unsigned long long*>(p) = v;
 }
-template <int SITE>
+template <int SITE, bool ON>
 __device__ __forceinline__ void fh_store16_wt(void* p, const u32x4& v) {
-  if constexpr ((FMT_WT & SITE) != 0) {
-    fh_store8_wt<SITE>(p, ((unsigned long long)v[1] << 32) | v[0]);
-    fh_store8_wt<SITE>(reinterpret_cast<char*>(p) + 8, ((unsigned long long)v[3] << 32) | v[2]);
+  if constexpr (ON && (FMT_WT & SITE) != 0) {
+    fh_store8_wt<SITE, true>(p, ((unsigned long long)v[1] << 32) | v[0]);
+    fh_store8_wt<SITE, true>(reinterpret_cast<char*>(p) + 8, ((unsigned long long)v[3] << 32) | v[2]);
   } else {
     *reinterpret_cast<u32x4*>(p) = v;
   }
 }
-template <int SITE>
+template <int SITE, bool ON>
 __device__ __forceinline__ void fh_store_f4_wt(float* p, const float4& v) {
-  if constexpr ((FMT_WT & SITE) != 0)
-    fh_store16_wt<SITE>(p, u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
+  if constexpr (ON && (FMT_WT & SITE) != 0)
+    fh_store16_wt<SITE, true>(p, u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
   else *reinterpret_cast<float4*>(p) = v;
 }
 
@@ -92,13 +96,13 @@ __device__ __forceinline__ void fh_store_f4_wt(float* p, const float4& v) {
     o.w = from_float(d);                                                                                                    \
     *reinterpret_cast<ushort4*>(p) = o;                                                                                     \
   }                                                                                                                         \
-  template <int SITE>                                                                                                       \
-  static __device__ __forceinline__ void store8_wt(elem* p, const pack8& v) { fh_store16_wt<SITE>(p, v); }                  \
-  template <int SITE>                                                                                                       \
+  template <int SITE, bool ON>                                                                                              \
+  static __device__ __forceinline__ void store8_wt(elem* p, const pack8& v) { fh_store16_wt<SITE, ON>(p, v); }              \
+  template <int SITE, bool ON>                                                                                              \
   static __device__ __forceinline__ void store4_wt(elem* p, float a, float b, float c, float d) {                           \
-    if constexpr ((FMT_WT & SITE) != 0)                                                                                     \
-      fh_store8_wt<SITE>(p, (unsigned long long)from_float(a) | ((unsigned long long)from_float(b) << 16) |                 \
-                                ((unsigned long long)from_float(c) << 32) | ((unsigned long long)from_float(d) << 48));     \
+    if constexpr (ON && (FMT_WT & SITE) != 0)                                                                               \
+      fh_store8_wt<SITE, true>(p, (unsigned long long)from_float(a) | ((unsigned long long)from_float(b) << 16) |           \
+                                      ((unsigned long long)from_float(c) << 32) | ((unsigned long long)from_float(d) << 48)); \
     else store4(p, a, b, c, d);                                                                                             \
   }
 
@@ -197,9 +201,9 @@ struct FP32 {
   static __device__ __forceinline__ void store4(elem* p, float a, float b, float c, float d) {
     *reinterpret_cast<f32x4*>(p) = f32x4{a, b, c, d};
   }
-  template <int SITE>
+  template <int SITE, bool ON>
   static __device__ __forceinline__ void store8_wt(elem* p, const pack8& v) { store8(p, v); }  // verification mode: plain stores
-  template <int SITE>
+  template <int SITE, bool ON>
   static __device__ __forceinline__ void store4_wt(elem* p, float a, float b, float c, float d) { store4(p, a, b, c, d); }
   static __device__ __forceinline__ f32x4 mfma(const pack8& a, const pack8& b, f32x4 c) {
 #pragma unroll

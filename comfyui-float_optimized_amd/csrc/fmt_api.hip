@@ -124,6 +124,7 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
   return pack_linear_pool<T>(&h->pool, tt, names, N_each, K, out);
 }
 
+constexpr int kWtRows = 256;  // LayerNorm / attention launches of at most this many rows store write-through (common.hpp, FMT_WT)
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
 int g_fmt_wide_variant = 7;  // FLOAT_FMT_WIDE_VARIANT: 6 / 7 = LDS-DMA 192 x 320 tile where the shape allows (else 2): lock step / wave rows half a step apart; register-staged 192 x 128 family: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2, 3 = 192 x 4, 4 / 5 = 8 waves
 template <class T, int MTW, int KCH, int NWV = 4, int EPI = EPI_F32>
@@ -516,14 +517,17 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   // rpw == 1: the kernel maps ids to rows in groups of 8 rows per XCD -> 64 row slots per group of 64 ids
   dim3 grid(rpw == 1 ? ((M + 63) / 64) * 64 : (M + rpw - 1) / rpw), block(64 * rpw);
   const int ks = pend ? pend->ks : 0;
+  const bool wt = M <= kWtRows;  // write-through outputs for one clip's rows only (common.hpp, FMT_WT)
   LnRed red{};
   if (ks) red = pend->red;
   TouchSpec pf{};
   if (next && (g_fmt_touch & (1 | touch_bit)) && rpw == 1 && !T::is32) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
 #define LN_LAUNCH(NV, KS)                                                                                                          \
   do {                                                                                                                             \
-    if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
-    else hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm);   \
+    if (pf.W && wt) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
+    else if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
+    else if (wt) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
+    else hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm);   \
   } while (0)
 #define LN_CASE(NV)                     \
   case NV:                              \
@@ -563,8 +567,11 @@ void launch_attn(float_fmt* h, int M, const Lin* pull, hipStream_t s) {
   dim3 grid(c.heads, (M + qpw - 1) / qpw), block(qpw * lpq);
   TouchSpec pf{};
   if (pull && !T::is32) pf = make_touch(*pull, M, 0, (grid.x * grid.y / 8) * block.x, 2);
-#define ATTN_LAUNCH(LPQ, TCH) \
-  hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf)
+#define ATTN_LAUNCH(LPQ, TCH)                                                                                                  \
+  do {                                                                                                                         \
+    if (M <= kWtRows) hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH, true>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf); \
+    else hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH, false>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf);             \
+  } while (0)
   if (lpq == 16) {
     if (pf.W) ATTN_LAUNCH(16, true);
     else ATTN_LAUNCH(16, false);

@@ -19,6 +19,7 @@ template <class T, int MTW, int NT, int NW, int EPI>
 __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   constexpr int BN = NT * 16;
   constexpr int ROWS = MTW * 16;
+  constexpr bool WT = NW >= 8;  // the single-clip tilings (stacked clips split K over 4 waves): see common.hpp, FMT_WT
   constexpr int NTHR = NW * 64;
   // k-steps of operands in flight per wave.  With 4 k-blocks per wave (K = 1024 over 8 waves) PF = 4 puts the whole
   // K slice in flight at once: one memory round trip instead of two for the 48x64 tilings (7 fragments per k-step,
@@ -214,8 +215,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
       }
       if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) {
         float* o = g.out_f32 + (size_t)ks * g.slab_stride + (size_t)row * g.ldo + nb;
-        fh_store_f4_wt<4>(o, float4{v[0], v[1], v[2], v[3]});
-        fh_store_f4_wt<4>(o + 4, float4{v[4], v[5], v[6], v[7]});
+        fh_store_f4_wt<4, WT>(o, float4{v[0], v[1], v[2], v[3]});
+        fh_store_f4_wt<4, WT>(o + 4, float4{v[4], v[5], v[6], v[7]});
       } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16 || EPI == EPI_GELUERF_P16) {
         P8 u;
 #pragma unroll
@@ -227,8 +228,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
           T::set(u, i, x);
         }
         E* const o16 = reinterpret_cast<E*>(g.out16);
-        if constexpr (EPI == EPI_T16) T::template store8_wt<8>(o16 + (size_t)row * g.ldo16 + nb, u);
-        else T::template store8_wt<8>(o16 + fmt_pack_off(row, nb, g.ldo16), u);
+        if constexpr (EPI == EPI_T16) T::template store8_wt<8, WT>(o16 + (size_t)row * g.ldo16 + nb, u);
+        else T::template store8_wt<8, WT>(o16 + fmt_pack_off(row, nb, g.ldo16), u);
       } else if constexpr (EPI == EPI_GATE_RES) {
         float* o = g.out_f32 + (size_t)row * g.ldo + nb;
         const float* gt = g.gate + (size_t)row * g.ldg + nb;
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
           x.y += gg.y * v[e + 1];
           x.z += gg.z * v[e + 2];
           x.w += gg.w * v[e + 3];
-          fh_store_f4_wt<16>(o + e, x);
+          fh_store_f4_wt<16, WT>(o + e, x);
         }
       } else if constexpr (EPI == EPI_XEMBED) {
         // input row = clip * ntok + token (the CFG rows of a clip share x); output rows (clip * bc + b2) * ntok + token
@@ -256,8 +257,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 8; ++i) v[i] += ps[i];
         for (int b2 = 0; b2 < g.bc; ++b2) {
           float* o = g.out_f32 + (size_t)((q * g.bc + b2) * g.ntok + tok) * g.ldo + nb;
-          fh_store_f4_wt<32>(o, float4{v[0], v[1], v[2], v[3]});
-          fh_store_f4_wt<32>(o + 4, float4{v[4], v[5], v[6], v[7]});
+          fh_store_f4_wt<32, WT>(o, float4{v[0], v[1], v[2], v[3]});
+          fh_store_f4_wt<32, WT>(o + 4, float4{v[4], v[5], v[6], v[7]});
         }
       }
     }
@@ -679,7 +680,7 @@ struct LnRed {
 
 constexpr int kLnTouch = 6;  // lines per lane: 192 single-wave workgroups cover 8 XCDs x 1 MB (fc1) with 6
 
-template <class T, int NV, int KS, bool TOUCH>
+template <class T, int NV, int KS, bool TOUCH, bool WT>
 __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, int M, const float* __restrict__ shift,
                                                         const float* __restrict__ scale, int ldm, u16* __restrict__ out,
                                                         LnRed red, TouchSpec pf, int ntok, int perm) {
@@ -741,7 +742,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
       v[i].y += gt[i].y * (t.y + bi[i].y);
       v[i].z += gt[i].z * (t.z + bi[i].z);
       v[i].w += gt[i].w * (t.w + bi[i].w);
-      fh_store_f4_wt<1>(xr + i * 256 + lane * 4, v[i]);
+      fh_store_f4_wt<1, WT>(xr + i * 256 + lane * 4, v[i]);
     }
   }
 #pragma unroll
@@ -764,7 +765,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
-    T::template store4_wt<1>(reinterpret_cast<typename T::elem*>(out) + fmt_pack_off(orow, c, D / 32),
+    T::template store4_wt<1, WT>(reinterpret_cast<typename T::elem*>(out) + fmt_pack_off(orow, c, D / 32),
               (v[i].x - mu) * rstd * (1.f + b[i].x) + a[i].x, (v[i].y - mu) * rstd * (1.f + b[i].y) + a[i].y,
               (v[i].z - mu) * rstd * (1.f + b[i].z) + a[i].z, (v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w);
   }
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 // per query this is 0.3 % of the evaluation's flops - MFMA/LDS tiling would only add latency - so q/k/v come straight from
 // L2.  For window <= 2 every load of the query's band is issued before the first use (one memory round trip); wider
 // windows loop.  Output is written in the packed A-operand order of the proj GEMM (K = D).
-template <class T, int LPQ, bool TOUCH>
+template <class T, int LPQ, bool TOUCH, bool WT>
 __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ntok,
                                                        int M, int D, int window, TouchSpec pf) {
   constexpr int HD = 128, PD = HD / LPQ, NU = PD / 8;
@@ -876,7 +877,7 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
     P8 uo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) T::set(uo, j, o[u * 8 + j] * inv);
-    T::template store8_wt<2>(reinterpret_cast<E*>(out) + fmt_pack_off(row, d0 + u * 8, D / 32), uo);
+    T::template store8_wt<2, WT>(reinterpret_cast<E*>(out) + fmt_pack_off(row, d0 + u * 8, D / 32), uo);
   }
   if constexpr (TOUCH) fmt_touch_retire(touched);
 }
