@@ -81,6 +81,8 @@ __device__ __forceinline__ void fh_store_f4_wt(float* p, const float4& v) {
   typedef u16 elem;                                                                                                         \
   typedef u32x4 pack8;                                                                                                      \
   static constexpr bool is32 = false;                                                                                       \
+  static constexpr int EB = 2;  /* bytes per element; a pack8 is 8 * EB bytes */                                          \
+  static __device__ __forceinline__ pack8 zero8() { return u32x4{0u, 0u, 0u, 0u}; }                                         \
   static __device__ __forceinline__ pack8 load8(const elem* p) { return *reinterpret_cast<const u32x4*>(p); }               \
   static __device__ __forceinline__ pack8 load8_nt(const elem* p) {                                                         \
     return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));                                                   \
@@ -182,9 +184,11 @@ struct FP32 {
   typedef float elem;
   typedef F32x8 pack8;
   static constexpr bool is32 = true;
+  static constexpr int EB = 4;
   static __device__ __forceinline__ float from_float(float x) { return x; }
   static __device__ __forceinline__ float to_float(float v) { return v; }
   static float host_from_float(float x) { return x; }
+  static __device__ __forceinline__ pack8 zero8() { return pack8{f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}; }
   static __device__ __forceinline__ pack8 load8(const elem* p) {
     return pack8{*reinterpret_cast<const f32x4*>(p), *reinterpret_cast<const f32x4*>(p + 4)};
   }

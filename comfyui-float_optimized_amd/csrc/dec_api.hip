@@ -10,7 +10,7 @@ namespace {
 struct Styled {  // one StyledConv (styledecoder.py:302-325)
   int cin = 0, cout = 0;
   bool up = false;
-  u16* W = nullptr;       // plain: [9][Cout][Cin]; up: four parity classes, [4+2+2+1][Cout][Cin]
+  void* W = nullptr;      // T::elem; plain: [9][Cout][Cin]; up: four parity classes, [4+2+2+1][Cout][Cin]
   float* WsqT = nullptr;  // [Cin][Cout] sum over taps of W^2 (fp32)
   float* abias = nullptr; // [Cout] FusedLeakyReLU bias
   int style_off = 0, demod_off = 0;
@@ -21,7 +21,7 @@ struct Level {  // ToFlow + ToRGB of one resolution
   float *wflow = nullptr, *bflow = nullptr, *wrgb = nullptr, *b1 = nullptr, *b2 = nullptr;
   float* lin = nullptr;  // [R] np.linspace(-1, 1, R) as float32
   int style_off = 0;
-  u16* feat = nullptr;  // [R][R][C]
+  void* feat = nullptr;  // [R][R][C] T::elem
 };
 
 int ilog2(int v) {
@@ -52,16 +52,19 @@ struct float_dec {
   //                               the 512-channel weights dominate, so many frames share a launch;
   //   high batch  (<= max_frames): levels 64..size, where activations are 17 MB per frame.
   int lo_levels = 0, lo_frames = 0;
-  float *styles = nullptr, *demod = nullptr;
-  u16 *loA = nullptr, *loB = nullptr, *loZ = nullptr, *loX = nullptr;  // low phase ping/pong/z + hand-over tensor
-  u16 *hiA = nullptr, *hiB = nullptr, *hiZ = nullptr;
+  float *styles = nullptr, *demod = nullptr, *eps = nullptr;  // eps: [kStyleCap][16] = 1e-8 / (style normaliser)^2
+  void *loA = nullptr, *loB = nullptr, *loZ = nullptr, *loX = nullptr;  // T::elem: low phase ping/pong/z + hand-over tensor
+  void *hiA = nullptr, *hiB = nullptr, *hiZ = nullptr;
+  unsigned long long* sat = nullptr;  // [kDecSatSites] saturation counters (dec_kernels.hpp), device
+  bool style_norm = true;
   float *loFlow[2] = {nullptr, nullptr}, *loRgb[2] = {nullptr, nullptr};
   float *hiFlow[2] = {nullptr, nullptr}, *hiRgb[2] = {nullptr, nullptr};
   // float_dec_frames_host, ride-along mode: the frames of the previous high batch still to be copied to the host by copy
   // workgroups inside the next batch's launches (CopyTail, dec_kernels.hpp)
   struct {
     const float* src = nullptr;
-    float* dst = nullptr;
+    float* dst = nullptr;       // device-side address of the pinned destination (what the copy workgroups store through)
+    float* dst_host = nullptr;  // the same position as the caller's host pointer (hipMemcpyAsync of what no launch took)
     size_t left16 = 0;   // 16-byte units not yet handed to a launch
     double wleft = 0.0;  // sum of the weights of the carrying launches still to come in this batch
   } ride;
@@ -85,17 +88,28 @@ const float_tensor_t* need(const TensorTable& tt, const std::string& k, int64_t 
 }
 
 template <class T>
-int upload16(float_dec* h, const std::vector<float>& src, u16** dst) {
-  std::vector<u16> tmp(src.size());
+int upload_elem(DevicePool* pool, const std::vector<float>& src, void** dst) {
+  typedef typename T::elem E;
+  std::vector<E> tmp(src.size());
   for (size_t i = 0; i < src.size(); ++i) tmp[i] = T::host_from_float(src[i]);
-  int rc = h->pool.alloc(dst, tmp.size(), false);
+  E* d = nullptr;
+  int rc = pool->alloc(&d, tmp.size(), false);
   if (rc) return rc;
-  FH_CHECK_HIP(hipMemcpy(*dst, tmp.data(), tmp.size() * sizeof(u16), hipMemcpyHostToDevice));
+  *dst = d;
+  FH_CHECK_HIP(hipMemcpy(d, tmp.data(), tmp.size() * sizeof(E), hipMemcpyHostToDevice));
   return FLOAT_OK;
 }
 
-int upload32(float_dec* h, const std::vector<float>& src, float** dst) {
-  int rc = h->pool.alloc(dst, src.size(), false);
+template <class T>
+int alloc_elem(DevicePool* pool, void** dst, size_t count) {
+  typename T::elem* d = nullptr;
+  int rc = pool->alloc(&d, count, true);
+  *dst = d;
+  return rc;
+}
+
+int upload32(DevicePool* pool, const std::vector<float>& src, float** dst) {
+  int rc = pool->alloc(dst, src.size(), false);
   if (rc) return rc;
   FH_CHECK_HIP(hipMemcpy(*dst, src.data(), src.size() * sizeof(float), hipMemcpyHostToDevice));
   return FLOAT_OK;
@@ -127,7 +141,7 @@ ClassTaps class_taps(int pu, int pv) {
 }
 
 template <class T>
-int pack_styled(float_dec* h, const TensorTable& tt, const std::string& p, int cin, int cout, bool up, Styled* s,
+int pack_styled(DevicePool* pool, const TensorTable& tt, const std::string& p, int cin, int cout, bool up, Styled* s,
                 std::vector<float>* WmT_host, std::vector<float>* bm_host, int style_dim) {
   s->cin = cin;
   s->cout = cout;
@@ -156,7 +170,7 @@ int pack_styled(float_dec* h, const TensorTable& tt, const std::string& p, int c
       }
   }
   int rc;
-  if ((rc = upload16<T>(h, packed, &s->W))) return rc;
+  if ((rc = upload_elem<T>(pool, packed, &s->W))) return rc;
   std::vector<float> wsq((size_t)cin * cout, 0.f);
   for (int o = 0; o < cout; ++o)
     for (int i = 0; i < cin; ++i) {
@@ -167,11 +181,29 @@ int pack_styled(float_dec* h, const TensorTable& tt, const std::string& p, int c
       }
       wsq[(size_t)i * cout + o] = (float)a;
     }
-  if ((rc = upload32(h, wsq, &s->WsqT))) return rc;
-  if ((rc = upload32(h, std::vector<float>(ab->data, ab->data + cout), &s->abias))) return rc;
+  if ((rc = upload32(pool, wsq, &s->WsqT))) return rc;
+  if ((rc = upload32(pool, std::vector<float>(ab->data, ab->data + cout), &s->abias))) return rc;
   s->style_off = (int)bm_host->size();
   for (int i = 0; i < cin; ++i) bm_host->push_back(mb->data[i]);
   WmT_host->insert(WmT_host->end(), mw->data, mw->data + (size_t)cin * style_dim);  // [cin][style_dim], transposed later
+  return FLOAT_OK;
+}
+
+// dynamic LDS above the 64 KiB default: 64 KiB per workgroup with 16-bit operands (2 workgroups per CU), twice that in the
+// fp32 verification mode (the z tile of dec_zblur_kernel: 32 x 32 x 128 B)
+template <class T>
+int raise_lds_limits() {
+  const int lim = 32 * 1024 * T::EB;
+#define CONV16_ATTR(NTv, TYv, TXv) \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, NTv, TYv, TXv>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3) CONV16_ATTR(4, 2, 2) CONV16_ATTR(2, 2, 2) CONV16_ATTR(4, 2, 1) CONV16_ATTR(2, 2, 1)
+  CONV16_ATTR(4, 1, 2) CONV16_ATTR(2, 1, 2) CONV16_ATTR(4, 1, 1) CONV16_ATTR(2, 1, 1)
+#undef CONV16_ATTR
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zconv4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zblur_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipGetLastError();
   return FLOAT_OK;
 }
 
@@ -184,14 +216,14 @@ int create_impl(float_dec* h, const TensorTable& tt) {
   std::vector<float> wm_rows, bm_host;  // rows = modulation outputs, [Stot][sdim]
   int rc;
   h->convs.resize(1 + 2 * h->n_levels);
-  if ((rc = pack_styled<T>(h, tt, "conv1", chan[2], chan[2], false, &h->convs[0], &wm_rows, &bm_host, sdim))) return rc;
+  if ((rc = pack_styled<T>(&h->pool, tt, "conv1", chan[2], chan[2], false, &h->convs[0], &wm_rows, &bm_host, sdim))) return rc;
   int cin = chan[2];
   for (int li = 0; li < h->n_levels; ++li) {
     const int cout = chan[li + 3];
-    if ((rc = pack_styled<T>(h, tt, "convs." + std::to_string(2 * li), cin, cout, true, &h->convs[1 + 2 * li], &wm_rows,
+    if ((rc = pack_styled<T>(&h->pool, tt, "convs." + std::to_string(2 * li), cin, cout, true, &h->convs[1 + 2 * li], &wm_rows,
                              &bm_host, sdim)))
       return rc;
-    if ((rc = pack_styled<T>(h, tt, "convs." + std::to_string(2 * li + 1), cout, cout, false, &h->convs[2 + 2 * li],
+    if ((rc = pack_styled<T>(&h->pool, tt, "convs." + std::to_string(2 * li + 1), cout, cout, false, &h->convs[2 + 2 * li],
                              &wm_rows, &bm_host, sdim)))
       return rc;
     cin = cout;
@@ -222,37 +254,37 @@ int create_impl(float_dec* h, const TensorTable& tt) {
       a[i] = fw->data[i] * sc;
       b[i] = rw->data[i] * sc;
     }
-    if ((rc = upload32(h, a, &L.wflow))) return rc;
-    if ((rc = upload32(h, b, &L.wrgb))) return rc;
-    if ((rc = upload32(h, std::vector<float>(fb->data, fb->data + 3), &L.bflow))) return rc;
-    if ((rc = upload32(h, std::vector<float>(rb1->data, rb1->data + 3), &L.b1))) return rc;
-    if ((rc = upload32(h, std::vector<float>(rb2->data, rb2->data + 3), &L.b2))) return rc;
+    if ((rc = upload32(&h->pool, a, &L.wflow))) return rc;
+    if ((rc = upload32(&h->pool, b, &L.wrgb))) return rc;
+    if ((rc = upload32(&h->pool, std::vector<float>(fb->data, fb->data + 3), &L.bflow))) return rc;
+    if ((rc = upload32(&h->pool, std::vector<float>(rb1->data, rb1->data + 3), &L.b1))) return rc;
+    if ((rc = upload32(&h->pool, std::vector<float>(rb2->data, rb2->data + 3), &L.b2))) return rc;
     L.style_off = (int)bm_host.size();
     for (int i = 0; i < L.C; ++i) bm_host.push_back(fmb->data[i]);
     wm_rows.insert(wm_rows.end(), fmw->data, fmw->data + (size_t)L.C * sdim);
-    if ((rc = h->pool.alloc(&L.feat, (size_t)L.R * L.R * L.C, true))) return rc;
+    if ((rc = alloc_elem<T>(&h->pool, &L.feat, (size_t)L.R * L.R * L.C))) return rc;
     {
       // np.linspace(-1, 1, R): start + i*step in float64, last element forced to stop, cast to f32
       std::vector<float> lin(L.R);
       const double step = 2.0 / (double)(L.R - 1);
       for (int i = 0; i < L.R; ++i) lin[i] = (float)(-1.0 + (double)i * step);
       lin[L.R - 1] = 1.0f;
-      if ((rc = upload32(h, lin, &L.lin))) return rc;
+      if ((rc = upload32(&h->pool, lin, &L.lin))) return rc;
     }
   }
   h->Stot = (int)bm_host.size();
   std::vector<float> wmT((size_t)sdim * h->Stot);
   for (int j = 0; j < h->Stot; ++j)
     for (int k = 0; k < sdim; ++k) wmT[(size_t)k * h->Stot + j] = wm_rows[(size_t)j * sdim + k];
-  if ((rc = upload32(h, wmT, &h->WmT))) return rc;
-  if ((rc = upload32(h, bm_host, &h->bm))) return rc;
+  if ((rc = upload32(&h->pool, wmT, &h->WmT))) return rc;
+  if ((rc = upload32(&h->pool, bm_host, &h->bm))) return rc;
   // ConstantInput (1,512,4,4) -> HWC
   const float_tensor_t* ci = need(tt, "input.input", (int64_t)chan[2] * 16);
   if (!ci) return FLOAT_E_MISSING;
   std::vector<float> hwc((size_t)16 * chan[2]);
   for (int c = 0; c < chan[2]; ++c)
     for (int p = 0; p < 16; ++p) hwc[(size_t)p * chan[2] + c] = ci->data[(size_t)c * 16 + p];
-  if ((rc = upload32(h, hwc, &h->cin_hwc))) return rc;
+  if ((rc = upload32(&h->pool, hwc, &h->cin_hwc))) return rc;
   // workspace
   h->lo_levels = 0;
   for (int li = 0; li < h->n_levels - 1; ++li)
@@ -272,13 +304,15 @@ int create_impl(float_dec* h, const TensorTable& tt) {
   }
   if ((rc = h->pool.alloc(&h->styles, (size_t)kStyleCap * h->Stot, true))) return rc;
   if ((rc = h->pool.alloc(&h->demod, (size_t)kStyleCap * h->Dtot, true))) return rc;
-  if ((rc = h->pool.alloc(&h->loA, FL * act_lo, true))) return rc;
-  if ((rc = h->pool.alloc(&h->loB, FL * act_lo, true))) return rc;
-  if ((rc = h->pool.alloc(&h->loZ, FL * act_lo, true))) return rc;
-  if ((rc = h->pool.alloc(&h->loX, FL * std::max(x_lo, (size_t)16 * chan[2]), true))) return rc;
-  if ((rc = h->pool.alloc(&h->hiA, FH * act_hi, true))) return rc;
-  if ((rc = h->pool.alloc(&h->hiB, FH * act_hi, true))) return rc;
-  if ((rc = h->pool.alloc(&h->hiZ, FH * act_hi, true))) return rc;
+  if ((rc = h->pool.alloc(&h->eps, (size_t)kStyleCap * 16, true))) return rc;
+  if ((rc = h->pool.alloc(&h->sat, (size_t)kDecSatSites, true))) return rc;
+  if ((rc = alloc_elem<T>(&h->pool, &h->loA, FL * act_lo))) return rc;
+  if ((rc = alloc_elem<T>(&h->pool, &h->loB, FL * act_lo))) return rc;
+  if ((rc = alloc_elem<T>(&h->pool, &h->loZ, FL * act_lo))) return rc;
+  if ((rc = alloc_elem<T>(&h->pool, &h->loX, FL * std::max(x_lo, (size_t)16 * chan[2])))) return rc;
+  if ((rc = alloc_elem<T>(&h->pool, &h->hiA, FH * act_hi))) return rc;
+  if ((rc = alloc_elem<T>(&h->pool, &h->hiB, FH * act_hi))) return rc;
+  if ((rc = alloc_elem<T>(&h->pool, &h->hiZ, FH * act_hi))) return rc;
   const size_t sk_lo = FL * 32 * 32 * 4, sk_hi = FH * (size_t)size * size * 4;  // flow / rgb pyramids: 4 floats per pixel
   for (int i = 0; i < 2; ++i) {
     if ((rc = h->pool.alloc(&h->loFlow[i], sk_lo, true))) return rc;
@@ -286,25 +320,23 @@ int create_impl(float_dec* h, const TensorTable& tt) {
     if ((rc = h->pool.alloc(&h->hiFlow[i], sk_hi, true))) return rc;
     if ((rc = h->pool.alloc(&h->hiRgb[i], sk_hi, true))) return rc;
   }
-#define CONV16_ATTR(NTv, TYv, TXv) \
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, NTv, TYv, TXv>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3) CONV16_ATTR(4, 2, 2) CONV16_ATTR(2, 2, 2) CONV16_ATTR(4, 2, 1) CONV16_ATTR(2, 2, 1)
-  CONV16_ATTR(4, 1, 2) CONV16_ATTR(2, 1, 2) CONV16_ATTR(4, 1, 1) CONV16_ATTR(2, 1, 1)
-#undef CONV16_ATTR
-  (void)hipGetLastError();
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zblur_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-  return FLOAT_OK;
+  return raise_lds_limits<T>();
 }
 
 // Copy workgroups per carrying launch (a multiple of 8), the lowest resolution whose launches carry a share, and the pause
 // between a wave's 1-KiB stores in units of 512 clocks.  Unpaced, the copy saturates PCIe (55 GB/s) and its posted writes
 // queue in front of the compute workgroups' memory traffic: the 512-px flow launch took 665 us instead of 508 with a 217 us
 // copy inside; at ~45 GB/s (16 workgroups, pace 4) it takes 548 (in-kernel stamps, -DDEC_STAMPS).
-static const unsigned kRideWgs = getenv("FLOAT_DEC_RIDE_WGS") ? (unsigned)atoi(getenv("FLOAT_DEC_RIDE_WGS")) / 8 * 8 : 16;
-static const int kRideMinRes = getenv("FLOAT_DEC_RIDE_MIN_RES") ? atoi(getenv("FLOAT_DEC_RIDE_MIN_RES")) : 64;
-static const unsigned kRidePace = getenv("FLOAT_DEC_RIDE_PACE") ? (unsigned)atoi(getenv("FLOAT_DEC_RIDE_PACE")) : 4;
+static int env_int(const char* name, int dflt, int lo, int hi) {  // tuning knobs: anything outside [lo, hi] falls back to the default
+  const char* v = getenv(name);
+  if (!v || !*v) return dflt;
+  char* end = nullptr;
+  const long x = strtol(v, &end, 10);
+  return (end && *end == 0 && x >= lo && x <= hi) ? (int)x : dflt;
+}
+static const unsigned kRideWgs = (unsigned)env_int("FLOAT_DEC_RIDE_WGS", 16, 0, 64) / 8 * 8;
+static const int kRideMinRes = env_int("FLOAT_DEC_RIDE_MIN_RES", 64, 64, 512);
+static const unsigned kRidePace = (unsigned)env_int("FLOAT_DEC_RIDE_PACE", 4, 0, 64);
 
 // Relative duration of a carrying launch (kind 0 = up-conv + blur, 1 = conv2, 2 = flow / warp / ToRGB) at resolution R: the
 // share of the pending copy it takes is proportional to it, so that every share ends inside its launch (measured per 32-frame
@@ -314,7 +346,6 @@ static double ride_weight(int R, int kind) {
   if (equal) return 1.0;
   static const double w[4][3] = {{211, 210, 99}, {184, 224, 99}, {268, 295, 354}, {393, 328, 508}};
   const int li = R == 64 ? 0 : R == 128 ? 1 : R == 256 ? 2 : R == 512 ? 3 : -1;
-  if (kind == 3) return li < 0 ? 400.0 : 0.8 * (w[li][1] + w[li][2]);  // conv2 + flow in one launch
   return li < 0 ? 250.0 : w[li][kind];
 }
 
@@ -333,11 +364,14 @@ static CopyTail take_ride(float_dec* h, int R, int kind) {
   ct.n16 = n;
   ct.nwg = kRideWgs;
   ct.pace = kRidePace;
-  static const int test = getenv("FLOAT_DEC_RIDE_TEST") ? atoi(getenv("FLOAT_DEC_RIDE_TEST")) : 0;  // probes, wrong results
+#ifdef DEC_STAMPS  // diagnostic build only: probes that give wrong frames
+  static const int test = env_int("FLOAT_DEC_RIDE_TEST", 0, 0, 2);
   if (test == 1) ct.dst = const_cast<u32x4*>(ct.src);  // device -> device instead of device -> host
   if (test == 2) ct.n16 = 1;                            // copy workgroups with nothing to do
+#endif
   r.src += n * 4;
   r.dst += n * 4;
+  r.dst_host += n * 4;
   r.left16 -= n;
   return ct;
 }
@@ -345,12 +379,15 @@ static CopyTail take_ride(float_dec* h, int R, int kind) {
 // FLOAT_DEC_CB_ORDER=0: output-channel blocks as grid.y (the round-1 order; A/B switch of dec_group_cb)
 static const bool g_dec_cb_order = !(getenv("FLOAT_DEC_CB_ORDER") && atoi(getenv("FLOAT_DEC_CB_ORDER")) == 0);
 
+// h != nullptr: the launch may carry a share of the pending device-to-host copy (16x16-tile kernel only)
 template <class T>
-int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, const u16* Wt, int ntaps, const int* dy, const int* dx,
-                u16* Y, int Ho, int Wo, int OH, int OW, int sy, int sx, int py, int px, int F, const float* demod, int ldd,
-                const float* bias, int act, const float* snext, int lds, hipStream_t st, const FlowArgs* fuse = nullptr) {
+int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, const void* Wt, int ntaps, const int* dy, const int* dx,
+                void* Y, int Ho, int Wo, int OH, int OW, int sy, int sx, int py, int px, int F, const float* demod, int ldd,
+                const float* bias, int act, const float* snext, int lds, unsigned long long* sat, hipStream_t st) {
+  constexpr size_t RB = 32 * T::EB;
   ConvArgs g;
   memset(&g, 0, sizeof(g));
+  g.sat = sat;
   g.X = X;
   g.Wt = Wt;
   g.Y = Y;
@@ -400,13 +437,10 @@ int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, con
   // Output channels per workgroup.  32 (NT = 2) everywhere: twice the workgroups and 39 KB instead of 58 KB of LDS each beat the
   // 64-channel tiles' better operand reuse (decode 35.2 -> 33.9 ms); FLOAT_DEC_CONV_BN=64 / FLOAT_DEC_CONV_BN_LO=64 restore them
   // for the 16x16-tile kernel / the generic low-resolution kernel.
-  static const int bn_hi = getenv("FLOAT_DEC_CONV_BN") ? atoi(getenv("FLOAT_DEC_CONV_BN")) : 32;
-  static const int bn_lo = getenv("FLOAT_DEC_CONV_BN_LO") ? atoi(getenv("FLOAT_DEC_CONV_BN_LO")) : 32;
+  static const int bn_hi = env_int("FLOAT_DEC_CONV_BN", 32, 32, 64);
+  static const int bn_lo = env_int("FLOAT_DEC_CONV_BN_LO", 32, 32, 64);
   const bool tile16 = tdim == 16;
-  // fused conv2 + flow (dec_flow_from_regs): one workgroup must hold every output channel of its pixels
-  const int bn = fuse ? s.cout : ((s.cout >= 64 && (tile16 ? bn_hi : bn_lo) == 64) ? 64 : 32);
-  FH_REQUIRE(!fuse || (tile16 && (s.cout == 32 || s.cout == 64) && ntaps == 9 && Ho % 16 == 0 && Wo % 16 == 0 && sy == 1 && sx == 1),
-             "conv2 + flow fusion needs a 3x3 conv of 32 or 64 output channels on whole 16x16 tiles");
+  const int bn = (s.cout >= 64 && (tile16 ? bn_hi : bn_lo) == 64) ? 64 : 32;
   FH_REQUIRE(s.cout % bn == 0 && s.cin % 32 == 0, "conv channels (%d -> %d) not tileable", s.cin, s.cout);
   const int ty_taps = dymax - dymin + 1, tx_taps = dxmax - dxmin + 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -414,42 +448,26 @@ int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, con
   if (tdim == 16 && ty_taps * tx_taps == ntaps) {
     // dense TY x TX window on 16x16 tiles: compile-time geometry, swizzled LDS, register prefetch
     const int total = g.tiles_x * g.tiles_y * F;
-    static const int tpw_env = getenv("FLOAT_DEC_TPW") ? atoi(getenv("FLOAT_DEC_TPW")) : 0;  // tuning aid
+    static const int tpw_env = env_int("FLOAT_DEC_TPW", 0, 0, 4096);  // tuning aid
     g.tpw = tpw_env ? tpw_env : (total >= 16384 ? 4 : (total >= 4096 ? 2 : 1));
-    const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * 64 + (size_t)ntaps * bn * 64 + (fuse ? (size_t)256 * bn * 2 + (size_t)7 * bn * 4 : 0);
-    if (h) g.ct = take_ride(h, Ho, fuse ? 3 : 1);
+    const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * RB + (size_t)ntaps * bn * RB;
+    if (h) g.ct = take_ride(h, Ho, 1);
     dim3 grid((total + g.tpw - 1) / g.tpw + g.ct.nwg, s.cout / bn);
     if (g_dec_cb_order && s.cout / bn > 1) {  // channel blocks of a tile group side by side on one XCD (dec_group_cb)
       g.ngroups = (unsigned)((total + g.tpw - 1) / g.tpw);
       g.ncb = (unsigned)(s.cout / bn);
       grid = dim3(g.ngroups * g.ncb + g.ct.nwg, 1);
     }
-    FlowArgs fg;
-    memset(&fg, 0, sizeof(fg));
-    if (fuse) {
-      fg = *fuse;
-#define CONV16F(NTv)                                                                                                     \
-  if (bn == NTv * 16) {                                                                                                   \
-    auto kern = dec_conv16_kernel<T, NTv, 3, 3, true>;                                                                    \
-    if (smem > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); \
-    if (prof) hipExtLaunchKernelGGL(kern, grid, dim3(256), smem, st, e0, e1, 0, g, fg);                                   \
-    else hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, g, fg);                                                      \
-  }
-      CONV16F(2) CONV16F(4)
-#undef CONV16F
-      FH_CHECK_HIP(hipGetLastError());
-      return FLOAT_OK;
-    }
 #define CONV16(NTv, TYv, TXv)                                                                                    \
   if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv) {                                                       \
-    if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g, fg); \
-    else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g, fg);                  \
+    if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
+    else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);                  \
   }
     CONV16(4, 3, 3) CONV16(2, 3, 3) CONV16(4, 2, 2) CONV16(2, 2, 2) CONV16(4, 2, 1) CONV16(2, 2, 1) CONV16(4, 1, 2)
     CONV16(2, 1, 2) CONV16(4, 1, 1) CONV16(2, 1, 1)
 #undef CONV16
   } else {
-    const size_t smem = (size_t)npix * 64 + (size_t)ntaps * bn * 64;
+    const size_t smem = (size_t)npix * RB + (size_t)ntaps * bn * RB;
     dim3 grid(g.tiles_x * g.tiles_y * fblocks, s.cout / bn);
     if (prof) {
       if (bn == 64) hipExtLaunchKernelGGL((dec_conv_kernel<T, 4>), grid, dim3(256), smem, st, e0, e1, 0, g);
@@ -465,71 +483,73 @@ int launch_conv(float_dec* h, const u16* X, int Hi, int Wi, const Styled& s, con
 
 static const int kDy9[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, kDx9[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
 
-// One resolution level for `n` frames: x_in (R/2, scaled by the up-conv's style) -> z -> U -> V ->
-// flow/warp/blend/rgb.  U and the next level's input may alias (U is dead once conv2 has run).
+// The up-sampling StyledConv (styledecoder.py:302-325 with upsample=True: conv_transpose2d stride 2 -> Blur -> + bias ->
+// leaky_relu * sqrt2) for `n` frames: x_in (Ri x Ri, already scaled by the layer's style) -> *U_out (2Ri x 2Ri, scaled by
+// `snext`, the consumer's style).  Three forms by size: transposed conv + blur in one launch from `zblur_min` px up (the
+// result lands in Zb: x_in may alias U), all four parity classes in one launch + blur kernel from 16 px up, class by class
+// through the generic kernel below.  h != nullptr: the fused launch may carry a share of the pending device-to-host copy.
 template <class T>
-int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16* V, u16* xnext, const float* styles,
-              const float* demod, const float* flow_prev, const float* rgb_prev, float* flow_cur, float* rgb_cur,
-              float* final_out, int final_mode, hipStream_t st) {
-  const Level& L = h->levels[li];
-  const Styled& up = h->convs[1 + 2 * li];
-  const Styled& c2 = h->convs[2 + 2 * li];
-  const int R = L.R, Ri = R / 2;
+int launch_upconv(float_dec* h, const Styled& up, int Ri, int n, const void* x_in, void* Zb, void* U, void** U_out,
+                  const float* demod, int ldd, const float* snext, int lds, unsigned long long* sat, hipStream_t st) {
+  typedef typename T::elem E;
+  constexpr size_t RB = 32 * T::EB;
+  const int R = 2 * Ri;
   int rc;
-  // transposed conv (stride 2) into z (R+1 x R+1), demodulated: all four parity classes in one launch when
-  // the (m, n) grid is at least one 16x16 block, else class by class through the generic kernel
   static const bool fuse_z = !getenv("FLOAT_DEC_NO_ZFUSE");
-  // from this resolution up the blur runs inside the transposed conv's launch (z never leaves the CU)
-  static const int zblur_min = getenv("FLOAT_DEC_ZBLUR_MIN") ? atoi(getenv("FLOAT_DEC_ZBLUR_MIN")) : 64;
+  static const int zblur_min = env_int("FLOAT_DEC_ZBLUR_MIN", 64, 16, 4096);
   if (R >= zblur_min && up.cout % 32 == 0 && up.cin % 32 == 0) {
-    U = Zb;  // x_in may alias U (the callers reuse one buffer); the z buffer is free in this path and large enough
     ConvArgs z;
     memset(&z, 0, sizeof(z));
     z.X = x_in;
     z.Wt = up.W;
-    z.Y = U;
-    z.demod = demod + up.demod_off;
+    z.Y = Zb;
+    z.demod = demod;
     z.bias = up.abias;
-    z.snext = styles + c2.style_off;
-    z.lds = h->Stot;
+    z.snext = snext;
+    z.lds = lds;
     z.F = n;
     z.Hi = z.Wi = Ri;
     z.Cin = up.cin;
     z.Cout = up.cout;
     z.OH = z.OW = R;
-    z.ldd = h->Dtot;
+    z.ldd = ldd;
+    z.sat = sat;
     z.tiles_x = z.tiles_y = (R + 27) / 28;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = fh_prof_pair(1, &e0, &e1);
-    z.ct = take_ride(h, R, 0);
+    if (h) z.ct = take_ride(h, R, 0);
     dim3 grid(z.tiles_x * z.tiles_y * n + z.ct.nwg, up.cout / 32);
     if (g_dec_cb_order && up.cout / 32 > 1) {
       z.ngroups = (unsigned)(z.tiles_x * z.tiles_y * n);
       z.ncb = (unsigned)(up.cout / 32);
       grid = dim3(z.ngroups * z.ncb + z.ct.nwg, 1);
     }
-    const size_t smem = 32 * 32 * 64;
+    const size_t smem = 32 * 32 * RB;
     if (prof) hipExtLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, e0, e1, 0, z);
     else hipLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, z);
-  } else {
+    *U_out = Zb;
+    FH_CHECK_HIP(hipGetLastError());
+    return FLOAT_OK;
+  }
   if (Ri + 1 > 8 && up.cout % 32 == 0 && fuse_z) {
     ConvArgs z;
     memset(&z, 0, sizeof(z));
     z.X = x_in;
     z.Wt = up.W;
     z.Y = Zb;
-    z.demod = demod + up.demod_off;
+    z.demod = demod;
     z.F = n;
     z.Hi = z.Wi = Ri;
     z.Cin = up.cin;
     z.Cout = up.cout;
     z.OH = z.OW = R + 1;
-    z.ldd = h->Dtot;
+    z.ldd = ldd;
+    z.sat = sat;
     z.tiles_x = z.tiles_y = (Ri + 1 + 15) / 16;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = fh_prof_pair(1, &e0, &e1);
     dim3 grid(z.tiles_x * z.tiles_y * n, up.cout / 32);
-    const size_t smem = 17 * 17 * 64 + 9 * 32 * 64;
+    const size_t smem = 17 * 17 * RB + 9 * 32 * RB;
     if (prof) hipExtLaunchKernelGGL((dec_zconv4_kernel<T>), grid, dim3(256), smem, st, e0, e1, 0, z);
     else hipLaunchKernelGGL((dec_zconv4_kernel<T>), grid, dim3(256), smem, st, z);
   } else {
@@ -537,20 +557,65 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
     for (int pu = 0; pu < 2; ++pu)
       for (int pv = 0; pv < 2; ++pv) {
         const ClassTaps c = class_taps(pu, pv);
-        if ((rc = launch_conv<T>(nullptr, x_in, Ri, Ri, up, up.W + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Zb, Ri + 1 - pu, Ri + 1 - pv,
-                                 R + 1, R + 1, 2, 2, pu, pv, n, demod + up.demod_off, h->Dtot, nullptr, 0, nullptr, 0, st)))
+        if ((rc = launch_conv<T>(nullptr, x_in, Ri, Ri, up, reinterpret_cast<const E*>(up.W) + t0 * up.cout * up.cin, c.n, c.dy, c.dx, Zb,
+                                 Ri + 1 - pu, Ri + 1 - pv, R + 1, R + 1, 2, 2, pu, pv, n, demod, ldd, nullptr, 0, nullptr, 0, sat, st)))
           return rc;
         t0 += c.n;
       }
   }
-  // FIR blur + bias + lrelu, scaled by conv2's style
-  {
-    const size_t tot = (size_t)n * (R / 2) * (R / 4) * (up.cout / 8);
-    hipLaunchKernelGGL((dec_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Zb, U, n, R, up.cout, up.abias,
-                       styles + c2.style_off, h->Stot);
-  }
-  }  // unfused path
-  // ToFlow + warp + blend + ToRGB operands (the launch itself follows conv2, or rides in conv2's epilogue)
+  // FIR blur + bias + lrelu, scaled by the consumer's style
+  const size_t tot = (size_t)n * (R / 2) * (R / 4) * (up.cout / 8);
+  hipLaunchKernelGGL((dec_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const E*>(Zb),
+                     reinterpret_cast<E*>(U), n, R, up.cout, up.abias, snext, lds, sat);
+  *U_out = U;
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+// ToFlow + warp + blend + ToRGB of one level (dec_flow_kernel); g holds everything but the grid.
+// Grid: ~2048 workgroups in total (8 per CU) so that every lane group runs many pixel iterations and the per-workgroup
+// prologue (56 per-lane weight values) is amortised; one row of workgroups per frame.
+template <class T>
+int launch_flow(float_dec* h, FlowArgs g, hipStream_t st) {
+  const int R = g.R, n = g.F;
+  const int lpp = g.C / 8, gpb = 256 / lpp;
+  static const int pix_env = env_int("FLOAT_DEC_FLOW_PIX", 0, 0, 4);  // tuning aid
+  const int pix = (pix_env == 1 || pix_env == 2 || pix_env == 4) ? pix_env : (lpp <= 8 ? 4 : 2);
+  const int step = gpb * pix;  // pixels one workgroup covers per iteration
+  const int max_bx = (R * R + step - 1) / step;
+  static const int wg_env = env_int("FLOAT_DEC_FLOW_WGS", 2048, 8, 1 << 20);
+  int bx = std::max(1, std::min(max_bx, (wg_env + n - 1) / n));
+  if (bx >= 8) bx &= ~7;  // bands in multiples of 8: band <-> XCD affinity (dec_flow_kernel)
+  g.band_pix = ((R * R + bx - 1) / bx + step - 1) / step * step;
+  g.nbands = bx = (R * R + g.band_pix - 1) / g.band_pix;
+  if (h) g.ct = take_ride(h, R, 2);
+  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
+  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+// One resolution level for `n` frames: x_in (R/2, scaled by the up-conv's style) -> z -> U -> V ->
+// flow/warp/blend/rgb.  U and the next level's input may alias (U is dead once conv2 has run).
+template <class T>
+int run_level(float_dec* h, int li, int n, const void* x_in, void* Zb, void* U, void* V, void* xnext, const float* styles,
+              const float* demod, const float* flow_prev, const float* rgb_prev, float* flow_cur, float* rgb_cur,
+              float* final_out, int final_mode, hipStream_t st) {
+  const Level& L = h->levels[li];
+  const Styled& up = h->convs[1 + 2 * li];
+  const Styled& c2 = h->convs[2 + 2 * li];
+  const int R = L.R;
+  int rc;
+  if ((rc = launch_upconv<T>(h, up, R / 2, n, x_in, Zb, U, &U, demod + up.demod_off, h->Dtot, styles + c2.style_off, h->Stot,
+                             h->sat + 1 + 2 * li, st)))
+    return rc;
+  // conv2 (plain 3x3); its unscaled output feeds ToFlow.  (Running the flow phase in conv2's epilogue at C <= 64 - the conv2
+  // tile through LDS instead of memory, -33.6 MB per frame at 512 px - was built in round 2, was bitwise equal and slower:
+  // 30.5-30.9 vs 26.2 ms per 250 frames; removed in round 3, see DESIGN.md "Negative results".)
+  if ((rc = launch_conv<T>(h, U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
+                           c2.abias, 1, nullptr, 0, h->sat + 2 + 2 * li, st)))
+    return rc;
   const bool last = (li == h->n_levels - 1);
   FlowArgs g;
   memset(&g, 0, sizeof(g));
@@ -576,44 +641,14 @@ int run_level(float_dec* h, int li, int n, const u16* x_in, u16* Zb, u16* U, u16
   g.R = R;
   g.C = L.C;
   g.ld_s = h->Stot;
-  // conv2 (plain 3x3); its unscaled output feeds ToFlow.  Where one workgroup of the conv holds every channel of its pixels
-  // (C <= FLOAT_DEC_FUSE_FLOW: 32 = the 512-px level, 64 = also 256 px) the flow phase CAN run in the conv's epilogue (the
-  // conv2 tile goes through LDS instead of memory: -33.6 MB per frame at 512 px); xnext must not alias the conv's input then
-  // (it is read as halo by other workgroups while this one already writes): U is the z buffer on this path, xnext the
-  // callers' ping buffer.  Built, bitwise equal to the separate launches, and OFF by default: measured 30.5-30.9 ms per 250
-  // frames against 26.2 - a workgroup then alternates an MFMA phase and a gather phase behind two barriers at 2 workgroups
-  // per CU (the gather phase alone wants 168-230 VGPRs), which hides less latency than two launches that each fill the chip.
-  static const int fuse_c = getenv("FLOAT_DEC_FUSE_FLOW") ? atoi(getenv("FLOAT_DEC_FUSE_FLOW")) : 0;
-  const bool fuse = L.C <= fuse_c && (L.C == 32 || L.C == 64) && c2.cout == L.C && R % 16 == 0 && R >= 16;
-  FH_REQUIRE(!fuse || g.xnext != U, "fused conv2 + flow: the next level's input buffer aliases the conv's input");
-  if ((rc = launch_conv<T>(h, U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
-                           c2.abias, 1, nullptr, 0, st, fuse ? &g : nullptr)))
-    return rc;
-  if (fuse) return FLOAT_OK;
-  // Grid: ~2048 workgroups in total (8 per CU) so that every lane group runs many pixel iterations and
-  // the per-workgroup prologue (56 per-lane weight values) is amortised; one row of workgroups per frame.
-  const int lpp = L.C / 8, gpb = 256 / lpp;
-  static const int pix_env = getenv("FLOAT_DEC_FLOW_PIX") ? atoi(getenv("FLOAT_DEC_FLOW_PIX")) : 0;  // tuning aid
-  const int pix = pix_env ? pix_env : (lpp <= 8 ? 4 : 2);
-  const int step = gpb * pix;  // pixels one workgroup covers per iteration
-  const int max_bx = (R * R + step - 1) / step;
-  static const int wg_env = getenv("FLOAT_DEC_FLOW_WGS") ? atoi(getenv("FLOAT_DEC_FLOW_WGS")) : 2048;
-  int bx = std::max(1, std::min(max_bx, (wg_env + n - 1) / n));
-  if (bx >= 8) bx &= ~7;  // bands in multiples of 8: band <-> XCD affinity (dec_flow_kernel)
-  g.band_pix = ((R * R + bx - 1) / bx + step - 1) / step * step;
-  g.nbands = bx = (R * R + g.band_pix - 1) / g.band_pix;
-  g.ct = take_ride(h, R, 2);
+  g.sat = h->sat + 16 + li;
 #ifdef DEC_STAMPS
   if (last) {
     const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
     FH_CHECK_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_dec_stamps), init, sizeof(init), 0, hipMemcpyHostToDevice, st));
   }
 #endif
-  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
-  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
-  FH_CHECK_HIP(hipGetLastError());
-  return FLOAT_OK;
+  return launch_flow<T>(h, g, st);
 }
 
 // Low phase for `n` frames (n <= lo_frames): constant input, conv1, levels 8..32.  Leaves the
@@ -622,17 +657,17 @@ template <class T>
 int run_low(float_dec* h, int n, const float* styles, const float* demod, int* skip_idx, hipStream_t st) {
   int rc;
   const Styled& c1 = h->convs[0];
-  const int tot = n * 16 * c1.cin;
-  hipLaunchKernelGGL((dec_input_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, h->loB, h->cin_hwc, styles + c1.style_off,
-                     h->Stot, n, 16, c1.cin);
-  u16* first_out = h->lo_levels > 0 ? h->loA : h->loX;
+  const int tot = n * 16 * c1.cin / 4;
+  hipLaunchKernelGGL((dec_input_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<typename T::elem*>(h->loB),
+                     h->cin_hwc, styles + c1.style_off, h->Stot, n, 16, c1.cin, h->sat + 32);
+  void* first_out = h->lo_levels > 0 ? h->loA : h->loX;
   if ((rc = launch_conv<T>(nullptr, h->loB, 4, 4, c1, c1.W, 9, kDy9, kDx9, first_out, 4, 4, 4, 4, 1, 1, 0, 0, n, demod + c1.demod_off,
-                           h->Dtot, c1.abias, 1, styles + h->convs[1].style_off, h->Stot, st)))
+                           h->Dtot, c1.abias, 1, styles + h->convs[1].style_off, h->Stot, h->sat + 0, st)))
     return rc;
   int cur = 0;
   const float *fp = nullptr, *rp = nullptr;
   for (int li = 0; li < h->lo_levels; ++li) {
-    u16* xnext = (li == h->lo_levels - 1) ? h->loX : h->loA;
+    void* xnext = (li == h->lo_levels - 1) ? h->loX : h->loA;
     if ((rc = run_level<T>(h, li, n, h->loA, h->loZ, h->loA, h->loB, xnext, styles, demod, fp, rp, h->loFlow[cur], h->loRgb[cur],
                            nullptr, 0, st)))
       return rc;
@@ -650,15 +685,16 @@ int run_high(float_dec* h, int n, int off, const float* styles, const float* dem
              hipStream_t st) {
   int rc;
   const int l0 = h->lo_levels;
-  const u16* x_in;
+  typedef typename T::elem E;
+  const void* x_in;
   const float *fp = nullptr, *rp = nullptr;
   if (l0 > 0) {
     const Level& P = h->levels[l0 - 1];
-    x_in = h->loX + (size_t)off * P.R * P.R * P.C;
+    x_in = reinterpret_cast<const E*>(h->loX) + (size_t)off * P.R * P.R * P.C;
     fp = h->loFlow[skip_idx] + (size_t)off * P.R * P.R * 4;
     rp = h->loRgb[skip_idx] + (size_t)off * P.R * P.R * 4;
   } else {
-    x_in = h->loX + (size_t)off * 16 * h->convs[0].cout;
+    x_in = reinterpret_cast<const E*>(h->loX) + (size_t)off * 16 * h->convs[0].cout;
   }
   int cur = 0;
   for (int li = l0; li < h->n_levels; ++li) {
@@ -677,12 +713,15 @@ int run_high(float_dec* h, int n, int off, const float* styles, const float* dem
 // (float_dec_frames_host); `st` is made to wait for the last copy before the call returns.
 template <class T>
 int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, float* out, int final_mode, hipStream_t st,
-                float* host = nullptr, hipStream_t cs = nullptr) {
+                float* host = nullptr, hipStream_t cs = nullptr, float* host_dev = nullptr) {
   const int S = h->cfg.size, sdim = h->cfg.style_dim, FH = h->cfg.max_frames, FL = h->lo_frames;
   size_t n_copy = 0;
   // same-stream hand-over: copy workgroups ride along the next batch's launches unless FLOAT_DEC_COPY=memcpy
   static const bool ride_on = !(getenv("FLOAT_DEC_COPY") && !strcmp(getenv("FLOAT_DEC_COPY"), "memcpy"));
-  const bool ride = host && cs == st && ride_on && (((size_t)S * S * 3 * sizeof(float)) % 16 == 0);
+  // the copy workgroups store straight through `host`: only when it is device-accessible (pinned / registered) host memory
+  // (host_dev = its device-side address); a pageable destination takes the hipMemcpyAsync path, batch by batch, in order
+  const bool ride = host_dev && cs == st && ride_on && (((size_t)S * S * 3 * sizeof(float)) % 16 == 0) &&
+                    ((uintptr_t)host_dev % 16 == 0) && ((uintptr_t)out % 16 == 0);
   h->ride.left16 = 0;
   h->ride.wleft = 0.0;
   for (int s0 = 0; s0 < n_frames; s0 += kStyleCap) {
@@ -704,10 +743,15 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
         maxcin = std::max(maxcin, h->convs[i].cin);
       }
       d.styles = h->styles;
+      d.eps = h->eps;
       d.demod = h->demod;
       d.ld_s = h->Stot;
       d.ld_d = h->Dtot;
       d.F = ns;
+      d.normalise = h->style_norm ? 1 : 0;
+      d.sat = h->sat;
+      // every StyledConv's style divided by its max |s| per frame, eps / max^2 left for the demodulation (dec_kernels.hpp)
+      hipLaunchKernelGGL(dec_style_norm_kernel, dim3((unsigned)h->convs.size(), ns), dim3(256), 0, st, d);
       dim3 g2((maxc + 255) / 256, (ns + FB - 1) / FB, (unsigned)h->convs.size());
       hipLaunchKernelGGL((dec_demod_all_kernel<FB>), g2, dim3(256), FB * maxcin * sizeof(float), st, d);
     }
@@ -740,9 +784,10 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
         const size_t bytes = (size_t)nb * S * S * 3 * sizeof(float);
         if (host && ride) {
           if (h->ride.left16)  // what no launch took (a decoder without carrying levels): plain copy, in order
-            FH_CHECK_HIP(hipMemcpyAsync(h->ride.dst, h->ride.src, h->ride.left16 * 16, hipMemcpyDeviceToHost, st));
+            FH_CHECK_HIP(hipMemcpyAsync(h->ride.dst_host, h->ride.src, h->ride.left16 * 16, hipMemcpyDeviceToHost, st));
           h->ride.src = out + off;  // this batch crosses PCIe under the next one's kernels
-          h->ride.dst = host + off;
+          h->ride.dst = host_dev + off;
+          h->ride.dst_host = host + off;
           h->ride.left16 = bytes / 16;
         } else if (host && cs == st) {  // in-order copy behind the batch's last kernel
           FH_CHECK_HIP(hipMemcpyAsync(host + off, out + off, bytes, hipMemcpyDeviceToHost, st));
@@ -761,7 +806,7 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
     }
   }
   if (host && ride && h->ride.left16) {  // the last batch has no successor to ride along
-    FH_CHECK_HIP(hipMemcpyAsync(h->ride.dst, h->ride.src, h->ride.left16 * 16, hipMemcpyDeviceToHost, st));
+    FH_CHECK_HIP(hipMemcpyAsync(h->ride.dst_host, h->ride.src, h->ride.left16 * 16, hipMemcpyDeviceToHost, st));
     h->ride.left16 = 0;
   }
   if (host && n_copy) {  // join: work queued on `st` after this call sees the frames in host memory
@@ -777,10 +822,187 @@ template <class T>
 int set_feats_impl(float_dec* h, const float* const* feats, hipStream_t st) {
   for (int li = 0; li < h->n_levels; ++li) {
     const Level& L = h->levels[li];
-    const int tot = L.C * L.R * L.R;
-    hipLaunchKernelGGL((dec_feat_pack_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, L.feat, feats[li], L.C, L.R * L.R);
+    const int tot = L.C * L.R * L.R / 4;
+    hipLaunchKernelGGL((dec_feat_pack_kernel<T>), dim3((tot + 255) / 256), dim3(256), 0, st, reinterpret_cast<typename T::elem*>(L.feat),
+                       feats[li], L.C, L.R * L.R, h->sat + 33);
   }
   FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+// Run `call` with T = the handle's operand type.
+#define DEC_DISPATCH(dtype, call)                          \
+  ((dtype) == FLOAT_DT_FP32 ? ([&] { typedef FP32 T; return call; })() : ([&] { typedef FP16 T; return call; })())
+
+// One StyledConv / one ToFlow + ToRGB level on caller data (float_dec_debug_*): a private pool, the production launchers.
+struct UnitCtx {
+  DevicePool pool;
+  ~UnitCtx() { pool.release(); }
+};
+
+template <class T>
+int unit_styles(UnitCtx* u, const float_tensor_t* mw, const float_tensor_t* mb, int cin, int sdim, const float* style, int F,
+                float** styles_out, hipStream_t st) {
+  // s = EqualLinear(style): style @ (W / sqrt(sdim))^T + b (styledecoder.py:229,241)
+  std::vector<float> wmT((size_t)sdim * cin);
+  for (int j = 0; j < cin; ++j)
+    for (int k = 0; k < sdim; ++k) wmT[(size_t)k * cin + j] = mw->data[(size_t)j * sdim + k];
+  float *WmT = nullptr, *bm = nullptr, *styles = nullptr;
+  int rc;
+  if ((rc = upload32(&u->pool, wmT, &WmT))) return rc;
+  if ((rc = upload32(&u->pool, std::vector<float>(mb->data, mb->data + cin), &bm))) return rc;
+  if ((rc = u->pool.alloc(&styles, (size_t)F * cin, true))) return rc;
+  constexpr int FB = 8;
+  dim3 grid((cin + 255) / 256, (F + FB - 1) / FB);
+  hipLaunchKernelGGL((dec_small_gemm_kernel<SG_STYLE, FB>), grid, dim3(256), FB * sdim * sizeof(float), st, style, sdim,
+                     (const float*)nullptr, WmT, sdim, cin, bm, 1.0f / sqrtf((float)sdim), styles, cin, F);
+  *styles_out = styles;
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
+template <class T>
+int unit_styled_conv(const float_dec_unit_t* cfg, const TensorTable& tt, const float* x, const float* style, float* out,
+                     uint64_t* saturated, int style_norm, hipStream_t st) {
+  typedef typename T::elem E;
+  const int cin = cfg->cin, cout = cfg->cout, Ri = cfg->res, F = cfg->n_frames, sdim = cfg->style_dim;
+  const int Ro = cfg->upsample ? 2 * Ri : Ri;
+  UnitCtx u;
+  int rc;
+  if ((rc = raise_lds_limits<T>())) return rc;
+  Styled s;
+  std::vector<float> wm_rows, bm_host;
+  if ((rc = pack_styled<T>(&u.pool, tt, "sc", cin, cout, cfg->upsample != 0, &s, &wm_rows, &bm_host, sdim))) return rc;
+  float* styles = nullptr;
+  if ((rc = unit_styles<T>(&u, tt.find("sc.conv.modulation.weight"), tt.find("sc.conv.modulation.bias"), cin, sdim, style, F, &styles, st)))
+    return rc;
+  float *demod = nullptr, *eps = nullptr, *ones = nullptr;
+  unsigned long long* sat = nullptr;
+  if ((rc = u.pool.alloc(&demod, (size_t)F * cout, true))) return rc;
+  if ((rc = u.pool.alloc(&eps, (size_t)F * 16, true))) return rc;
+  if ((rc = u.pool.alloc(&sat, 1, true))) return rc;
+  if ((rc = upload32(&u.pool, std::vector<float>((size_t)F * cout, 1.0f), &ones))) return rc;
+  DemodArgs d;
+  memset(&d, 0, sizeof(d));
+  d.L[0] = {s.WsqT, cin, cout, 0, 0};
+  d.styles = styles;
+  d.eps = eps;
+  d.demod = demod;
+  d.ld_s = cin;
+  d.ld_d = cout;
+  d.F = F;
+  d.normalise = style_norm;
+  d.sat = nullptr;
+  constexpr int FB = 8;
+  hipLaunchKernelGGL(dec_style_norm_kernel, dim3(1, F), dim3(256), 0, st, d);
+  hipLaunchKernelGGL((dec_demod_all_kernel<FB>), dim3((cout + 255) / 256, (F + FB - 1) / FB, 1), dim3(256), FB * cin * sizeof(float), st, d);
+  E *X = nullptr, *Z = nullptr, *U = nullptr;
+  const size_t nin = (size_t)F * Ri * Ri * cin, nout = (size_t)F * (Ro + 1) * (Ro + 1) * cout;
+  if ((rc = u.pool.alloc(&X, nin, true))) return rc;
+  if ((rc = u.pool.alloc(&Z, nout, true))) return rc;
+  if ((rc = u.pool.alloc(&U, nout, true))) return rc;
+  hipLaunchKernelGGL((dec_dbg_pack_kernel<T>), dim3((unsigned)((nin / 4 + 255) / 256)), dim3(256), 0, st, X, x, styles, cin, F, cin,
+                     Ri * Ri, sat);
+  void* Y = U;
+  if (cfg->upsample) {
+    if ((rc = launch_upconv<T>(nullptr, s, Ri, F, X, Z, U, &Y, demod, cout, ones, cout, sat, st))) return rc;
+  } else {
+    if ((rc = launch_conv<T>(nullptr, X, Ri, Ri, s, s.W, 9, kDy9, kDx9, U, Ri, Ri, Ri, Ri, 1, 1, 0, 0, F, demod, cout, s.abias, 1, nullptr,
+                             0, sat, st)))
+      return rc;
+  }
+  const size_t no = (size_t)F * Ro * Ro * cout;
+  hipLaunchKernelGGL((dec_dbg_unpack_kernel<T>), dim3((unsigned)((no + 255) / 256)), dim3(256), 0, st, out, reinterpret_cast<const E*>(Y), F,
+                     cout, Ro * Ro);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(st));
+  unsigned long long n = 0;
+  FH_CHECK_HIP(hipMemcpy(&n, sat, sizeof(n), hipMemcpyDeviceToHost));
+  if (saturated) *saturated = n;
+  return FLOAT_OK;
+}
+
+template <class T>
+int unit_flow_level(const float_dec_unit_t* cfg, const TensorTable& tt, const float* x, const float* feat, const float* style,
+                    const float* prev_flow, const float* prev_rgb, float* out_flow, float* out_blend, float* out_rgb, hipStream_t st) {
+  typedef typename T::elem E;
+  const int C = cfg->cin, R = cfg->res, F = cfg->n_frames, sdim = cfg->style_dim, Rp = R / 2;
+  UnitCtx u;
+  int rc;
+  const float_tensor_t* fw = need(tt, "to_flow.conv.weight", 3 * C);
+  const float_tensor_t* fmw = need(tt, "to_flow.conv.modulation.weight", (int64_t)C * sdim);
+  const float_tensor_t* fmb = need(tt, "to_flow.conv.modulation.bias", C);
+  const float_tensor_t* fb = need(tt, "to_flow.bias", 3);
+  const float_tensor_t* rw = need(tt, "to_rgb.conv.0.weight", 3 * C);
+  const float_tensor_t* rb1 = need(tt, "to_rgb.conv.1.bias", 3);
+  const float_tensor_t* rb2 = need(tt, "to_rgb.bias", 3);
+  if (!fw || !fmw || !fmb || !fb || !rw || !rb1 || !rb2) return FLOAT_E_MISSING;
+  const float sc = 1.0f / sqrtf((float)C);
+  std::vector<float> a(3 * C), b(3 * C), lin(R);
+  for (int i = 0; i < 3 * C; ++i) {
+    a[i] = fw->data[i] * sc;
+    b[i] = rw->data[i] * sc;
+  }
+  const double step = 2.0 / (double)(R - 1);
+  for (int i = 0; i < R; ++i) lin[i] = (float)(-1.0 + (double)i * step);
+  lin[R - 1] = 1.0f;
+  FlowArgs g;
+  memset(&g, 0, sizeof(g));
+  float *wflow, *wrgb, *bflow, *b1, *b2, *dlin, *styles = nullptr, *ones, *pf = nullptr, *pr = nullptr, *fo, *ro;
+  if ((rc = upload32(&u.pool, a, &wflow)) || (rc = upload32(&u.pool, b, &wrgb))) return rc;
+  if ((rc = upload32(&u.pool, std::vector<float>(fb->data, fb->data + 3), &bflow))) return rc;
+  if ((rc = upload32(&u.pool, std::vector<float>(rb1->data, rb1->data + 3), &b1))) return rc;
+  if ((rc = upload32(&u.pool, std::vector<float>(rb2->data, rb2->data + 3), &b2))) return rc;
+  if ((rc = upload32(&u.pool, lin, &dlin))) return rc;
+  if ((rc = upload32(&u.pool, std::vector<float>((size_t)F * C, 1.0f), &ones))) return rc;
+  if ((rc = unit_styles<T>(&u, fmw, fmb, C, sdim, style, F, &styles, st))) return rc;
+  E *X, *Ft, *XN;
+  unsigned long long* sat;
+  if ((rc = u.pool.alloc(&sat, 1, true))) return rc;
+  if ((rc = u.pool.alloc(&X, (size_t)F * R * R * C, true)) || (rc = u.pool.alloc(&XN, (size_t)F * R * R * C, true))) return rc;
+  if ((rc = u.pool.alloc(&Ft, (size_t)R * R * C, true))) return rc;
+  if ((rc = u.pool.alloc(&fo, (size_t)F * R * R * 4, true)) || (rc = u.pool.alloc(&ro, (size_t)F * R * R * 4, true))) return rc;
+  const size_t nx = (size_t)F * R * R * C;
+  hipLaunchKernelGGL((dec_dbg_pack_kernel<T>), dim3((unsigned)((nx / 4 + 255) / 256)), dim3(256), 0, st, X, x, (const float*)nullptr, 0, F,
+                     C, R * R, sat);
+  hipLaunchKernelGGL((dec_dbg_pack_kernel<T>), dim3((unsigned)(((size_t)R * R * C / 4 + 255) / 256)), dim3(256), 0, st, Ft, feat,
+                     (const float*)nullptr, 0, 1, C, R * R, sat);
+  if (prev_flow) {
+    if ((rc = u.pool.alloc(&pf, (size_t)F * Rp * Rp * 4, true))) return rc;
+    hipLaunchKernelGGL(dec_dbg_pyr_kernel, dim3((F * Rp * Rp + 255) / 256), dim3(256), 0, st, pf, prev_flow, F, Rp * Rp, 0);
+  }
+  if (prev_rgb) {
+    if ((rc = u.pool.alloc(&pr, (size_t)F * Rp * Rp * 4, true))) return rc;
+    hipLaunchKernelGGL(dec_dbg_pyr_kernel, dim3((F * Rp * Rp + 255) / 256), dim3(256), 0, st, pr, prev_rgb, F, Rp * Rp, 0);
+  }
+  g.x = X;
+  g.feat = Ft;
+  g.pflow = pf;
+  g.prgb = pr;
+  g.wflow = wflow;
+  g.sflow = styles;
+  g.bflow = bflow;
+  g.wrgb = wrgb;
+  g.b1 = b1;
+  g.b2 = b2;
+  g.lin = dlin;
+  g.snext = ones;
+  g.xnext = XN;
+  g.flow_out = fo;
+  g.rgb_out = ro;
+  g.write_pyr = 1;
+  g.F = F;
+  g.R = R;
+  g.C = C;
+  g.ld_s = C;
+  g.sat = sat;
+  if ((rc = launch_flow<T>(nullptr, g, st))) return rc;
+  if (out_flow) hipLaunchKernelGGL(dec_dbg_pyr_kernel, dim3((F * R * R + 255) / 256), dim3(256), 0, st, out_flow, fo, F, R * R, 1);
+  if (out_rgb) hipLaunchKernelGGL(dec_dbg_pyr_kernel, dim3((F * R * R + 255) / 256), dim3(256), 0, st, out_rgb, ro, F, R * R, 1);
+  if (out_blend)
+    hipLaunchKernelGGL((dec_dbg_unpack_kernel<T>), dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, st, out_blend, XN, F, C, R * R);
+  FH_CHECK_HIP(hipGetLastError());
+  FH_CHECK_HIP(hipStreamSynchronize(st));
   return FLOAT_OK;
 }
 
@@ -794,13 +1016,16 @@ int float_dec_create(const float_dec_cfg_t* cfg, const float_tensor_t* tensors, 
              "decoder size must be a power of two in [64, 512] (got %d)", cfg->size);
   FH_REQUIRE(cfg->style_dim > 0 && cfg->style_dim <= 2048, "style_dim %d unsupported", cfg->style_dim);
   FH_REQUIRE(cfg->max_frames >= 1 && cfg->max_frames <= 128, "max_frames must be in [1,128] (got %d)", cfg->max_frames);
-  // fp16 operands only: with bf16 the 512-px frames sat at the 40 dB limit (40.7 dB, max |d| 0.15 on a [0,1] pixel: the
-  // flow field positions the bilinear sampling, 8 mantissa bits are too few there); fp16 runs at the same MFMA rate
-  FH_REQUIRE(cfg->dtype == FLOAT_DT_FP16, "the decoder supports FLOAT_DT_FP16 operands only (got dtype %d)", cfg->dtype);
+  // fp16 operands in production: with bf16 the 512-px frames sat at the 40 dB limit (40.7 dB, max |d| 0.15 on a [0,1] pixel: the
+  // flow field positions the bilinear sampling, 8 mantissa bits are too few there); fp16 runs at the same MFMA rate.
+  // FLOAT_DT_FP32 is the verification mode: the same launch chain with fp32 activations and weights (1/16 of the MFMA rate).
+  FH_REQUIRE(cfg->dtype == FLOAT_DT_FP16 || cfg->dtype == FLOAT_DT_FP32,
+             "the decoder supports FLOAT_DT_FP16 operands (and FLOAT_DT_FP32 for verification) only (got dtype %d)", cfg->dtype);
   float_dec* h = new float_dec();
   h->cfg = *cfg;
+  h->style_norm = env_int("FLOAT_DEC_STYLE_NORM", 1, 0, 1) != 0;
   TensorTable tt(tensors, n_tensors);
-  int rc = create_impl<FP16>(h, tt);
+  int rc = DEC_DISPATCH(cfg->dtype, create_impl<T>(h, tt));
   if (!rc) {
     if (const float_tensor_t* dw = tt.find("direction.weight")) {
       if (dw->ndim == 2 && dw->shape[0] == cfg->style_dim) {
@@ -839,7 +1064,7 @@ int float_dec_set_feats(float_dec_t* h, const float* const* feats, int32_t n_fea
   FH_REQUIRE(n_feats == h->n_levels, "expected %d feature maps (8..%d), got %d", h->n_levels, h->cfg.size, n_feats);
   for (int i = 0; i < n_feats; ++i) FH_REQUIRE(feats[i] != nullptr, "feats[%d] is null", i);
   hipStream_t st = (hipStream_t)stream;
-  int rc = set_feats_impl<FP16>(h, feats, st);
+  int rc = DEC_DISPATCH(h->cfg.dtype, set_feats_impl<T>(h, feats, st));
   if (!rc) h->feats_set = true;
   return rc;
 }
@@ -850,9 +1075,10 @@ int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_
   FH_REQUIRE(dtype == h->cfg.dtype, "feature dtype %d differs from the decoder's (%d)", dtype, h->cfg.dtype);
   for (int i = 0; i < n_feats; ++i) FH_REQUIRE(feats16[i] != nullptr, "feats16[%d] is null", i);
   hipStream_t st = (hipStream_t)stream;
+  const size_t eb = dtype == FLOAT_DT_FP32 ? 4 : 2;
   for (int li = 0; li < h->n_levels; ++li) {
     const Level& L = h->levels[li];
-    int rc = fh_copy_d2d(L.feat, feats16[li], (size_t)L.R * L.R * L.C * sizeof(u16), st);
+    int rc = fh_copy_d2d(L.feat, feats16[li], (size_t)L.R * L.R * L.C * eb, st);
     if (rc) return rc;
   }
   h->feats_set = true;
@@ -864,7 +1090,7 @@ static int dec_run(float_dec_t* h, const float* s_r, const float* r_d, int32_t n
   FH_REQUIRE(h->feats_set, "float_dec_set_feats must be called before decoding");
   FH_REQUIRE(n_frames >= 1, "n_frames must be >= 1 (got %d)", n_frames);
   hipStream_t st = (hipStream_t)stream;
-  return frames_impl<FP16>(h, s_r, r_d, n_frames, out, mode, st);
+  return DEC_DISPATCH(h->cfg.dtype, frames_impl<T>(h, s_r, r_d, n_frames, out, mode, st));
 }
 
 int float_dec_frames(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames, float* out_hwc, void* stream) {
@@ -877,7 +1103,57 @@ int float_dec_frames_host(float_dec_t* h, const float* s_r, const float* r_d, in
   FH_REQUIRE(h->feats_set, "float_dec_set_feats must be called before decoding");
   FH_REQUIRE(n_frames >= 1, "n_frames must be >= 1 (got %d)", n_frames);
   hipStream_t st = (hipStream_t)stream, cs = copy_stream ? (hipStream_t)copy_stream : st;
-  return frames_impl<FP16>(h, s_r, r_d, n_frames, out_hwc, 1, st, host_hwc, cs);
+  // Is host_hwc memory a kernel may store through?  Only pinned (hipHostMalloc) or registered (hipHostRegister) host memory
+  // has a device-side address; for anything else - pageable memory - the frames go by hipMemcpyAsync behind each batch.
+  float* host_dev = nullptr;
+  {
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, host_hwc) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer)
+      host_dev = reinterpret_cast<float*>(at.devicePointer);
+    else
+      (void)hipGetLastError();  // "invalid value" for pageable memory: not an error of this call
+  }
+  return DEC_DISPATCH(h->cfg.dtype, frames_impl<T>(h, s_r, r_d, n_frames, out_hwc, 1, st, host_hwc, cs, host_dev));
+}
+
+int float_dec_saturation(float_dec_t* h, uint64_t* total, uint64_t* per_site, int32_t reset, void* stream) {
+  FH_REQUIRE(h && total, "null argument to float_dec_saturation");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long host[kDecSatSites];
+  FH_CHECK_HIP(hipStreamSynchronize(st));
+  FH_CHECK_HIP(hipMemcpy(host, h->sat, sizeof(host), hipMemcpyDeviceToHost));
+  uint64_t sum = 0;
+  for (int i = 0; i < kDecSatSites; ++i) {
+    sum += host[i];
+    if (per_site) per_site[i] = host[i];
+  }
+  *total = sum;
+  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(host)));
+  return FLOAT_OK;
+}
+
+int float_dec_debug_styled_conv(const float_dec_unit_t* u, const float_tensor_t* tensors, int32_t n_tensors, const float* x,
+                                const float* style, float* out, uint64_t* saturated, void* stream) {
+  FH_REQUIRE(u && tensors && x && style && out, "null argument to float_dec_debug_styled_conv");
+  FH_REQUIRE(u->dtype == FLOAT_DT_FP16 || u->dtype == FLOAT_DT_FP32, "unit op: dtype %d unsupported", u->dtype);
+  FH_REQUIRE(u->cin % 32 == 0 && u->cout % 32 == 0 && u->cin > 0 && u->cout > 0, "unit op: channels must be multiples of 32");
+  FH_REQUIRE(u->res >= 4 && (u->res & (u->res - 1)) == 0 && u->res <= 512, "unit op: resolution must be a power of two in [4, 512]");
+  FH_REQUIRE(u->n_frames >= 1 && u->style_dim >= 1 && u->style_dim <= 2048, "unit op: bad batch / style_dim");
+  TensorTable tt(tensors, n_tensors);
+  return DEC_DISPATCH(u->dtype, unit_styled_conv<T>(u, tt, x, style, out, saturated, (u->flags & 1) ? 0 : 1, (hipStream_t)stream));
+}
+
+int float_dec_debug_flow_level(const float_dec_unit_t* u, const float_tensor_t* tensors, int32_t n_tensors, const float* x,
+                               const float* feat, const float* style, const float* prev_flow, const float* prev_rgb, float* out_flow,
+                               float* out_blend, float* out_rgb, void* stream) {
+  FH_REQUIRE(u && tensors && x && feat && style, "null argument to float_dec_debug_flow_level");
+  FH_REQUIRE(u->dtype == FLOAT_DT_FP16 || u->dtype == FLOAT_DT_FP32, "unit op: dtype %d unsupported", u->dtype);
+  FH_REQUIRE(u->cin >= 32 && u->cin <= 512 && (u->cin & (u->cin - 1)) == 0, "unit op: channels must be a power of two in [32, 512]");
+  FH_REQUIRE(u->res >= 8 && (u->res & (u->res - 1)) == 0 && u->res <= 512, "unit op: resolution must be a power of two in [8, 512]");
+  FH_REQUIRE(u->n_frames >= 1 && u->style_dim >= 1 && u->style_dim <= 2048, "unit op: bad batch / style_dim");
+  TensorTable tt(tensors, n_tensors);
+  return DEC_DISPATCH(u->dtype, unit_flow_level<T>(u, tt, x, feat, style, prev_flow, prev_rgb, out_flow, out_blend, out_rgb, (hipStream_t)stream));
 }
 
 #ifdef DEC_STAMPS

@@ -1,5 +1,8 @@
 // HIP kernels of the Synthesis decoder (reference styledecoder.py:195-425, 497-534), batched over
-// frames.  Activations are NHWC 16-bit; accumulation, style/demod, flow and rgb pyramids are fp32.
+// frames.  Activations are NHWC in the operand type T (FP16 in production; FP32 = the verification mode, the same kernels
+// with 4-byte elements on v_mfma_f32_16x16x4_f32); accumulation, style/demod, flow and rgb pyramids are fp32 in every mode.
+// Every kernel is written against T::elem / T::pack8 (8 consecutive channels = one lane's share of an MFMA fragment, 8 * EB
+// bytes); an LDS row holds 32 channels = 4 packs, the XOR swizzles permute packs, so the layouts carry over unchanged.
 //
 // ModulatedConv2d is evaluated as "scale the input channels by the style, convolve with the SHARED
 // weight, scale the output channels by the demodulation factor" (identical algebra to modulating
@@ -7,6 +10,59 @@
 // batch and the conv becomes an implicit GEMM with M = frames*pixels.
 #pragma once
 #include "common.hpp"
+
+// ------------------------------------------------------------------------------------------
+// Range check of the fp16 mode (float_dec_saturation).  fp16 ends at 65504; a checkpoint whose activations leave that range
+// must not come out as plausible-looking wrong frames.  Every 16-bit activation store of the decoder goes through dec_store4 /
+// dec_pack8: the values are converted WITHOUT a clamp (an overflow becomes inf and poisons what it touches - loud, not
+// silent), and the thread keeps the per-half maximum of the packed results' magnitudes (v_and_b32 + v_pk_max_u16 per two
+// values: what the clamp's v_med3_f32 per value used to cost, so the check is free); once per output tile dec_sat_flush adds
+// 1 to the site's 64-bit device counter if a half reached the inf / NaN encodings (>= 0x7c00).  The counter counts
+// (thread, tile) groups of 16..128 outputs with at least one such value - zero or not is what matters.  Cost ladder, ms per
+// 250 frames on one box: exact count with a compare + branch per 4 values 30.2 vs 28.1 without; running fp32 max
+// (v_max3_f32) + clamp 27.65 vs 26.80; this form: DESIGN.md.  FP32 instantiations compile to the plain store.
+constexpr int kDecSatSites = 40;  // [0..15] StyledConv outputs (index = conv), [16..23] flow kernel of level li, 32 constant input, 33 skip features, 34 non-finite styles
+typedef unsigned short dec_us2 __attribute__((ext_vector_type(2)));
+typedef _Float16 dec_h2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ unsigned dec_cvt2(float a, float b, unsigned& m) {  // two floats -> packed fp16, range-tracked
+  static_assert(!T::is32, "16-bit path");
+  const unsigned u = __builtin_bit_cast(unsigned, dec_h2{(_Float16)a, (_Float16)b});
+#ifndef DEC_NO_SAT  // A/B build only (make EXTRA=-DDEC_NO_SAT): what the tracking costs
+  m = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(dec_us2, m), __builtin_bit_cast(dec_us2, u & 0x7fff7fffu)));
+#endif
+  return u;
+}
+template <class T>
+__device__ __forceinline__ void dec_sat_flush(unsigned long long* ctr, unsigned& m) {
+  if constexpr (!T::is32) {
+    if ((m & 0xffffu) >= 0x7c00u || (m >> 16) >= 0x7c00u) atomicAdd(ctr, 1ull);
+    m = 0u;
+  }
+}
+template <class T>
+__device__ __forceinline__ void dec_store4(typename T::elem* p, float a, float b, float c, float d, unsigned& m) {
+  if constexpr (T::is32) {
+    T::store4(p, a, b, c, d);
+  } else {
+    static_assert(sizeof(typename T::elem) == 2 && !T::is32);
+    uint2 o;
+    o.x = dec_cvt2<T>(a, b, m);
+    o.y = dec_cvt2<T>(c, d, m);
+    *reinterpret_cast<uint2*>(p) = o;
+  }
+}
+template <class T>
+__device__ __forceinline__ typename T::pack8 dec_pack8(const float (&v)[8], unsigned& m) {
+  if constexpr (T::is32) {
+    typename T::pack8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) T::set(o, i, v[i]);
+    return o;
+  } else {
+    return u32x4{dec_cvt2<T>(v[0], v[1], m), dec_cvt2<T>(v[2], v[3], m), dec_cvt2<T>(v[4], v[5], m), dec_cvt2<T>(v[6], v[7], m)};
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 // out[f][j] = epi( sum_k in[f][k]^(1|2) * Wt[k][j] ), fp32, Wt stored k-major so lanes read
@@ -54,16 +110,47 @@ __global__ __launch_bounds__(256) void dec_small_gemm_kernel(const float* __rest
 
 // Demodulation factors of every StyledConv in ONE launch (blockIdx.z = layer):
 // d[f][o] = rsqrt( 1/(Cin*9) * sum_i s[f][i]^2 * Wsq[o][i] + 1e-8 )   (styledecoder.py:244-245)
+//
+// Range: the producers store x * s (activation times the consumer's style) in the operand type, and fp16 ends at 65504.  A
+// demodulated conv does not depend on the scale of its style - with s = a s',
+//   rsqrt(sum (W s)^2 + eps) * sum W s x  ==  rsqrt(sum (W s')^2 + eps / a^2) * sum W s' x
+// exactly - so dec_style_norm_kernel divides every StyledConv's style by a = max |s| (per frame and layer, in place, before
+// anybody reads it) and leaves eps / a^2 for the demodulation: what is stored is x * s' with |s'| <= 1, whatever the checkpoint's
+// modulation weights are (the remedy StyleGAN2-ADA uses for its fp16 layers).  ToFlow's style is not normalised: that 1x1
+// conv has no demodulation and is evaluated in fp32 (dec_flow_kernel).
 struct DemodLayer {
   const float* WsqT;  // [Cin][Cout]
   int cin, cout, style_off, demod_off;
 };
 struct DemodArgs {
   DemodLayer L[16];
-  const float* styles;
+  float* styles;      // normalised in place by dec_style_norm_kernel
+  float* eps;         // [F][16]: 1e-8 / a^2 per (frame, layer)
   float* demod;
   int ld_s, ld_d, F;
+  int normalise;      // 0: a = 1 (A/B switch, FLOAT_DEC_STYLE_NORM=0)
+  unsigned long long* sat;  // counters base (site 34: non-finite styles) or nullptr
 };
+__global__ __launch_bounds__(256) void dec_style_norm_kernel(DemodArgs g) {  // grid (layers, frames)
+  const DemodLayer L = g.L[blockIdx.x];
+  const int f = blockIdx.y;
+  float* s = g.styles + (size_t)f * g.ld_s + L.style_off;
+  __shared__ float red[4];
+  float m = 0.f;
+  for (int i = threadIdx.x; i < L.cin; i += 256) m = fmaxf(m, fabsf(s[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;  // NaN / inf anywhere in the segment makes this non-finite (fmaxf skips NaN)
+  for (int i = threadIdx.x; i < L.cin; i += 256) sum += s[i] * 0.f;
+  if (sum != 0.f && g.sat) atomicAdd(g.sat + 34, 1ull);  // 0 * finite == 0; NaN != 0
+  if (!g.normalise || !(m > 0.f) || !(m < 3e38f)) m = 1.f;  // all-zero / non-finite styles: leave them alone
+  const float inv = 1.f / m;
+  for (int i = threadIdx.x; i < L.cin; i += 256) s[i] *= inv;
+  if (threadIdx.x == 0) g.eps[f * 16 + blockIdx.x] = 1e-8f * inv * inv;
+}
 template <int FB>
 __global__ __launch_bounds__(256) void dec_demod_all_kernel(DemodArgs g) {
   extern __shared__ float s2[];  // [FB][cin]
@@ -90,17 +177,22 @@ __global__ __launch_bounds__(256) void dec_demod_all_kernel(DemodArgs g) {
   const float alpha = 1.0f / (float)(L.cin * 9);
 #pragma unroll
   for (int f = 0; f < FB; ++f)
-    if (f0 + f < g.F) g.demod[(size_t)(f0 + f) * g.ld_d + L.demod_off + j] = rsqrtf(acc[f] * alpha + 1e-8f);
+    if (f0 + f < g.F)
+      g.demod[(size_t)(f0 + f) * g.ld_d + L.demod_off + j] = 1.0f / sqrtf(acc[f] * alpha + g.eps[(f0 + f) * 16 + blockIdx.z]);
 }
 
 // ConstantInput repeated over the batch and pre-scaled by conv1's style (styledecoder.py:289-299, 513-514).
 template <class T>
-__global__ void dec_input_kernel(u16* __restrict__ out, const float* __restrict__ cin_hwc, const float* __restrict__ s, int ld_s,
-                                 int F, int HW, int C) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void dec_input_kernel(typename T::elem* __restrict__ out, const float* __restrict__ cin_hwc, const float* __restrict__ s,
+                                 int ld_s, int F, int HW, int C, unsigned long long* sat) {
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;  // C % 4 == 0: 4 consecutive channels of one pixel
   if (idx >= F * HW * C) return;
   const int c = idx % C, f = idx / (HW * C);
-  out[idx] = T::from_float(cin_hwc[idx % (HW * C)] * s[(size_t)f * ld_s + c]);
+  const float4 x = *reinterpret_cast<const float4*>(cin_hwc + idx % (HW * C));
+  const float4 sv = *reinterpret_cast<const float4*>(s + (size_t)f * ld_s + c);
+  unsigned sm = 0u;
+  dec_store4<T>(out + idx, x.x * sv.x, x.y * sv.y, x.z * sv.z, x.w * sv.w, sm);
+  dec_sat_flush<T>(sat, sm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -168,8 +260,8 @@ __device__ unsigned long long g_dec_stamps[4];
 
 // C/8 lanes share one pixel (8 channels each); `warp` never leaves registers.
 struct FlowArgs {
-  const u16* x;        // [F][R][R][C] conv2 output (unscaled)
-  const u16* feat;     // [R][R][C]
+  const void* x;       // [F][R][R][C] conv2 output (unscaled), T::elem
+  const void* feat;    // [R][R][C], T::elem
   const float* pflow;  // [F][R/2][R/2][4] (3 channels + pad: one 16-byte load per tap) or nullptr
   const float* prgb;   // [F][R/2][R/2][4] or nullptr
   const float* wflow;  // [3][C], already * 1/sqrt(C)
@@ -179,7 +271,7 @@ struct FlowArgs {
   const float* b1;     // [3] FusedLeakyReLU bias
   const float* b2;     // [3] ToRGB bias
   const float* snext;  // [F][ld_s] or nullptr
-  u16* xnext;          // [F][R][R][C] or nullptr (last level)
+  void* xnext;         // [F][R][R][C] T::elem, or nullptr (last level)
   float* flow_out;     // [F][R][R][4]
   float* rgb_out;      // [F][R][R][4]
   const float* lin;    // [R] identity grid: np.linspace(-1, 1, R) (float64) cast to float32
@@ -189,6 +281,7 @@ struct FlowArgs {
   int F, R, C, ld_s;
   int nbands, band_pix;  // the image is cut into nbands runs of band_pix consecutive pixels (multiple of gpb*PIX)
   CopyTail ct;           // copy that rides along (nwg == 0: none)
+  unsigned long long* sat;  // saturation counter of this level's xnext stores
 };
 
 __device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, int Rp, int Y, int X, float out[3]) {
@@ -226,11 +319,14 @@ __device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x});
 
 // One run of PIX consecutive pixels of a row (first pixel p0 = Y * R + X0 of frame f) for one lane group: ToFlow (1x1
 // modulated conv + up-sampled previous flow -> tanh / sigmoid), grid_sample of the skip features, blend, ToRGB, the pyramids,
-// the next level's input, the final frame.  xu[k] = this lane's 8 channels (c0 ..) of conv2's output at pixel k, 16-bit.
-// Shared by dec_flow_kernel (xu from memory) and the fused conv2 + flow epilogue of dec_conv16_kernel (xu from LDS).
+// the next level's input, the final frame.  xu[k] = this lane's 8 channels (c0 ..) of conv2's output at pixel k.
 template <class T, int PIX>
 __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* __restrict__ sw, int f, int p0, int sub, int lpp,
-                                                const uint4 (&xu)[PIX]) {
+                                                const typename T::pack8 (&xu)[PIX], unsigned& sm) {
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  const E* const featp = reinterpret_cast<const E*>(g.feat);
+  E* const xnextp = reinterpret_cast<E*>(g.xnext);
   const int C = g.C, c0 = sub * 8;
   const bool owner = sub < PIX;
   const float bf0 = g.bflow[0], bf1 = g.bflow[1], bf2 = g.bflow[2];
@@ -253,10 +349,9 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
       const float wv[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
 #pragma unroll
       for (int k = 0; k < PIX; ++k) {
-        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
         float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a += wv[i] * T::to_float(xe[i]);
+        for (int i = 0; i < 8; ++i) a += wv[i] * T::get(xu[k], i);
         o[k][j] = a;
       }
     }
@@ -277,7 +372,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
       }
     }
     float mask[PIX], ax[PIX], ay[PIX];
-    uint4 fu[PIX][4];
+    P8 fu[PIX][4];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
       const float sx = fh_tanh_fast(o[k][0]) + g.lin[X0 + k], sy = fh_tanh_fast(o[k][1]) + gy;
@@ -294,7 +389,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
         for (int b = 0; b < 2; ++b) {
           const int yy = y0 + a, xx = x0 + b;
           const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
-          fu[k][a * 2 + b] = in ? *reinterpret_cast<const uint4*>(g.feat + ((size_t)yy * R + xx) * C + c0) : uint4{0u, 0u, 0u, 0u};
+          fu[k][a * 2 + b] = in ? T::load8(featp + ((size_t)yy * R + xx) * C + c0) : T::zero8();
         }
     }
     float upr[3] = {0.f, 0.f, 0.f};
@@ -310,9 +405,8 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
           const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]) * mask[k];
-          const u16* fe = reinterpret_cast<const u16*>(&fu[k][a * 2 + b]);
 #pragma unroll
-          for (int i = 0; i < 8; ++i) fw[i] += wgt * T::to_float(fe[i]);
+          for (int i = 0; i < 8; ++i) fw[i] += wgt * T::get(fu[k][a * 2 + b], i);
         }
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -324,13 +418,11 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
         const float4 n0 = *reinterpret_cast<const float4*>(sw + 6 * C + c0);
         const float4 n1 = *reinterpret_cast<const float4*>(sw + 6 * C + c0 + 4);
         const float sn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
-        const u16* xe = reinterpret_cast<const u16*>(&xu[k]);
         const float om = 1.f - mask[k];
-        uint4 ou;
-        u16* oe = reinterpret_cast<u16*>(&ou);
+        float ov[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) oe[i] = T::from_float((fw[i] + T::to_float(xe[i]) * om) * sn[i]);
-        *reinterpret_cast<uint4*>(g.xnext + (po0 + k) * C + c0) = ou;
+        for (int i = 0; i < 8; ++i) ov[i] = (fw[i] + T::get(xu[k], i) * om) * sn[i];
+        T::store8(xnextp + (po0 + k) * C + c0, dec_pack8<T>(ov, sm));
       }
     }
     for (int d = 1; d < lpp; d <<= 1) {
@@ -377,9 +469,9 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
 }
 
 struct ConvArgs {
-  const u16* X;   // [F][Hi][Wi][Cin], already multiplied by the layer's style
-  const u16* Wt;  // [ntaps][Cout][Cin]
-  u16* Y;         // [F][OH][OW][Cout]
+  const void* X;   // [F][Hi][Wi][Cin] T::elem, already multiplied by the layer's (normalised) style
+  const void* Wt;  // [ntaps][Cout][Cin] T::elem
+  void* Y;         // [F][OH][OW][Cout] T::elem
   const float* demod;  // [F][ldd] (offset applied) or nullptr
   const float* bias;   // [Cout] or nullptr
   const float* snext;  // [F][lds] (offset applied) or nullptr: style of the consumer layer
@@ -397,6 +489,7 @@ struct ConvArgs {
   // dec_conv16_kernel / dec_zblur_kernel, ncb > 0: 1-D grid of ngroups x ncb compute workgroups, decoded by dec_group_cb
   // (ncb == 0: the output-channel block is blockIdx.y)
   unsigned ncb, ngroups;
+  unsigned long long* sat;          // saturation counter of this layer's output stores
 };
 
 // (tile group, output-channel block) of compute workgroup `bid`.  A layer with more than 32 output channels runs ncb workgroups
@@ -418,7 +511,12 @@ __device__ __forceinline__ void dec_group_cb(unsigned bid, unsigned ngroups, uns
 }
 
 template <class T, int NT>
-__global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
+__global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv_kernel(ConvArgs g) {
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  constexpr int RB = 32 * T::EB, CB = 8 * T::EB;  // bytes of a 32-channel LDS row / of one pack of 8 channels
+  const E* const X = reinterpret_cast<const E*>(g.X);
+  const E* const Wt = reinterpret_cast<const E*>(g.Wt);
   constexpr int BN = NT * 16;
   constexpr int KC = 32;
   constexpr int MAXA = 9;  // halo pixels * 4 chunks / 256 threads, worst case 16 x 6 x 6
@@ -433,8 +531,8 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
   const int fb = tile / g.tiles_y;
   const int n0 = blockIdx.y * BN;
   const int npix = nf * g.hh * g.hw;
-  unsigned char* sA = smem;                 // [npix][64 B]
-  unsigned char* sB = smem + npix * 64;     // [ntaps][BN][64 B]
+  unsigned char* sA = smem;                 // [npix][RB]
+  unsigned char* sB = smem + npix * RB;     // [ntaps][BN][RB]
 
   // global element offsets of this thread's halo chunks (constant over the channel loop)
   int aoff[MAXA];
@@ -477,25 +575,25 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
 #pragma unroll
     for (int i = 0; i < MAXA; ++i) {
       if (aoff[i] != -1) {
-        u32x4 v = u32x4{0u, 0u, 0u, 0u};
-        if (aoff[i] >= 0) v = *reinterpret_cast<const u32x4*>(g.X + (size_t)aoff[i] + c0);
-        *reinterpret_cast<u32x4*>(sA + (size_t)(tid + i * 256) * 16) = v;
+        P8 v = T::zero8();
+        if (aoff[i] >= 0) v = T::load8(X + (size_t)aoff[i] + c0);
+        *reinterpret_cast<P8*>(sA + (size_t)(tid + i * 256) * CB) = v;
       }
     }
     for (int e = tid; e < nb; e += 256) {
       const int row = e >> 2, ch = e & 3;   // row = tap * BN + n
       const int tap = row / BN, n = row - tap * BN;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
-      *reinterpret_cast<u32x4*>(sB + (size_t)e * 16) = v;
+      const P8 v = T::load8(Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+      *reinterpret_cast<P8*>(sB + (size_t)e * CB) = v;
     }
     __syncthreads();
     for (int t = 0; t < g.ntaps; ++t) {
       const int shift = (g.dy[t] - g.dymin) * g.hw + (g.dx[t] - g.dxmin);
-      u32x4 a[4], b[NT];
+      P8 a[4], b[NT];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const u32x4*>(sA + (size_t)(pbase[mt] + shift) * 64 + q * 16);
+      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const P8*>(sA + (size_t)(pbase[mt] + shift) * RB + q * CB);
 #pragma unroll
-      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + (size_t)((t * BN + j * 16 + r16) * 64 + q * 16));
+      for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const P8*>(sB + (size_t)((t * BN + j * 16 + r16) * RB + q * CB));
 #pragma unroll
       // operands swapped on purpose: D = W_tile (16 channels x K) * X_tile^T (K x 16 pixels), so a lane
       // ends up with 4 CONSECUTIVE CHANNELS of one pixel (row = q*4 + reg -> channel, col = r16 -> pixel)
@@ -507,13 +605,14 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
   }
 
   // epilogue: lane -> pixel m = tile row r16, channels n0 + j*16 + q*4 .. +3
+  unsigned sm = 0u;
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) {
     const int m = (w * 4 + mt) * 16 + r16;
     const int x = m & (tw - 1), y = (m >> g.ltw) & (th - 1), fl = m >> (g.ltw + g.lth);
     const int f = fb * nf + fl, oy = ty * th + y, ox = tx * tw + x;
     if (f >= g.F || oy >= g.Ho || ox >= g.Wo) continue;
-    u16* yp = g.Y + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
+    E* yp = reinterpret_cast<E*>(g.Y) + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int co = n0 + j * 16 + q * 4;
@@ -539,14 +638,10 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
         v[2] *= sn.z;
         v[3] *= sn.w;
       }
-      ushort4 o;
-      o.x = T::from_float(v[0]);
-      o.y = T::from_float(v[1]);
-      o.z = T::from_float(v[2]);
-      o.w = T::from_float(v[3]);
-      *reinterpret_cast<ushort4*>(yp + co) = o;
+      dec_store4<T>(yp + co, v[0], v[1], v[2], v[3], sm);
     }
   }
+  dec_sat_flush<T>(g.sat, sm);
 }
 
 // Specialisation of the conv for 16x16-pixel tiles of one frame and a dense TY x TX tap window (3x3
@@ -560,23 +655,19 @@ __global__ __launch_bounds__(256, 2) void dec_conv_kernel(ConvArgs g) {
 //     lane groups, tools/probes/lds_swizzle.py);
 //   * a workgroup walks `tpw` consecutive tiles and all K chunks as one item stream, and the global
 //     loads of item i+1 are issued into registers before the MFMAs of item i (single LDS buffer).
-#ifndef FUSE_PIX
-#define FUSE_PIX 2  // pixels per lane group and pass of the fused flow phase (1: 14 spilled VGPRs, 2: 67, 4: 99)
-#endif
-template <class T, int NT, int TY, int TX, bool FUSE = false>
-__global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs fg) {
+template <class T, int NT, int TY, int TX>
+__global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  constexpr int RB = 32 * T::EB, CB = 8 * T::EB;
+  const E* const X = reinterpret_cast<const E*>(g.X);
+  const E* const Wt = reinterpret_cast<const E*>(g.Wt);
   constexpr int BN = NT * 16, HH = 15 + TY, HW = 15 + TX, NPIX = HH * HW, NTAPS = TY * TX;
-  static_assert(!FUSE || NT == 2 || NT == 4, "the fused flow phase takes 32 or 64 channels");
   constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;              // [NPIX][64 B], chunk-swizzled
-  unsigned char* sB = smem + NPIX * 64;  // [NTAPS][BN][64 B], chunk-swizzled
-  // FUSE: conv2's output tile [256 pixels][BN] 16-bit (what dec_flow_kernel would have read from memory) and the flow
-  // phase's folded per-frame weights [7][BN]
-  unsigned char* const sV = smem + NPIX * 64 + NTAPS * BN * 64;
-  float* const sw = reinterpret_cast<float*>(sV + 256 * BN * 2);
-  int sw_frame = -1;
+  unsigned char* sA = smem;              // [NPIX][RB], pack-swizzled
+  unsigned char* sB = smem + NPIX * RB;  // [NTAPS][BN][RB], pack-swizzled
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
 
@@ -585,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
   // row (3x3: 18 ds_read_b128 per chunk instead of 36; the kernel was LDS-read bound: 54 reads per 72 MFMAs).
   // Per-lane swizzled LDS byte offsets of those fragments, two 16-bit offsets per register.
   constexpr int HR = 3 + TY, NFR = HR * TX, NTP = (NFR + 1) / 2;
+  static_assert(NPIX * RB <= 65536, "packed 16-bit LDS offsets");
   unsigned aaddr[NTP];
 #pragma unroll
   for (int tp = 0; tp < NTP; ++tp) {
@@ -594,12 +686,12 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
       const int idx = tp * 2 + h;
       if (idx < NFR) {
         const int P = (w * 4 + idx / TX) * HW + r16 + idx % TX;
-        packed |= (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4)) << (16 * h);
+        packed |= (unsigned)(P * RB + (q ^ ((P >> 1) & 3)) * CB) << (16 * h);
       }
     }
     aaddr[tp] = packed;
   }
-  const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);  // rows t*BN + j*16 + r16: same swizzle term
+  const int baddr = r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB;  // rows t*BN + j*16 + r16: same swizzle term
 
   const int tiles_pf = g.tiles_x * g.tiles_y;
   const int total = tiles_pf * g.F;
@@ -611,7 +703,7 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
   const int nitems = ntile * nchunks;
   const int n0 = cb * BN;
 
-  u32x4 ra[NA], rb[NB];
+  P8 ra[NA], rb[NB];
   auto issue = [&](int item) {
     const int tile = tile0 + item / nchunks, c0 = (item % nchunks) << 5;
     const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
@@ -620,12 +712,12 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      ra[i] = u32x4{0u, 0u, 0u, 0u};
+      ra[i] = T::zero8();
       if (p < NPIX) {
         const int hy = p / HW, hx = p - hy * HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
         if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
-          ra[i] = *reinterpret_cast<const u32x4*>(g.X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
+          ra[i] = T::load8(X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
       }
     }
     if (nchunks > 1 || item == 0) {
@@ -635,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
         if (e < NBC) {
           const int row = e >> 2, ch = e & 3;
           const int tap = row / BN, n = row - tap * BN;
-          rb[i] = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+          rb[i] = T::load8(Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
         }
       }
     }
@@ -648,7 +740,7 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      if (p < NPIX) *reinterpret_cast<u32x4*>(sA + p * 64 + ((ch ^ ((p >> 1) & 3)) << 4)) = ra[i];
+      if (p < NPIX) *reinterpret_cast<P8*>(sA + p * RB + (ch ^ ((p >> 1) & 3)) * CB) = ra[i];
     }
     if (nchunks > 1 || item == 0) {
 #pragma unroll
@@ -656,13 +748,11 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
         const int e = tid + i * 256;
         if (e < NBC) {
           const int row = e >> 2, ch = e & 3;
-          *reinterpret_cast<u32x4*>(sB + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = rb[i];
+          *reinterpret_cast<P8*>(sB + row * RB + (ch ^ ((row >> 1) & 3)) * CB) = rb[i];
         }
       }
     }
     __syncthreads();
-    // the next item's loads fly while this item computes; the fused form issues them behind its flow phase instead (their
-    // 44 staging registers would otherwise be live across it: 85 spilled VGPRs)
     if (item + 1 < nitems) issue(item + 1);  // in flight while this item computes
     const int chunk = item % nchunks;
     if (chunk == 0) {
@@ -673,15 +763,15 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
     }
 #pragma unroll
     for (int tx = 0; tx < TX; ++tx) {
-      u32x4 b[TY][NT];
+      P8 b[TY][NT];
 #pragma unroll
       for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const u32x4*>(sB + baddr + ((ty * TX + tx) * BN + j * 16) * 64);
+        for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + baddr + ((ty * TX + tx) * BN + j * 16) * RB);
 #pragma unroll
       for (int hr = 0; hr < HR; ++hr) {
         const int idx = hr * TX + tx;
-        const u32x4 a = *reinterpret_cast<const u32x4*>(sA + ((idx & 1) ? (aaddr[idx >> 1] >> 16) : (aaddr[idx >> 1] & 0xffffu)));
+        const P8 a = *reinterpret_cast<const P8*>(sA + ((idx & 1) ? (aaddr[idx >> 1] >> 16) : (aaddr[idx >> 1] & 0xffffu)));
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int ty = hr - mt;
@@ -712,86 +802,27 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
           es[j].w *= 1.4142135623730951f;
         }
       }
-      const bool act = g.act != 0;
-      if constexpr (FUSE) {
-        // folded per-frame weights of the flow phase: rebuilt when the workgroup's tile stream enters another frame
-        if (f != sw_frame) {
-          __syncthreads();  // nobody still reads the previous frame's weights
-          for (int c = tid; c < BN; c += 256) {
-            const float s = fg.sflow[(size_t)f * fg.ld_s + c];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-              sw[j * BN + c] = fg.wflow[j * BN + c] * s;
-              sw[(3 + j) * BN + c] = fg.wrgb[j * BN + c];
-            }
-            sw[6 * BN + c] = fg.snext ? fg.snext[(size_t)f * fg.ld_s + c] : 0.f;
-          }
-          sw_frame = f;
-          __syncthreads();
-        }
-        // conv2's own epilogue into the LDS tile (the previous tile's flow phase finished reading it before this item's first
-        // barrier), then the flow phase of dec_flow_kernel on it: lane group = BN / 8 lanes per pixel, runs of consecutive pixels
-        // of a tile row per group
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int pix = (w * 4 + mt) * 16 + r16;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            float v[4] = {acc[mt][j][0] * ed[j].x + eb[j].x, acc[mt][j][1] * ed[j].y + eb[j].y, acc[mt][j][2] * ed[j].z + eb[j].z,
-                          acc[mt][j][3] * ed[j].w + eb[j].w};
-            if (act) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.2f * v[r]);
-            }
-            ushort4 o;
-            o.x = T::from_float(v[0] * es[j].x);
-            o.y = T::from_float(v[1] * es[j].y);
-            o.z = T::from_float(v[2] * es[j].z);
-            o.w = T::from_float(v[3] * es[j].w);
-            *reinterpret_cast<ushort4*>(sV + pix * (BN * 2) + (j * 16 + q * 4) * 2) = o;
-          }
-        }
-        __syncthreads();
-        {
-          // 2 pixels per lane group and pass: the 4-pixel form of dec_flow_kernel holds 230 VGPRs, which do not fit beside the
-          // conv's staging registers (99 spilled VGPRs); 2 pixels hold 168
-          constexpr int LPP = BN / 8, GPB = 256 / LPP, PIXF = FUSE_PIX, RPR = 16 / PIXF, PASSES = 256 / (GPB * PIXF);
-          const int sub = tid % LPP, grp = tid / LPP;
-#pragma unroll 1
-          for (int ps = 0; ps < PASSES; ++ps) {
-            const int run = ps * GPB + grp;            // run of PIXF consecutive pixels of a tile row
-            const int trow = run / RPR, tcol = (run % RPR) * PIXF;
-            uint4 xu[PIXF];
-#pragma unroll
-            for (int k = 0; k < PIXF; ++k) xu[k] = *reinterpret_cast<const uint4*>(sV + (trow * 16 + tcol + k) * (BN * 2) + sub * 16);
-            dec_flow_pixels<T, PIXF>(fg, sw, f, (ty * 16 + trow) * fg.R + tx * 16 + tcol, sub, LPP, xu);
-          }
-        }
-        continue;
-      }
+      // leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf): one instruction (fmaxf costs a canonicalising v_max first),
+      // and slope = 1 when the layer has no activation, so the epilogue has no branch per fragment; the sqrt(2) rides in es
+      const float slope = g.act ? 0.2f : 1.0f;
+      unsigned sm = 0u;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
         const int m = (w * 4 + mt) * 16 + r16;
         const int oy = ty * 16 + (m >> 4), ox = tx * 16 + (m & 15);
         if (oy >= g.Ho || ox >= g.Wo) continue;
-        u16* yp = g.Y + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
+        E* yp = reinterpret_cast<E*>(g.Y) + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const int co = n0 + j * 16 + q * 4;
           float v[4] = {acc[mt][j][0] * ed[j].x + eb[j].x, acc[mt][j][1] * ed[j].y + eb[j].y, acc[mt][j][2] * ed[j].z + eb[j].z,
                         acc[mt][j][3] * ed[j].w + eb[j].w};
-          if (act) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.2f * v[r]);  // leaky_relu(0.2); the sqrt(2) rides in es
-          }
-          ushort4 o;
-          o.x = T::from_float(v[0] * es[j].x);
-          o.y = T::from_float(v[1] * es[j].y);
-          o.z = T::from_float(v[2] * es[j].z);
-          o.w = T::from_float(v[3] * es[j].w);
-          *reinterpret_cast<ushort4*>(yp + co) = o;
+          for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], slope * v[r], __builtin_inff());
+          dec_store4<T>(yp + co, v[0] * es[j].x, v[1] * es[j].y, v[2] * es[j].z, v[3] * es[j].w, sm);
         }
       }
+      dec_sat_flush<T>(g.sat, sm);
     }
   }
 }
@@ -803,12 +834,17 @@ __global__ __launch_bounds__(256, 2) void dec_conv16_kernel(ConvArgs g, FlowArgs
 // the halo four times for a quarter of the MFMA work each (r01: 165 TFLOP/s vs 530-810 for the 3x3 convs).
 // Weights: [9][Cout][Cin] in class order (0,0),(0,1),(1,0),(1,1), taps by ascending (dy, dx).
 template <class T>
-__global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
+__global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zconv4_kernel(ConvArgs g) {
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  constexpr int RB = 32 * T::EB, CB = 8 * T::EB;
+  const E* const X = reinterpret_cast<const E*>(g.X);
+  const E* const Wt = reinterpret_cast<const E*>(g.Wt);
   constexpr int NT = 2, BN = 32, HW = 17, NPIX = HW * HW, NTAPS = 9;
   constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;              // [17*17][64 B], chunk-swizzled
-  unsigned char* sB = smem + NPIX * 64;  // [9][BN][64 B], chunk-swizzled
+  unsigned char* sA = smem;              // [17*17][RB], pack-swizzled
+  unsigned char* sB = smem + NPIX * RB;  // [9][BN][RB], pack-swizzled
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   // swizzled LDS offsets of the four distinct input shifts (dy, dx) in {-1,0}^2, two per register
@@ -819,12 +855,12 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
 #pragma unroll
     for (int sh = 0; sh < 4; ++sh) {
       const int P = (mrow + (sh >> 1)) * HW + x + (sh & 1);  // halo origin is (m-1, n-1)
-      const unsigned off = (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4));
+      const unsigned off = (unsigned)(P * RB + (q ^ ((P >> 1) & 3)) * CB);
       if (sh & 1) aaddr[mt][sh >> 1] |= off << 16;
       else aaddr[mt][sh >> 1] = off;
     }
   }
-  const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);
+  const int baddr = r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB;
   const int tiles_pf = g.tiles_x * g.tiles_y;
   const int tile = blockIdx.x;
   const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
@@ -841,18 +877,18 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[NA], rb[NB];
+  P8 ra[NA], rb[NB];
   auto issue = [&](int chunk) {
     const int c0 = chunk << 5;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      ra[i] = u32x4{0u, 0u, 0u, 0u};
+      ra[i] = T::zero8();
       if (p < NPIX) {
         const int hy = p / HW, hx = p - hy * HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
         if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
-          ra[i] = *reinterpret_cast<const u32x4*>(g.X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
+          ra[i] = T::load8(X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
       }
     }
 #pragma unroll
@@ -861,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
       if (e < NBC) {
         const int row = e >> 2, ch = e & 3;
         const int tap = row / BN, n = row - tap * BN;
-        rb[i] = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+        rb[i] = T::load8(Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
       }
     }
   };
@@ -871,14 +907,14 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      if (p < NPIX) *reinterpret_cast<u32x4*>(sA + p * 64 + ((ch ^ ((p >> 1) & 3)) << 4)) = ra[i];
+      if (p < NPIX) *reinterpret_cast<P8*>(sA + p * RB + (ch ^ ((p >> 1) & 3)) * CB) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + i * 256;
       if (e < NBC) {
         const int row = e >> 2, ch = e & 3;
-        *reinterpret_cast<u32x4*>(sB + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = rb[i];
+        *reinterpret_cast<P8*>(sB + row * RB + (ch ^ ((row >> 1) & 3)) * CB) = rb[i];
       }
     }
     __syncthreads();
@@ -891,17 +927,17 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
     constexpr int kCls[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 1, 2, 3}};
 #pragma unroll
     for (int sh = 0; sh < 4; ++sh) {
-      u32x4 a[4];
+      P8 a[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
-        a[mt] = *reinterpret_cast<const u32x4*>(sA + ((sh & 1) ? (aaddr[mt][sh >> 1] >> 16) : (aaddr[mt][sh >> 1] & 0xffffu)));
+        a[mt] = *reinterpret_cast<const P8*>(sA + ((sh & 1) ? (aaddr[mt][sh >> 1] >> 16) : (aaddr[mt][sh >> 1] & 0xffffu)));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (u < kNum[sh]) {
           const int t = kTap[sh][u], c = kCls[sh][u];
-          u32x4 b[NT];
+          P8 b[NT];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + baddr + (t * BN + j * 16) * 64);
+          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const P8*>(sB + baddr + (t * BN + j * 16) * RB);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -912,6 +948,7 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
   }
   // epilogue: z[f][2m+pu][2n+pv][co] = acc * demod, for the positions that exist (u, v <= R = OH-1)
   float4 ed[NT];
+  unsigned sm = 0u;
 #pragma unroll
   for (int j = 0; j < NT; ++j) ed[j] = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + n0 + j * 16 + q * 4);
 #pragma unroll
@@ -921,20 +958,16 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
     for (int c = 0; c < 4; ++c) {
       const int u = 2 * mpos + (c >> 1), v = 2 * npos + (c & 1);
       if (u >= g.OH || v >= g.OW) continue;
-      u16* yp = g.Y + ((size_t)(f * g.OH + u) * g.OW + v) * g.Cout;
+      E* yp = reinterpret_cast<E*>(g.Y) + ((size_t)(f * g.OH + u) * g.OW + v) * g.Cout;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = n0 + j * 16 + q * 4;
         const float4 d = ed[j];
-        ushort4 o;
-        o.x = T::from_float(acc[c][mt][j][0] * d.x);
-        o.y = T::from_float(acc[c][mt][j][1] * d.y);
-        o.z = T::from_float(acc[c][mt][j][2] * d.z);
-        o.w = T::from_float(acc[c][mt][j][3] * d.w);
-        *reinterpret_cast<ushort4*>(yp + co) = o;
+        dec_store4<T>(yp + co, acc[c][mt][j][0] * d.x, acc[c][mt][j][1] * d.y, acc[c][mt][j][2] * d.z, acc[c][mt][j][3] * d.w, sm);
       }
     }
   }
+  dec_sat_flush<T>(g.sat, sm);
 }
 
 // Transposed conv AND its FIR blur in one launch, for the levels whose z tensor is HBM traffic (r01: at 512x512 the separate
@@ -945,14 +978,19 @@ __global__ __launch_bounds__(256, 2) void dec_zconv4_kernel(ConvArgs g) {
 // outside the image read zero inputs, so their z (the blur's zero padding) comes out as exact zeros by itself.  (16/14)^2 =
 // 1.31x the MFMA work of the unfused kernel buys 59 -> 25 MB of traffic per frame at 512x512.
 template <class T>
-__global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
+__global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  constexpr int RB = 32 * T::EB, CB = 8 * T::EB;
+  const E* const X = reinterpret_cast<const E*>(g.X);
+  const E* const Wt = reinterpret_cast<const E*>(g.Wt);
   constexpr int NT = 2, BN = 32, HW = 17, NPIX = HW * HW, NTAPS = 9;
   constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;              // [17*17][64 B], chunk-swizzled
-  unsigned char* sB = smem + NPIX * 64;  // [9][BN][64 B], chunk-swizzled
-  unsigned char* sZ = smem;              // after the K loop: [32][32][64 B] z tile, chunk c of pixel (zr, zc) at c ^ ((zc >> 2) & 3)
+  unsigned char* sA = smem;              // [17*17][RB], pack-swizzled
+  unsigned char* sB = smem + NPIX * RB;  // [9][BN][RB], pack-swizzled
+  unsigned char* sZ = smem;              // after the K loop: [32][32][RB] z tile, pack c of pixel (zr, zc) at c ^ ((zc >> 2) & 3)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   unsigned aaddr[4][2];
@@ -962,12 +1000,12 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
 #pragma unroll
     for (int sh = 0; sh < 4; ++sh) {
       const int P = (mrow + (sh >> 1)) * HW + x + (sh & 1);  // halo origin is (m-1, n-1)
-      const unsigned off = (unsigned)(P * 64 + ((q ^ ((P >> 1) & 3)) << 4));
+      const unsigned off = (unsigned)(P * RB + (q ^ ((P >> 1) & 3)) * CB);
       if (sh & 1) aaddr[mt][sh >> 1] |= off << 16;
       else aaddr[mt][sh >> 1] = off;
     }
   }
-  const int baddr = r16 * 64 + ((q ^ ((r16 >> 1) & 3)) << 4);
+  const int baddr = r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB;
   const int tiles_pf = g.tiles_x * g.tiles_y;
   unsigned grp = bid, cb = blockIdx.y;
   if (g.ncb) dec_group_cb(bid, g.ngroups, g.ncb, grp, cb);
@@ -986,18 +1024,18 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  u32x4 ra[NA], rb[NB];
+  P8 ra[NA], rb[NB];
   auto issue = [&](int chunk) {
     const int c0 = chunk << 5;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      ra[i] = u32x4{0u, 0u, 0u, 0u};
+      ra[i] = T::zero8();
       if (p < NPIX) {
         const int hy = p / HW, hx = p - hy * HW;
         const int iy = iy0 + hy, ix = ix0 + hx;
         if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
-          ra[i] = *reinterpret_cast<const u32x4*>(g.X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
+          ra[i] = T::load8(X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
       }
     }
 #pragma unroll
@@ -1006,7 +1044,7 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
       if (e < NBC) {
         const int row = e >> 2, ch = e & 3;
         const int tap = row / BN, n = row - tap * BN;
-        rb[i] = *reinterpret_cast<const u32x4*>(g.Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+        rb[i] = T::load8(Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
       }
     }
   };
@@ -1016,14 +1054,14 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      if (p < NPIX) *reinterpret_cast<u32x4*>(sA + p * 64 + ((ch ^ ((p >> 1) & 3)) << 4)) = ra[i];
+      if (p < NPIX) *reinterpret_cast<P8*>(sA + p * RB + (ch ^ ((p >> 1) & 3)) * CB) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int e = tid + i * 256;
       if (e < NBC) {
         const int row = e >> 2, ch = e & 3;
-        *reinterpret_cast<u32x4*>(sB + row * 64 + ((ch ^ ((row >> 1) & 3)) << 4)) = rb[i];
+        *reinterpret_cast<P8*>(sB + row * RB + (ch ^ ((row >> 1) & 3)) * CB) = rb[i];
       }
     }
     __syncthreads();
@@ -1033,17 +1071,17 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
     constexpr int kCls[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 1, 2, 3}};
 #pragma unroll
     for (int sh = 0; sh < 4; ++sh) {
-      u32x4 a[4];
+      P8 a[4];
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt)
-        a[mt] = *reinterpret_cast<const u32x4*>(sA + ((sh & 1) ? (aaddr[mt][sh >> 1] >> 16) : (aaddr[mt][sh >> 1] & 0xffffu)));
+        a[mt] = *reinterpret_cast<const P8*>(sA + ((sh & 1) ? (aaddr[mt][sh >> 1] >> 16) : (aaddr[mt][sh >> 1] & 0xffffu)));
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (u < kNum[sh]) {
           const int t = kTap[sh][u], c = kCls[sh][u];
-          u32x4 b[NT];
+          P8 b[NT];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + baddr + (t * BN + j * 16) * 64);
+          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const P8*>(sB + baddr + (t * BN + j * 16) * RB);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -1054,6 +1092,7 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
   }
   // z tile -> LDS: lane (r16, q) holds channels j*16 + q*4 .. +3 of z pixel (2*(w*4+mt) + pu, 2*r16 + pv)
   __syncthreads();  // every wave is done with the operand tiles
+  unsigned sm = 0u;
   {
     float4 ed[NT];
 #pragma unroll
@@ -1063,17 +1102,13 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int zr = 2 * (w * 4 + mt) + (c >> 1), zc = 2 * r16 + (c & 1);
-        unsigned char* zp = sZ + (zr * 32 + zc) * 64;
+        unsigned char* zp = sZ + (zr * 32 + zc) * RB;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const float4 d = ed[j];
-          ushort4 o;
-          o.x = T::from_float(acc[c][mt][j][0] * d.x);
-          o.y = T::from_float(acc[c][mt][j][1] * d.y);
-          o.z = T::from_float(acc[c][mt][j][2] * d.z);
-          o.w = T::from_float(acc[c][mt][j][3] * d.w);
           const int chunk = (j * 2 + (q >> 1)) ^ ((zc >> 2) & 3);
-          *reinterpret_cast<ushort4*>(zp + chunk * 16 + (q & 1) * 8) = o;
+          dec_store4<T>(reinterpret_cast<E*>(zp + chunk * CB + (q & 1) * (CB / 2)), acc[c][mt][j][0] * d.x, acc[c][mt][j][1] * d.y,
+                        acc[c][mt][j][2] * d.z, acc[c][mt][j][3] * d.w, sm);
         }
       }
   }
@@ -1108,25 +1143,23 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const int zc = X + 1 + b;
-          const uint4 u = *reinterpret_cast<const uint4*>(sZ + (zr * 32 + zc) * 64 + ((cg ^ ((zc >> 2) & 3)) << 4));
-          const u16* e = reinterpret_cast<const u16*>(&u);
+          const P8 u = *reinterpret_cast<const P8*>(sZ + (zr * 32 + zc) * RB + (cg ^ ((zc >> 2) & 3)) * CB);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h[i] += k1[b] * v2f{T::to_float(e[2 * i]), T::to_float(e[2 * i + 1])};
+          for (int i = 0; i < 4; ++i) h[i] += k1[b] * v2f{T::get(u, 2 * i), T::get(u, 2 * i + 1)};
         }
         if (r >= 3) {
           const int gy = ty * 28 + half * 14 + (r - 3);
           if (gy < g.OH) {
-            uint4 o;
-            u16* oe = reinterpret_cast<u16*>(&o);
+            float ov[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               v2f v = k1[0] * h0[i] + k1[1] * h1[i] + k1[2] * h2[i] + k1[3] * h[i] + bs[i];
               const v2f lo = 0.2f * v;
-              v = v2f{fmaxf(v.x, lo.x), fmaxf(v.y, lo.y)} * sn[i];  // leaky_relu(0.2)
-              oe[2 * i] = T::from_float(v.x);
-              oe[2 * i + 1] = T::from_float(v.y);
+              v = v2f{__builtin_amdgcn_fmed3f(v.x, lo.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v.y, lo.y, __builtin_inff())} * sn[i];  // leaky_relu(0.2)
+              ov[2 * i] = v.x;
+              ov[2 * i + 1] = v.y;
             }
-            *reinterpret_cast<uint4*>(g.Y + ((size_t)(f * g.OH + gy) * g.OW + gx) * g.Cout + n0 + cg * 8) = o;
+            T::store8(reinterpret_cast<E*>(g.Y) + ((size_t)(f * g.OH + gy) * g.OW + gx) * g.Cout + n0 + cg * 8, dec_pack8<T>(ov, sm));
           }
         }
 #pragma unroll
@@ -1138,6 +1171,7 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
       }
     }
   }
+  dec_sat_flush<T>(g.sat, sm);
 }
 
 // Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4) over the
@@ -1146,8 +1180,10 @@ __global__ __launch_bounds__(256, 2) void dec_zblur_kernel(ConvArgs g) {
 // (channels) block: 5 rows x 7 columns of z are read once (4.4 loads per output instead of 16), each
 // row is filtered horizontally once and feeds both output rows (18 VALU per output element, was 31).
 template <class T>
-__global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z, u16* __restrict__ out, int F, int R, int C,
-                                                       const float* __restrict__ bias, const float* __restrict__ snext, int lds) {
+__global__ __launch_bounds__(256) void dec_blur_kernel(const typename T::elem* __restrict__ z, typename T::elem* __restrict__ out,
+                                                       int F, int R, int C, const float* __restrict__ bias,
+                                                       const float* __restrict__ snext, int lds, unsigned long long* sat) {
+  typedef typename T::pack8 P8;
   const int c8 = C >> 3, xq = R >> 2, yh = R >> 1;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)F * yh * xq * c8) return;
@@ -1170,12 +1206,11 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
   for (int a = 0; a < 5; ++a) {  // z rows Y0-1 .. Y0+3
     const int zy = Y0 + a - 1;
     if (zy < 0 || zy > R) continue;
-    uint4 u[7];
+    P8 u[7];
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
       const int zx = X0 + b - 1;
-      u[b] = (zx >= 0 && zx <= R) ? *reinterpret_cast<const uint4*>(z + ((size_t)(f * Z + zy) * Z + zx) * C + cg * 8)
-                                  : uint4{0u, 0u, 0u, 0u};
+      u[b] = (zx >= 0 && zx <= R) ? T::load8(z + ((size_t)(f * Z + zy) * Z + zx) * C + cg * 8) : T::zero8();
     }
     float h[4][8];  // horizontal FIR of this row for the 4 output columns
 #pragma unroll
@@ -1184,10 +1219,9 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
       for (int i = 0; i < 8; ++i) h[j][i] = 0.f;
 #pragma unroll
     for (int b = 0; b < 7; ++b) {
-      const u16* e = reinterpret_cast<const u16*>(&u[b]);
       float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = T::to_float(e[i]);
+      for (int i = 0; i < 8; ++i) v[i] = T::get(u[b], i);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int t = b - j;
@@ -1210,6 +1244,7 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
     }
   }
   float bs[8], sn[8];
+  unsigned sm = 0u;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     bs[i] = bias[cg * 8 + i];
@@ -1219,12 +1254,12 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const u16* __restrict__ z
   for (int y = 0; y < 2; ++y)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      uint4 o;
-      u16* oe = reinterpret_cast<u16*>(&o);
+      float ov[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) oe[i] = T::from_float(fh_lrelu_s2(acc[y][j][i] + bs[i]) * sn[i]);
-      *reinterpret_cast<uint4*>(out + ((size_t)(f * R + Y0 + y) * R + X0 + j) * C + cg * 8) = o;
+      for (int i = 0; i < 8; ++i) ov[i] = fh_lrelu_s2(acc[y][j][i] + bs[i]) * sn[i];
+      T::store8(out + ((size_t)(f * R + Y0 + y) * R + X0 + j) * C + cg * 8, dec_pack8<T>(ov, sm));
     }
+  dec_sat_flush<T>(sat, sm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1276,21 +1311,70 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   __syncthreads();
   const int npix = g.R * g.R;
   const int pend = min(npix, (band + 1) * g.band_pix);
+  unsigned sm = 0u;
   for (int p0 = band * g.band_pix + grp * PIX; p0 < pend; p0 += gpb * PIX) {
     const size_t po0 = (size_t)f * npix + p0;
-    uint4 xu[PIX];
+    typename T::pack8 xu[PIX];
 #pragma unroll
-    for (int k = 0; k < PIX; ++k) xu[k] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(g.x + (po0 + k) * C + c0)));  // read once: leave L2 to the features
-    dec_flow_pixels<T, PIX>(g, sw, f, p0, sub, lpp, xu);
+    for (int k = 0; k < PIX; ++k) xu[k] = T::load8_nt(reinterpret_cast<const typename T::elem*>(g.x) + (po0 + k) * C + c0);  // read once: leave L2 to the features
+    dec_flow_pixels<T, PIX>(g, sw, f, p0, sub, lpp, xu, sm);
   }
+  dec_sat_flush<T>(g.sat, sm);
   DEC_STAMP_MAX(3);
 }
 
 // Encoder skip feature NCHW fp32 -> NHWC 16-bit (once per clip).
 template <class T>
-__global__ void dec_feat_pack_kernel(u16* __restrict__ out, const float* __restrict__ in, int C, int HW) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void dec_feat_pack_kernel(typename T::elem* __restrict__ out, const float* __restrict__ in, int C, int HW,
+                                     unsigned long long* sat) {
+  const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 4;  // 4 consecutive channels of one pixel
   if (idx >= C * HW) return;
   const int c = idx % C, p = idx / C;
-  out[idx] = T::from_float(in[(size_t)c * HW + p]);
+  const float* ip = in + (size_t)c * HW + p;
+  unsigned sm = 0u;
+  dec_store4<T>(out + idx, ip[0], ip[HW], ip[2 * (size_t)HW], ip[3 * (size_t)HW], sm);
+  dec_sat_flush<T>(sat, sm);
+}
+
+// ------------------------------------------------------------------------------------------
+// Layout converters of the unit-op test hooks (float_dec_debug_*): fp32 NCHW <-> NHWC T::elem (optionally times a per-frame
+// style row, what a producer's epilogue does), and the 3-channel pyramids <-> their 4-floats-per-pixel form.
+template <class T>
+__global__ void dec_dbg_pack_kernel(typename T::elem* __restrict__ out, const float* __restrict__ in, const float* __restrict__ s,
+                                    int ld_s, int F, int C, int HW, unsigned long long* sat) {
+  const size_t idx = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (idx >= (size_t)F * C * HW) return;
+  const int c = (int)(idx % C);
+  const size_t fp = idx / C;
+  const int p = (int)(fp % HW), f = (int)(fp / HW);
+  const float* ip = in + ((size_t)f * C + c) * HW + p;
+  float v[4] = {ip[0], ip[HW], ip[2 * (size_t)HW], ip[3 * (size_t)HW]};
+  if (s) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] *= s[(size_t)f * ld_s + c + i];
+  }
+  unsigned sm = 0u;
+  dec_store4<T>(out + idx, v[0], v[1], v[2], v[3], sm);
+  dec_sat_flush<T>(sat, sm);
+}
+template <class T>
+__global__ void dec_dbg_unpack_kernel(float* __restrict__ out, const typename T::elem* __restrict__ in, int F, int C, int HW) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)F * C * HW) return;
+  const int c = (int)(idx % C);
+  const size_t fp = idx / C;
+  const int p = (int)(fp % HW), f = (int)(fp / HW);
+  out[((size_t)f * C + c) * HW + p] = T::to_float(in[idx]);
+}
+// dir 0: (F,3,HW) -> [F][HW][4];  dir 1: back
+__global__ void dec_dbg_pyr_kernel(float* __restrict__ out, const float* __restrict__ in, int F, int HW, int dir) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)F * HW) return;
+  const int p = (int)(idx % HW), f = (int)(idx / HW);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    if (dir == 0) out[idx * 4 + c] = in[((size_t)f * 3 + c) * HW + p];
+    else out[((size_t)f * 3 + c) * HW + p] = in[idx * 4 + c];
+  }
+  if (dir == 0) out[idx * 4 + 3] = 0.f;
 }

@@ -9,8 +9,9 @@ from . import native
 
 class SynthesisHIP:
     def __init__(self, state_dict, size=512, style_dim=512, device="cuda:0", dtype="fp16", max_frames=16):
-        if native.DTYPES.get(dtype) != native.FLOAT_DT_FP16:
-            raise ValueError("the decoder runs fp16 operands only (got %r): bf16 left the 512-px frames at the 40 dB limit" % (dtype,))
+        if native.DTYPES.get(dtype) not in (native.FLOAT_DT_FP16, native.FLOAT_DT_FP32):
+            raise ValueError("the decoder runs fp16 operands (fp32 = verification mode) only (got %r): bf16 left the 512-px "
+                             "frames at the 40 dB limit" % (dtype,))
         self.size, self.style_dim = size, style_dim
         self.device = torch.device(device)
         self.dtype = dtype
@@ -78,13 +79,25 @@ class SynthesisHIP:
             self.set_feats(s_r_feats)
         return self._run(native.lib().float_dec_frames, s_r, r_d, (self.size, self.size, 3))
 
+    def saturation(self, reset=False, per_site=False):
+        """Activations the fp16 operator had to clamp at +-65504 since create / the last reset (float_dec_saturation):
+        0 unless the checkpoint leaves fp16's range - then the frames are not the reference's and dtype="fp32" is the
+        way to run it.  per_site: also the 40 per-layer counters.  Synchronises the current stream."""
+        tot = C.c_uint64(0)
+        sites = (C.c_uint64 * native.DEC_SAT_SITES)()
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_dec_saturation(self._h, C.byref(tot), sites, 1 if reset else 0,
+                                                           native.stream_ptr(self.device)))
+        return (tot.value, list(sites)) if per_site else tot.value
+
     @torch.no_grad()
     def decode_into_host(self, s_r, r_d, host, staging=None, copy_stream=None):
         """decode_latent_into_processed_images with the reference's destination (a pre-allocated CPU tensor, FLOAT.py:139):
-        `host` (T, size, size, 3) fp32, pinned for the copies to be asynchronous.  Every finished batch of frames is copied
-        behind its last kernel on the current stream, or on `copy_stream` (a torch stream) while the next batch renders -
-        see include/float_hip.h for why the second form does not pay on MI355X.  Returns the device staging tensor; the
-        frames are in `host` once the current stream has been synchronised."""
+        `host` (T, size, size, 3) fp32.  Pinned (`pin_memory()`): the frames of batch i are stored into it by copy
+        workgroups inside the launches of batch i+1 (or, with `copy_stream`, copied on that stream while the next batch
+        renders - see include/float_hip.h for why that form does not pay on MI355X).  Pageable: accepted, one staged
+        hipMemcpyAsync behind each batch (the operator asks the runtime what `host` is, nothing is assumed).  Returns the
+        device staging tensor; the frames are in `host` once the current stream has been synchronised."""
         s_r = s_r.to(self.device, torch.float32).reshape(-1).contiguous()
         r_d = r_d.to(self.device, torch.float32).reshape(-1, self.style_dim).contiguous()
         T = r_d.shape[0]
@@ -116,3 +129,53 @@ class SynthesisHIP:
     def synthesis_raw(self, s_r, r_d):
         """Un-clamped Synthesis.forward output (T, 3, H, W) (styledecoder.py:532-534)."""
         return self._run(native.lib().float_dec_frames_raw, s_r, r_d, (3, self.size, self.size))
+
+
+def _unit(dtype, cin, cout, res, upsample, n_frames, style_dim, flags=0):
+    if native.DTYPES.get(dtype) not in (native.FLOAT_DT_FP16, native.FLOAT_DT_FP32):
+        raise ValueError("unit ops run fp16 or fp32 operands (got %r)" % (dtype,))
+    return native.DecUnit(native.DTYPES[dtype], cin, cout, res, 1 if upsample else 0, n_frames, style_dim, flags)
+
+
+@torch.no_grad()
+def debug_styled_conv(state, x, style, upsample=False, dtype="fp16", device="cuda:0", style_norm=True):
+    """Test hook (float_dec_debug_styled_conv): StyledConv.forward(x, style) of the reference (styledecoder.py:302-325, noise
+    weight 0) through the production kernels.  state: `conv.weight` (1,cout,cin,3,3), `conv.modulation.weight|bias`,
+    `activate.bias`; x (F,cin,R,R), style (F,style_dim).  Returns (out (F,cout,R',R') on the GPU, values clamped at fp16's range)."""
+    dev = torch.device(device)
+    F, cin, R, _ = x.shape
+    cout = state["conv.weight"].shape[1]
+    sd = {"sc." + k: v for k, v in state.items()}
+    arr, keep = native.tensor_table(sd)
+    u = _unit(dtype, cin, cout, R, upsample, F, style.shape[-1], 0 if style_norm else 1)
+    xd, sdv = x.to(dev, torch.float32).contiguous(), style.to(dev, torch.float32).contiguous()
+    Ro = 2 * R if upsample else R
+    out = torch.empty(F, cout, Ro, Ro, device=dev, dtype=torch.float32)
+    sat = C.c_uint64(0)
+    with torch.cuda.device(dev):
+        native.check(native.lib().float_dec_debug_styled_conv(C.byref(u), arr, len(sd), native.dev_ptr(xd), native.dev_ptr(sdv),
+                                                              native.dev_ptr(out), C.byref(sat), native.stream_ptr(dev)))
+    del keep
+    return out, sat.value
+
+
+@torch.no_grad()
+def debug_flow_level(state, x, feat, style, prev_flow=None, prev_rgb=None, dtype="fp16", device="cuda:0"):
+    """Test hook (float_dec_debug_flow_level): ToFlow (styledecoder.py:399-425) + ToRGB (:368-386) of one level through
+    dec_flow_kernel.  state: `to_flow.*`, `to_rgb.*` with the reference modules' key names.  Returns (flow `out` (F,3,R,R),
+    blend (F,C,R,R), rgb (F,3,R,R)) on the GPU."""
+    dev = torch.device(device)
+    F, Cc, R, _ = x.shape
+    arr, keep = native.tensor_table(state)
+    u = _unit(dtype, Cc, 0, R, False, F, style.shape[-1])
+    f32 = lambda t: None if t is None else t.to(dev, torch.float32).contiguous()  # noqa: E731
+    xd, fd, sdv, pf, pr = f32(x), f32(feat.reshape(Cc, R, R)), f32(style), f32(prev_flow), f32(prev_rgb)
+    of = torch.empty(F, 3, R, R, device=dev)
+    ob = torch.empty(F, Cc, R, R, device=dev)
+    org = torch.empty(F, 3, R, R, device=dev)
+    with torch.cuda.device(dev):
+        native.check(native.lib().float_dec_debug_flow_level(
+            C.byref(u), arr, len(state), native.dev_ptr(xd), native.dev_ptr(fd), native.dev_ptr(sdv), native.dev_ptr(pf),
+            native.dev_ptr(pr), native.dev_ptr(of), native.dev_ptr(ob), native.dev_ptr(org), native.stream_ptr(dev)))
+    del keep
+    return of, ob, org

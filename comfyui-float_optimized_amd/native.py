@@ -11,7 +11,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libfloat_hip.so")
 FLOAT_DT_BF16, FLOAT_DT_FP16, FLOAT_DT_FP32 = 0, 1, 2
 ODE_METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "heun2": 3, "heun3": 4}
 DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16,
-          "fp32": FLOAT_DT_FP32, "float32": FLOAT_DT_FP32}  # fp32: the FMT operator's verification mode only
+          "fp32": FLOAT_DT_FP32, "float32": FLOAT_DT_FP32}  # fp32: the verification mode of the FMT and decoder operators
+DEC_SAT_SITES = 40
 
 
 class NativeLibraryError(RuntimeError):
@@ -30,6 +31,10 @@ class FmtCfg(C.Structure):
 
 class DecCfg(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("size", "style_dim", "dtype", "max_frames")]
+
+
+class DecUnit(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "cin", "cout", "res", "upsample", "n_frames", "style_dim", "flags")]
 
 
 class EncCfg(C.Structure):
@@ -75,6 +80,10 @@ _SIGNATURES = {
     "float_dec_feat_shape": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "float_dec_frames_raw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_dec_direction": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "float_dec_saturation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, C.c_void_p]),
+    "float_dec_debug_styled_conv": (C.c_int, [C.POINTER(DecUnit), C.POINTER(FloatTensor), C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]),
+    "float_dec_debug_flow_level": (C.c_int, [C.POINTER(DecUnit), C.POINTER(FloatTensor), C.c_int32] + [C.c_void_p] * 9),
     "float_dec_set_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_void_p]),
     "float_enc_create": (C.c_int, [C.POINTER(EncCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_enc_destroy": (None, [C.c_void_p]),
@@ -111,7 +120,7 @@ def lib():
             raise NativeLibraryError("libfloat_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if L.float_hip_abi_version() != 2:
+    if L.float_hip_abi_version() != 3:
         raise NativeLibraryError("libfloat_hip.so ABI version mismatch")
     _lib = L
     return L

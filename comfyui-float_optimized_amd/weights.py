@@ -148,6 +148,35 @@ def synth_feats(size=512, seed=0, smooth=8, hi=0.02):
     return feats
 
 
+def stress_decoder(size=512, seed=0, kind="warp", style_gain=100.0, act_gain=300.0):
+    """Hard cases for the 16-bit decoder (tests/test_dec_stress_gpu.py, tools/make_goldens.py::gen_dec_stress), same layout
+    as synth_decoder_state / synth_feats; returns (state dict, feats).
+    kind "warp":  unit-gain ToFlow convs and white-noise skip features - a displacement field of the full tanh range
+                  sampling a feature map with no smoothness at all (the tame goldens use flow_gain 0.1 on smooth features).
+                  With random weights this map is chaotic: the reference's own fp32 output differs from an fp64 evaluation
+                  by 2.6e-3 at 64 px and by 2.4 (rel-L2 0.25) at 512 px, so it is only a test case at 64 px;
+    kind "warp_smooth": unit-gain ToFlow convs on the smooth features of the tame goldens - the 512-px form (reference fp32
+                  vs fp64: max 0.21, rel-L2 2.8e-3; the fixtures record that sensitivity and the tests scale their limits by it).
+    kind "range": modulation weights x style_gain (styles reach +-3 style_gain = 300: StyleGAN2's fp16 overflow case) and
+                  ConstantInput / skip features x act_gain (activations 1e2..1e4); the ToFlow convs (whose own modulation is
+                  left alone) are scaled back by 1 / act_gain so that the warp stays a warp instead of saturating tanh."""
+    if kind in ("warp", "warp_smooth"):
+        sd = synth_decoder_state(size, seed=seed, flow_gain=1.0)
+        feats = synth_feats(size, seed=seed, smooth=1, hi=0.5) if kind == "warp" else synth_feats(size, seed=seed)
+        return sd, feats
+    if kind != "range":
+        raise ValueError(kind)
+    sd = synth_decoder_state(size, seed=seed)
+    feats = [f * act_gain for f in synth_feats(size, seed=seed)]
+    for k in list(sd):
+        if k.endswith(".conv.modulation.weight") and not k.startswith("to_flows."):
+            sd[k] = sd[k] * style_gain
+        if k.startswith("to_flows.") and k.endswith(".conv.weight"):
+            sd[k] = sd[k] / (act_gain)
+    sd["input.input"] = sd["input.input"] * act_gain
+    return sd, feats
+
+
 ENC_CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
 
 

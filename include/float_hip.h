@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FLOAT_HIP_ABI_VERSION 2
+#define FLOAT_HIP_ABI_VERSION 3
 
 enum {
   FLOAT_OK = 0,
@@ -47,8 +47,9 @@ enum {
 };
 
 /* MFMA operand type; accumulation, statistics, softmax, residual stream and ODE state are fp32 in every mode.
- * FLOAT_DT_FP32 (FMT only): the verification mode - fp32 operands on v_mfma_f32_16x16x4_f32, the same launch chain, held to
- * the reference goldens at 1e-4 (tests/test_fmt_fp32_gpu.py); 1/16 of the 16-bit MFMA rate, no tuned tilings. */
+ * FLOAT_DT_FP32 (FMT and decoder): the verification mode - fp32 operands on v_mfma_f32_16x16x4_f32, the same launch chain and
+ * the same kernels with 4-byte elements, held to the reference goldens at 1e-4 (tests/test_fmt_fp32_gpu.py,
+ * tests/test_dec_fp32_gpu.py); 1/16 of the 16-bit MFMA rate, no tuned tilings. */
 enum { FLOAT_DT_BF16 = 0, FLOAT_DT_FP16 = 1, FLOAT_DT_FP32 = 2 };
 
 /* One checkpoint tensor, named with the reference's state-dict key (prefix stripped):
@@ -152,7 +153,8 @@ int float_fmt_debug(float_fmt_t* h, int32_t what, const float* in, float* out, v
 typedef struct {
   int32_t size;        /* output resolution, 64..512 (styledecoder.py:448) */
   int32_t style_dim;   /* 512 */
-  int32_t dtype;       /* FLOAT_DT_FP16 (activations / conv weights); bf16 is refused: too few mantissa bits for the warp */
+  int32_t dtype;       /* FLOAT_DT_FP16 (activations / conv weights), or FLOAT_DT_FP32 = the verification mode (the same launch
+                          chain with 4-byte activations and weights); bf16 is refused: too few mantissa bits for the warp */
   int32_t max_frames;  /* frames decoded per internal batch (sizes the workspace) */
 } float_dec_cfg_t;
 
@@ -174,8 +176,12 @@ int float_dec_frames(float_dec_t* h, const float* s_r, const float* r_d, int32_t
 
 /* The same with the reference's hand-over to host memory (FLOAT.py:139,157-167: frames land in a pre-allocated CPU tensor):
  * frames are rendered into out_hwc (device, n_frames * size * size * 3) and every finished batch of max_frames frames is
- * copied to host_hwc (same layout; pinned host memory for the copy to be asynchronous).
- *   copy_stream == NULL or == stream: the copies are queued on `stream` behind each batch (in order).
+ * copied to host_hwc (same layout).
+ *   host_hwc: PINNED or REGISTERED host memory (hipHostMalloc / hipHostRegister / torch pin_memory), 16-byte aligned, gets
+ *     the fast path: copy workgroups inside the next batch's launches store the frames straight through its device-side
+ *     address (hipPointerGetAttributes decides; nothing is assumed).  Pageable memory is accepted too and takes one
+ *     hipMemcpyAsync behind each batch on `stream` (staged by the runtime, slower, same bytes).
+ *   copy_stream == NULL or == stream: the copies ride along / are queued on `stream` behind each batch (in order).
  *   another stream: the copy of batch i runs there while `stream` renders batch i+1, and `stream` is made to wait for the
  *     last copy before the call returns.  Measured on MI355X / ROCm 7.2 this does NOT pay inside the whole path: the
  *     decode + copy phase drops from 42 to 30 ms per 250 frames, but a device-to-host copy issued on a second stream leaves
@@ -193,12 +199,55 @@ int float_dec_feat_shape(float_dec_t* h, int32_t i, int32_t* channels, int32_t* 
 int float_dec_frames_raw(float_dec_t* h, const float* s_r, const float* r_d, int32_t n_frames,
                          float* out_chw, void* stream);
 
+/* Range check of the 16-bit mode.  fp16 ends at 65504; the operator keeps what it stores small by construction (every
+ * StyledConv's style is divided by its max |s| per frame, the factor goes into the demodulation's epsilon: exact algebra,
+ * dec_kernels.hpp) and COUNTS what still did not fit: such a value is stored as inf and poisons what it touches (loud, not a
+ * plausible-looking wrong frame); every thread keeps the maximum magnitude of the 16-bit values it stores and adds 1 to its
+ * layer's counter per output tile that held an inf / NaN - the count is of (thread, tile) groups of 16..128 values, zero or not
+ * is what matters.
+ *   total: the sum since the handle was created / last reset;  per_site: NULL or FLOAT_DEC_SAT_SITES counters
+ *   ([0..15] output of StyledConv i (0 = conv1, 1 + 2l / 2 + 2l = up-conv / conv of level l), [16 + l] blend of level l,
+ *   [32] constant input, [33] skip features, [34] style vectors with a NaN / inf in them, i.e. a non-finite latent).
+ *   Synchronises `stream`.  A non-zero total means the frames are NOT the reference's: run that checkpoint with dtype
+ *   FLOAT_DT_FP32.  Always 0 in the fp32 mode (except [34]). */
+#define FLOAT_DEC_SAT_SITES 40
+int float_dec_saturation(float_dec_t* h, uint64_t* total, uint64_t* per_site, int32_t reset, void* stream);
+
+/* Test hooks: ONE op of the decoder on caller data through the production kernels and launchers (what the full chain cannot
+ * show: which op is off).  All pointers device fp32; tensors are host fp32 with the reference module's own key names.
+ *   float_dec_debug_styled_conv: StyledConv.forward(x, style) (styledecoder.py:302-325, noise weight 0):
+ *     leaky_relu(ModulatedConv2d(x, style) + bias) * sqrt(2).  keys `sc.conv.weight` (1,cout,cin,3,3),
+ *     `sc.conv.modulation.weight` (cin,style_dim), `sc.conv.modulation.bias` (cin), `sc.activate.bias` (cout).
+ *     x (n_frames,cin,res,res) NCHW, style (n_frames,style_dim), out (n_frames,cout,R',R'), R' = res or 2 res (upsample).
+ *     Which kernel runs follows the production rules: plain conv res >= 16 -> dec_conv16_kernel, below -> dec_conv_kernel;
+ *     up-conv 2 res >= 64 -> dec_zblur_kernel, res >= 8 -> dec_zconv4_kernel + dec_blur_kernel, res = 4 -> per-class
+ *     dec_conv_kernel + dec_blur_kernel.  *saturated = values clamped at +-65504 (fp16).  flags bit 0: no style normalisation.
+ *   float_dec_debug_flow_level: ToFlow (styledecoder.py:399-425) + ToRGB (:368-386) of one level: keys `to_flow.conv.weight`,
+ *     `to_flow.conv.modulation.weight|bias`, `to_flow.bias`, `to_rgb.conv.0.weight`, `to_rgb.conv.1.bias`, `to_rgb.bias`.
+ *     x (F,C,R,R) the conv output, feat (C,R,R) the skip feature (the reference repeats it over the batch), style (F,style_dim),
+ *     prev_flow / prev_rgb (F,3,R/2,R/2) or NULL;  out_flow (F,3,R,R) = ToFlow's `out` before tanh / sigmoid,
+ *     out_blend (F,C,R,R) = feat_warp + x (1 - mask), out_rgb (F,3,R,R) = ToRGB(feat_warp, prev_rgb).  Each output optional. */
+typedef struct {
+  int32_t dtype;      /* FLOAT_DT_FP16 | FLOAT_DT_FP32 */
+  int32_t cin, cout;  /* flow level: cin = C, cout unused */
+  int32_t res;        /* input resolution */
+  int32_t upsample;
+  int32_t n_frames;
+  int32_t style_dim;
+  int32_t flags;
+} float_dec_unit_t;
+int float_dec_debug_styled_conv(const float_dec_unit_t* u, const float_tensor_t* tensors, int32_t n_tensors, const float* x,
+                                const float* style, float* out, uint64_t* saturated, void* stream);
+int float_dec_debug_flow_level(const float_dec_unit_t* u, const float_tensor_t* tensors, int32_t n_tensors, const float* x,
+                               const float* feat, const float* style, const float* prev_flow, const float* prev_rgb,
+                               float* out_flow, float* out_blend, float* out_rgb, void* stream);
+
 /* Direction.forward (styledecoder.py:428-444; FLOAT.py:289-291, nodes_vadv.py:479-533): r_s = lam @ Q^T with
  * Q from the QR of (direction.weight + 1e-8), factorised once at create time.  lam: (motion_dim), r_s: (style_dim). */
 int float_dec_direction(float_dec_t* h, const float* lam, float* r_s, void* stream);
 
-/* Same hand-over without the fp32 round trip: feats16[i] = (R_i, R_i, C_i) NHWC 16-bit device buffers
- * of element type `dtype` (must equal the decoder's), e.g. the ones float_enc_feats16 returns. */
+/* Same hand-over without the fp32 round trip: feats16[i] = (R_i, R_i, C_i) NHWC device buffers of element type `dtype`
+ * (must equal the decoder's: 16-bit, or fp32 in the verification mode), e.g. the ones float_enc_feats16 returns. */
 int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_feats, int32_t dtype,
                           void* stream);
 

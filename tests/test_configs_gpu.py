@@ -54,6 +54,7 @@ def test_full_length_frames_vs_reference(tag):
     mean_err = float((frames.mean(dim=(1, 2, 3)) - f["mean"]).abs().max())
     print("%s frames %s: PSNR %s dB, band mean|d| %.2e, frame-mean err %.2e" % (tag, pick, " ".join("%.1f" % p for p in psnr), band, mean_err))
     assert min(psnr) >= 40.0 and band <= 2.0 / 255 and mean_err < 2e-3
+    assert dec.saturation() == 0
 
 
 def test_sixty_second_clip_full_size():
@@ -90,5 +91,6 @@ def test_sixty_second_clip_full_size():
     shard = dec.decode_latent_into_processed_images(s_r, r_long[:, t0:t1])
     whole_tail = dec.decode_latent_into_processed_images(s_r, r_long[:, 1250:1500])
     assert (t0, t1) == (1313, 1500) and torch.equal(shard, whole_tail[t0 - 1250:])
+    assert dec.saturation() == 0  # 2000 frames decoded, nothing clamped at fp16's range
     print("60 s clip: prefix == 10 s clip bitwise; frames %s PSNR %s dB; window rms %.3f..%.3f" % (
         pick, " ".join("%.1f" % p for p in psnr), float(rms.min()), float(rms.max())))

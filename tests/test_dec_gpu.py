@@ -37,6 +37,7 @@ def test_dec_64_golden(dtype):
         p, m, float((frames - g["frames"]).abs().max()), float((raw - g["raw0"]).abs().max())))
     assert p >= LIMITS[dtype]["psnr"] and m <= LIMITS[dtype]["mean"]
     assert frames.min() >= 0 and frames.max() <= 1
+    assert dec.saturation() == 0  # nothing had to be clamped at fp16's range
 
 
 @pytest.mark.parametrize("dtype", ["fp16"])
@@ -53,10 +54,12 @@ def test_dec_512_golden_lattice(dtype):
     print(dtype, "512px: PSNR %.1f dB mean|d| %.2e max|d| %.2e mean err of means %.2e" % (
         p, m, float((lat - g["lattice"]).abs().max()), float((frames.mean(dim=(1, 2, 3)) - g["mean"]).abs().max())))
     assert p >= LIMITS[dtype]["psnr"] and m <= LIMITS[dtype]["mean"]
+    assert dec.saturation() == 0
 
 
 def test_dec_512_vs_oracle_levels():
-    """Per-level check at full size against the live oracle (one frame): flow and rgb pyramids."""
+    """Full size against the live oracle (one frame, un-clamped output).  The per-op checks against the reference modules are
+    tests/test_dec_units_gpu.py; the per-level logic is held at 1e-4 by the fp32 mode (tests/test_dec_fp32_gpu.py)."""
     sd = W.synth_decoder_state(512, seed=3)
     feats = W.synth_feats(512, seed=3)
     gen = torch.Generator().manual_seed(5)
@@ -116,6 +119,29 @@ def test_decode_into_host_equals_decode(side_stream):
     assert torch.equal(host, want) and torch.equal(staging.cpu(), want)
     with pytest.raises(ValueError):
         dec.decode_into_host(s_r, r_d, torch.empty(10, 64, 64, 3))
+
+
+def test_decode_into_pageable_host():
+    """a destination that is NOT pinned must not be written by the copy workgroups (a kernel storing to an
+    unmapped host address is a GPU fault).  float_dec_frames_host asks hipPointerGetAttributes and sends pageable memory through
+    hipMemcpyAsync behind each batch: same frames, several batches."""
+    sd = W.synth_decoder_state(64, seed=4)
+    feats = W.synth_feats(64, seed=4)
+    gen = torch.Generator().manual_seed(1)
+    s_r, r_d = torch.randn(1, 512, generator=gen), torch.randn(1, 11, 512, generator=gen) * 0.5
+    dec = pkg.decoder.SynthesisHIP(sd, 64, 512, "cuda:0", max_frames=4)  # 11 frames -> 3 batches
+    want = dec.decode_latent_into_processed_images(s_r, r_d, feats).cpu()
+    host = torch.full((11, 64, 64, 3), -1.0)
+    assert not host.is_pinned()
+    dec.decode_into_host(s_r, r_d, host)
+    torch.cuda.current_stream().synchronize()
+    assert torch.equal(host, want)
+    # a pinned tensor viewed at an offset that is not 16-byte aligned takes the same path
+    big = torch.full((11 * 64 * 64 * 3 + 1,), -1.0).pin_memory()
+    off = big[1:].view(11, 64, 64, 3)
+    dec.decode_into_host(s_r, r_d, off)
+    torch.cuda.current_stream().synchronize()
+    assert torch.equal(off, want)
 
 
 def test_set_feats_validates_every_map():

@@ -78,8 +78,3 @@ def test_batched_and_runge_kutta_fp32():
     got = fmt.sample(cs[0]["r_s"], cs[0]["wa"], cs[0]["we"], noise[:, :1], 3).cpu()
     ref = O.sample_rd(sd, cfg, cs[0]["r_s"], cs[0]["wa"], cs[0]["we"], noise[:, :1], 3, 2.0, 1.0, 1.0, method="rk4")
     assert rel_l2(got, ref) < TOL
-
-
-def test_other_operators_refuse_fp32():
-    with pytest.raises(ValueError):
-        pkg.decoder.SynthesisHIP(W.synth_decoder_state(64, seed=1), 64, 512, "cuda:0", dtype="fp32")

@@ -11,12 +11,12 @@ pkg = load_pkg()
 def test_library_exports_header_symbols():
     hdr = open(os.path.join(ROOT, "include", "float_hip.h")).read()
     declared = set(re.findall(r"\b(float_[a-z_0-9]+)\s*\(", hdr))
-    declared -= {"float_tensor_t", "float_fmt_cfg_t", "float_dec_cfg_t"}
+    declared -= {"float_tensor_t", "float_fmt_cfg_t", "float_dec_cfg_t", "float_dec_unit_t"}
     assert declared == set(pkg.native.EXPORTS), declared ^ set(pkg.native.EXPORTS)
     L = pkg.native.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.float_hip_abi_version() == 2  # v2: float_fmt_cfg_t.max_batch, FLOAT_DT_FP32, batch / host hand-over / reserve / debug entries
+    assert L.float_hip_abi_version() == 3  # v3: fp32 decoder, float_dec_saturation, float_dec_debug_* unit ops
 
 
 def test_product_does_not_import_oracle():

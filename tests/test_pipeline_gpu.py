@@ -77,3 +77,4 @@ def test_config1_golden_end_to_end(fmt_dtype, min_psnr):
     print("config1 %s: r_d rel-L2 %.3e, lattice PSNR %.1f dB, frame-mean err %.2e" % (fmt_dtype, e_rd, psnr, mean_err))
     assert frames.shape == (25, 512, 512, 3) and mean_err < 2e-3
     assert e_rd < (2e-2 if fmt_dtype == "bf16" else 4e-3) and psnr >= min_psnr
+    assert hp.dec.saturation() == 0

@@ -294,6 +294,88 @@ def gen_dec(ns, size, seed, n_frames, sparse):
     save("dec_%d" % size, **arrs)
 
 
+def gen_dec_units_hip(ns, seed):
+    """Unit ops at shapes the HIP kernels take (channels in multiples of 32), one case per kernel route of
+    float_dec_debug_styled_conv / float_dec_debug_flow_level.  Inputs are regenerated from the seeds by the tests
+    (tests/test_dec_units_gpu.py); the fixture holds the reference modules' outputs."""
+    print("[decoder unit ops, kernel shapes]")
+    S = ns.styledecoder
+    arrs = dict(seed=seed)
+    F = 2
+    style = rnd(seed + 1, F, 512)
+    cases = (("plain8", 64, 32, 8, False), ("plain32", 64, 64, 32, False), ("up4", 64, 32, 4, True), ("up8", 64, 32, 8, True),
+             ("up32", 32, 32, 32, True))
+    arrs["sc_cases"] = np.array([[c[1], c[2], c[3], int(c[4])] for c in cases])
+    for i, (name, cin, cout, R, up) in enumerate(cases):
+        sc = S.StyledConv(cin, cout, 3, 512, upsample=up)
+        k = seed + 100 * (i + 1)
+        w, mw, mb, ab = rnd(k + 2, 1, cout, cin, 3, 3), rnd(k + 3, cin, 512), 1 + rnd(k + 4, cin, std=0.1), rnd(k + 5, 1, cout, 1, 1, std=0.1)
+        sc.conv.weight.data.copy_(w)
+        sc.conv.modulation.weight.data.copy_(mw)
+        sc.conv.modulation.bias.data.copy_(mb)
+        sc.activate.bias.data.copy_(ab.reshape(sc.activate.bias.shape))
+        sc.noise.weight.data.zero_()
+        x = rnd(k + 6, F, cin, R, R)
+        with torch.no_grad():
+            ref = sc(x, style)
+        sd = {"c.conv.weight": w, "c.conv.modulation.weight": mw, "c.conv.modulation.bias": mb, "c.activate.bias": ab}
+        orc = O.styled_conv(x, style, sd, "c", up)
+        print("  styled_conv %-8s oracle-ref max|d| %.3e rel %.3e  out std %.3f" % ((name,) + maxdiff(orc, ref) + (float(ref.std()),)))
+        arrs["sc_%s_out" % name] = ref
+    for j, (name, C, R, prev) in enumerate((("c32", 32, 16, True), ("c128", 128, 32, False))):
+        k = seed + 1000 * (j + 1)
+        tf, tr = S.ToFlow(C, 512), S.ToRGB(C, 512)
+        fb, fw = rnd(k + 6, 1, 3, 1, 1, std=0.1), rnd(k + 7, 1, 3, C, 1, 1, std=0.3)
+        fmw, fmb = rnd(k + 8, C, 512), 1 + rnd(k + 9, C, std=0.1)
+        rb, rw, rb1 = rnd(k + 13, 1, 3, 1, 1, std=0.1), rnd(k + 14, 3, C, 1, 1), rnd(k + 15, 1, 3, 1, 1, std=0.1)
+        tf.bias.data.copy_(fb)
+        tf.conv.weight.data.copy_(fw)
+        tf.conv.modulation.weight.data.copy_(fmw)
+        tf.conv.modulation.bias.data.copy_(fmb)
+        tr.bias.data.copy_(rb)
+        tr.conv[0].weight.data.copy_(rw)
+        tr.conv[1].bias.data.copy_(rb1.reshape(tr.conv[1].bias.shape))
+        x, feat = rnd(k + 10, F, C, R, R), rnd(k + 11, 1, C, R, R)
+        pflow = rnd(k + 12, F, 3, R // 2, R // 2, std=0.5) if prev else None
+        prgb = rnd(k + 16, F, 3, R // 2, R // 2) if prev else None
+        with torch.no_grad():
+            fwarp, blend, o3, grid = tf(x, style, feat.repeat(F, 1, 1, 1), pflow)
+            rgb = tr(fwarp, prgb)
+        print("  flow level %-5s out std %.3f blend std %.3f rgb std %.3f" % (name, float(o3.std()), float(blend.std()), float(rgb.std())))
+        arrs.update({"fl_%s_out" % name: o3, "fl_%s_blend" % name: blend, "fl_%s_rgb" % name: rgb})
+    arrs["fl_cases"] = np.array([[32, 16, 1], [128, 32, 0]])
+    save("dec_units_hip", **arrs)
+
+
+def gen_dec_stress(ns, size, seed, kind, sparse):
+    """Hard cases for the 16-bit decoder (weights.stress_decoder): the reference Synthesis on a full-range warp over white-noise
+    features, and on styles of +-300 with activations of 1e2..1e4 (where an unnormalised fp16 decoder overflows)."""
+    print("[decoder stress %s, size %d]" % (kind, size))
+    sd, feats = weights.stress_decoder(size, seed=seed, kind=kind)
+    d = ns.styledecoder.Synthesis(size, 512, 20)
+    d.load_state_dict(sd, strict=True)
+    d.eval()
+    s_r = rnd(seed + 21, 1, 512)
+    r_d = rnd(seed + 22, 1, 2, 512, std=0.5)
+    raws = []
+    with torch.no_grad():
+        for t in range(r_d.shape[1]):
+            raws.append(d(s_r + r_d[:, t], None, feats)[0])
+    raw = torch.cat(raws)
+    o32 = torch.cat([O.synthesis(sd, s_r + r_d[:, t], feats) for t in range(r_d.shape[1])])
+    o64 = torch.cat([O.synthesis(sd, s_r + r_d[:, t], feats, dtype=torch.float64) for t in range(r_d.shape[1])])
+    print("  raw std %.3e max %.3e ; oracle32-ref max|d| %.3e ; ref-oracle64 max|d| %.3e rel %.3e" % (
+        float(raw.std()), float(raw.abs().max()), maxdiff(o32, raw)[0], maxdiff(raw, o64.float())[0], maxdiff(raw, o64.float())[1]))
+    arrs = dict(seed=seed, size=size, s_r=s_r, r_d=r_d, raw_std=float(raw.std()), ref_vs_f64_max=maxdiff(raw, o64.float())[0],
+                ref_vs_f64_rel=maxdiff(raw, o64.float())[1])
+    if sparse:
+        arrs["raw_lattice"] = raw[:, :, ::7, ::5]
+        arrs["raw_band"] = raw[:, :, 250:258]
+    else:
+        arrs["raw"] = raw
+    save("dec_stress_%s_%d" % (kind, size), **arrs)
+
+
 def gen_e2e_config1(ns, seed=900):
     """BASELINE.json configs[0]: 1 s audio -> 25 frames, 512x512, nfe=10 (9 Euler evaluations), fp32, the
     reference's own sampler (nodes_adv.py:545-694) and decode loop (FLOAT.py:113-169) chained on CPU."""
@@ -514,6 +596,13 @@ def main():
         gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
         gen_audio(ns, "base", config.AudioConfig(), seed=1300, seconds=2.0, T=50)
         return
+    if os.environ.get("GOLDENS_ONLY") == "decx":
+        gen_dec_units_hip(ns, seed=1600)
+        gen_dec_stress(ns, 64, 1700, "warp", sparse=False)
+        gen_dec_stress(ns, 64, 1710, "range", sparse=False)
+        gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
+        gen_dec_stress(ns, 512, 1730, "range", sparse=True)
+        return
     if os.environ.get("GOLDENS_ONLY") == "enc":
         gen_encoder(ns, 64, seed=1000, sparse=False)
         gen_encoder(ns, 512, seed=1100, sparse=True)
@@ -540,6 +629,11 @@ def main():
     gen_dec_units(ns, seed=600)
     gen_dec(ns, 64, seed=700, n_frames=3, sparse=False)
     gen_dec(ns, 512, seed=800, n_frames=2, sparse=True)
+    gen_dec_units_hip(ns, seed=1600)
+    gen_dec_stress(ns, 64, 1700, "warp", sparse=False)
+    gen_dec_stress(ns, 64, 1710, "range", sparse=False)
+    gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
+    gen_dec_stress(ns, 512, 1730, "range", sparse=True)
     gen_encoder(ns, 64, seed=1000, sparse=False)
     gen_encoder(ns, 512, seed=1100, sparse=True)
     gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
