@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """Benchmark of the FLOAT audio -> talking-portrait path on MI355X.
 
-One "step" = one clip end to end: a 512x512 portrait and `--seconds` of 16 kHz audio, both resident in HBM, through
-every operator of the path - appearance encoder, wav2vec2 audio encoder, FMT sampling (`--nfe` grid points: default 51 =
-50 Euler evaluations per 50-frame window, 3-way CFG a=2 e=1), Synthesis decoder - to `T` fp32 frames in pinned HOST
-memory (the reference's destination, FLOAT.py:139; every finished batch of frames is copied behind its last kernel).  `value` = frames of all ranks / wall-clock of the timed steps.  The FMT sampling + decode part alone (frames left
-in HBM: round 1's headline) is reported beside it as `hot_path`.
+One "step" = one clip end to end through the PRODUCT's own call, `InferenceAgent.infer_device` (what `run_inference` and the
+FLOAT Process node run after their host-side image / audio plumbing): a 512x512 portrait and `--seconds` of 16 kHz audio, both
+resident in HBM, through every operator of the path - appearance encoder, wav2vec2 audio encoder, noise draw, FMT sampling
+(`--nfe` grid points: default 51 = 50 Euler evaluations per 50-frame window, 3-way CFG a=2 e=1), Synthesis decoder - to `T`
+fp32 frames in a freshly allocated pinned HOST tensor (the reference's destination, FLOAT.py:139; the frames of decode batch i
+leave inside the launches of batch i+1), stream synchronised.  `value` = frames of all ranks / wall-clock of the timed steps.
+The FMT sampling + decode part alone (frames left in HBM: round 1's headline) is reported beside it as `hot_path`, and the same
+step with bf16 FMT operands (BASELINE.json's wording for configs[1]) as `value_bf16`.
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -40,8 +43,8 @@ MFMA_PEAK_TFLOPS = 2500.0              # dense bf16/fp16
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=100, help="default: >= 10 s of timed GPU work")
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--seconds", type=float, default=10.0)
     ap.add_argument("--nfe", type=int, default=51, help="Euler grid points; evaluations = nfe-1")
     ap.add_argument("--size", type=int, default=512)
@@ -56,6 +59,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stage split / hot-path side numbers")
+    ap.add_argument("--no-bf16", action="store_true", help="skip the second measurement with bf16 FMT operands")
     return ap.parse_args()
 
 
@@ -178,12 +182,18 @@ def main():
     T = int(math.ceil(args.seconds * fps_video))
     fmt_sd = pkg.weights.synth_fmt_state(cfg, seed=1)
     dec_sd = pkg.weights.synth_decoder_state(args.size, seed=1)
-    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, dev, args.size, args.fmt_dtype, args.dec_dtype,
-                                   args.max_frames, use_graph=0 if args.no_graph else 2)
-    enc = pkg.encoder.EncoderHIP(pkg.weights.synth_encoder_state(args.size, seed=1), args.size, cfg.dim_w, 20, dev,
-                                 args.dec_dtype, direction_weight=dec_sd["direction.weight"])
+    # the product object: the agent the Load FLOAT Models node builds (src/nodes/generate.py), on seeded weights of the
+    # checkpoint's shapes (wav2vec2-base audio encoder; no speech-emotion model: the clip's emotion is a label)
+    import importlib
+    gen = importlib.import_module(pkg.__name__ + ".src.nodes.generate")
+    opt = importlib.import_module(pkg.__name__ + ".src.nodes.options.base_options").BaseOptions()
+    opt.nfe, opt.input_size, opt.fps, opt.rank = args.nfe, args.size, fps_video, dev
     acfg = pkg.config.AudioConfig()
-    aud = pkg.audio.AudioEncoderHIP(pkg.weights.synth_audio_state(acfg, seed=1), acfg, dev, args.dec_dtype)
+    parts = dict(enc=pkg.weights.synth_encoder_state(args.size, seed=1), dec=dec_sd, fmt=fmt_sd,
+                 audio_encoder=(pkg.weights.synth_audio_state(acfg, seed=1), acfg))
+    agent = gen.InferenceAgent(opt, parts, dev, max_frames=args.max_frames, use_graph=0 if args.no_graph else 2,
+                               fmt_dtype=args.fmt_dtype, dec_dtype=args.dec_dtype)
+    hp, enc, aud = agent.G, agent.enc, agent.audio_encoder
 
     one_clip = args.mode in ("shard", "window") and world > 1
     T_total = T * world if one_clip else T
@@ -201,9 +211,11 @@ def main():
         w0, w1 = pkg.distributed.window_shard(hp.n_chunks(T_total), world, rank)
         t0f, t1f = w0 * L, min(T_total, w1 * L)
     n_local = t1f - t0f
-    host = torch.empty(n_local, args.size, args.size, 3, dtype=torch.float32, pin_memory=True)
-    staging = torch.empty(n_local, args.size, args.size, 3, dtype=torch.float32, device=dev)
     seam = {}
+    product = world == 1 or args.mode == "replicas"  # the agent's call; shard / window drive the operators themselves
+    if args.dynamic_we:
+        product = False  # per-window emotion comes from the VA sampler node, not from run_inference
+    last = {}
 
     def conditioning():
         s_r, _, _, r_s = enc.encode_image_into_latent(img, want_feats=False)
@@ -213,15 +225,20 @@ def main():
 
     def step():
         """(image, waveform) in HBM -> this rank's frames in pinned host memory."""
+        last.pop("host", None)  # the previous result is released first, as a caller that consumed it would have
+        if product:
+            last["host"] = agent.infer_device(img, wav, a_cfg, 1.0, e_cfg, emo="neutral", seed=15)
+            return
         s_r, r_s, wa = conditioning()
         if args.mode == "window" and world > 1:
             r_loc, _, rep = pkg.distributed.sample_window_parallel(hp.fmt, cfg, r_s, wa, we, noise, args.nfe, a_cfg, 1.0, e_cfg,
                                                                    iters=args.window_iters)
             seam.update(rep)
-            hp.dec.decode_into_host(s_r, r_loc[0], host, staging)
-            return
-        r_d = hp.sample(r_s, wa, we, args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
-        hp.dec.decode_into_host(s_r, r_d[0, t0f:t1f], host, staging)
+            last["host"] = hp.decode_to_host(s_r, r_loc[0])
+        else:
+            r_d = hp.sample(r_s, wa, we, args.nfe, a_cfg, 1.0, e_cfg, noise=noise)
+            last["host"] = hp.decode_to_host(s_r, r_d[0, t0f:t1f])
+        torch.cuda.current_stream(dev).synchronize()
 
     def barrier():
         torch.cuda.synchronize()
@@ -245,9 +262,13 @@ def main():
             t = torch.as_tensor(seam.get("seam_rel_change", 0.0)).reshape(1).to(dev if backend == "nccl" else "cpu", torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             seam["seam_rel_change"] = float(t.item())
+    host = last["host"]
+    assert host.shape[0] == n_local and host.is_pinned()
     assert float(host[0].min()) >= 0.0 and float(host[-1].max()) <= 1.0 and float(host.mean()) > 0.0
+    assert hp.dec.saturation() == 0, "the fp16 decoder clamped activations: frames are not the reference's"
     frames_per_step = T_total if one_clip else T * world
     fps = frames_per_step * args.steps / elapsed
+    staging = hp.staging(n_local)
 
     extra, warnings = {}, []
     if rank == 0 and not args.no_extras:
@@ -331,6 +352,23 @@ def main():
         extra["kernel_class_ms"] = {"fmt_gemm": round(gemm_total_ms, 2), "dec_conv": round(conv_total_ms, 2),
                                     "fmt_adaln_gemm": round(mod_total_ms, 2)}
 
+    # the same step with bf16 FMT operands (BASELINE.json names bf16 for configs[1]; it fails the 40 dB frame tolerance -
+    # tests/test_pipeline_gpu.py - so the headline type is fp16, same MFMA rate): measured in the same run
+    bf16 = None
+    if rank == 0 and world == 1 and product and not args.no_bf16 and args.fmt_dtype != "bf16":
+        fmt_keep = hp.fmt
+        hp.fmt = pkg.fmt.FlowMatchingTransformerHIP(fmt_sd, cfg, dev, "bf16", 0 if args.no_graph else 2, 1)
+        k = max(3, min(20, args.steps))
+        step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        bf16 = {"value_bf16": round(T * k / el, 3), "ms_per_step_bf16": round(el / k * 1e3, 3), "steps_bf16": k}
+        hp.fmt = fmt_keep
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(pkg, torch, cfg, fmt_sd, dec_sd, pkg.weights.synth_feats(args.size, seed=1), cond, args.nfe - 1)
@@ -348,15 +386,18 @@ def main():
             "vs_baseline": None,
             "dtype": "%s+%s" % (args.fmt_dtype, args.dec_dtype) if args.fmt_dtype != args.dec_dtype else args.fmt_dtype,
             "data": "synthetic",
-            "config": {"workload": "configs[%d]: %.0f s audio + %dx%d portrait in HBM -> %d frames in pinned host memory; appearance "
-                                   "encoder + wav2vec2 audio encoder + FMT sampling (%d Euler evaluations/window, CFG a=%.1f e=%.1f%s) "
-                                   "+ decode + D2H"
-                                   % (4 if args.dynamic_we else 1, args.seconds * (world if one_clip else 1), args.size, args.size,
-                                      T_total, args.nfe - 1, a_cfg, e_cfg, ", dynamic per-window emotion" if args.dynamic_we else ""),
+            "config": {"workload": ("configs[%d]: %.0f s audio + %dx%d portrait in HBM -> %d frames in pinned host memory; appearance "
+                                    "encoder + wav2vec2 audio encoder + FMT sampling (%d Euler evaluations/window, CFG a=%.1f e=%.1f%s) "
+                                    "+ decode + D2H"
+                                    % (4 if args.dynamic_we else 1, args.seconds * (world if one_clip else 1), args.size, args.size,
+                                       T_total, args.nfe - 1, a_cfg, e_cfg, ", dynamic per-window emotion" if args.dynamic_we else ""))
+                                   + (", through InferenceAgent.infer_device (the product call)" if product else ""),
                        "nfe": args.nfe, "frames_per_clip": T_total, "fmt_dtype": args.fmt_dtype, "dec_dtype": args.dec_dtype,
                        "decode_batch": args.max_frames, "hip_graph": not args.no_graph, "parallelism": par},
         }
         out.update(extra)
+        if bf16:
+            out.update(bf16)
         if roof:
             out["roofline"] = roof[0]
             out["roofline_secondary"] = roof[1]

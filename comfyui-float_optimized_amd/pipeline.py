@@ -41,6 +41,47 @@ class FloatHotPath:
             rd = rd[frame_range[0]:frame_range[1]]
         return self.dec.decode_latent_into_processed_images(s_r, rd)
 
+    def staging(self, n_frames):
+        """Device-side frame buffer of float_dec_frames_host, cached per clip length (786 MB for 250 frames at 512 px;
+        sized for 288 GB).  The host side is NOT cached: callers get a fresh pinned tensor (torch's caching host allocator
+        hands the block of a released earlier result back without a new hipHostMalloc), because ComfyUI keeps node outputs
+        alive across executions and a re-used buffer would silently overwrite them."""
+        cache = self.__dict__.setdefault("_staging", {})
+        shape = (n_frames, self.size, self.size, 3)
+        if shape not in cache:
+            cache.clear()  # one clip length at a time
+            cache[shape] = torch.empty(shape, device=self.device, dtype=torch.float32)
+        return cache[shape]
+
+    @torch.no_grad()
+    def decode_to_host(self, s_r, r_d, feats=None, frame_range=None, out=None):
+        """Frames of one clip (r_d (T,512)) into pinned host memory through float_dec_frames_host: the frames of batch i cross
+        PCIe inside the launches of batch i+1.  Returns the host tensor (T,H,W,3); it is complete once the current stream has
+        been synchronised (the callers that hand it to the user do that)."""
+        if feats is not None:
+            self.dec.set_feats(feats)
+        rd = r_d[0] if r_d.dim() == 3 else r_d
+        if frame_range is not None:
+            rd = rd[frame_range[0]:frame_range[1]]
+        n = rd.shape[0]
+        if out is None:
+            out = torch.empty((n, self.size, self.size, 3), dtype=torch.float32, pin_memory=True)
+        self.dec.decode_into_host(s_r, rd, out, self.staging(n))
+        return out
+
+    @torch.no_grad()
+    def generate_to_host(self, r_s, wa, we, s_r, feats, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, seed=15,
+                         noise=None, frame_range=None, out=None, return_rd=False):
+        """The product's hot path for one clip (B = 1): conditioning tensors in HBM -> frames in pinned host memory, the
+        reference's destination (FLOAT.py:139,157-167).  This is what InferenceAgent.run_inference, FloatProcess and bench.py run."""
+        if feats is not None:
+            self.dec.set_feats(feats)
+        if noise is None:
+            noise = draw_noise(self.n_chunks(wa.shape[1]), 1, self.cfg, seed)
+        r_d = self.sample(r_s, wa, we, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale, seed, noise)
+        host = self.decode_to_host(s_r, r_d, None, frame_range, out)
+        return (host, r_d) if return_rd else host
+
     @torch.no_grad()
     def generate(self, r_s, wa, we, s_r, feats, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, seed=15,
                  noise=None, overlap=False, frame_range=None, return_rd=False):

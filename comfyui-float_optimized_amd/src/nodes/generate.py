@@ -36,7 +36,7 @@ def split_unified(state):
 
 
 class InferenceAgent:
-    def __init__(self, opt, parts=None, device=None):
+    def __init__(self, opt, parts=None, device=None, max_frames=32, use_graph=2, fmt_dtype=None, dec_dtype=None):
         self.opt = opt
         self.rank = torch.device(device if device is not None else getattr(opt, "rank", "cuda:0"))
         self.cfg = FmtConfig.from_options(opt)
@@ -47,8 +47,9 @@ class InferenceAgent:
         # bf16 at the same rate (end-to-end 48.7 vs 34.1 dB on BASELINE configs[0]); FLOAT_AMD_FMT_DTYPE=bf16
         # selects the type BASELINE configs[1] names.
         self.G = FloatHotPath(parts["fmt"], parts["dec"], self.cfg, self.rank, opt.input_size,
-                              fmt_dtype=os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
-                              dec_dtype=os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"))
+                              fmt_dtype=fmt_dtype or os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
+                              dec_dtype=dec_dtype or os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"), max_frames=max_frames,
+                              use_graph=use_graph)
         self.G.fmt.set_method(getattr(opt, "torchdiffeq_ode_method", "euler"))
         # appearance encoder + Encoder.fc + Direction as one HIP operator (float_enc_*); same 16-bit type as the
         # decoder so the skip features go to it without an fp32 round trip
@@ -95,18 +96,13 @@ class InferenceAgent:
 
     # ------------------------------------------------------------------ inference
     @torch.no_grad()
-    def conditions(self, ref_img, ref_audio, emo=None, no_crop=True):
-        """Once-per-clip stage, all on HIP operators: image -> (s_r, feats, r_s), audio -> (wa, T), and for any `emo` that
-        is not one of the seven labels (None, 'none', 'S2E', ...) the speech-emotion scores (FLOAT.py:196-198)."""
+    def conditions_device(self, s, a, emo=None):
+        """Once-per-clip stage on HIP operators, inputs already in HBM: s (1,3,H,W) in [-1,1] -> (s_r, feats handed to the
+        decoder, r_s); a (N,) the normalised 16 kHz waveform -> (wa, T); and for any `emo` that is not one of the seven labels
+        (None, 'none', 'S2E', ...) the speech-emotion scores (FLOAT.py:196-198)."""
         o = self.opt
-        img = ref_img[0] if ref_img.dim() == 4 else ref_img
-        if not no_crop:  # generate.py:77-78
-            img, _ = host_models.process_img(img[..., :3].float(), o.input_size, getattr(o, "face_margin", 1.6), logger=main_logger)
-        s = host_models.preprocess_image(img, o.input_size).to(self.rank)
-        a = host_models.preprocess_audio(ref_audio["waveform"][0], ref_audio["sample_rate"], o.sampling_rate).to(self.rank)
         s_r, _, _, r_s = self.enc.encode_image_into_latent(s, want_feats=False)  # FLOAT.py:283-291
         self.enc.hand_feats_to(self.G.dec)
-        feats = None  # already in the decoder (NHWC 16-bit)
         T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
         wa = self.audio_encoder.inference(a, seq_len=T)
         if host_models.emotion_index(emo) is None:
@@ -117,18 +113,41 @@ class InferenceAgent:
             we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
         else:
             we = host_models.emotion_one_hot(emo, self.rank)
-        return dict(s_r=s_r, feats=feats, r_s=r_s, wa=wa, we=we, T=T)
+        return dict(s_r=s_r, feats=None, r_s=r_s, wa=wa, we=we, T=T)  # feats: already in the decoder (NHWC 16-bit)
+
+    def host_inputs(self, ref_img, ref_audio, no_crop=True):
+        """Host plumbing of the reference's DataProcessor (generate.py:34-81): optional face crop, area resize to the model
+        size, [-1,1]; mono, resample to 16 kHz, normalise.  Returns (s (1,3,H,W), a (N,)) on the device."""
+        o = self.opt
+        img = ref_img[0] if ref_img.dim() == 4 else ref_img
+        if not no_crop:  # generate.py:77-78
+            img, _ = host_models.process_img(img[..., :3].float(), o.input_size, getattr(o, "face_margin", 1.6), logger=main_logger)
+        s = host_models.preprocess_image(img, o.input_size).to(self.rank)
+        a = host_models.preprocess_audio(ref_audio["waveform"][0], ref_audio["sample_rate"], o.sampling_rate).to(self.rank)
+        return s, a
+
+    @torch.no_grad()
+    def conditions(self, ref_img, ref_audio, emo=None, no_crop=True):
+        s, a = self.host_inputs(ref_img, ref_audio, no_crop)
+        return self.conditions_device(s, a, emo)
+
+    @torch.no_grad()
+    def infer_device(self, s, a, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, emo="S2E", seed=25, out=None):
+        """Portrait and waveform in HBM -> (T,H,W,3) fp32 frames in [0,1] in pinned host memory: every operator of the path and
+        the hand-over (frames of decode batch i leave inside the launches of batch i+1, float_dec_frames_host).  bench.py
+        times exactly this call.  Like the reference, the grid size comes from opt.nfe (FLOAT.py:188)."""
+        c = self.conditions_device(s, a, emo)
+        n_chunks = int(math.ceil(c["T"] / self.cfg.num_frames_for_clip))
+        noise = draw_noise(n_chunks, 1, self.cfg, seed if seed is not None else self.opt.seed)
+        host = self.G.generate_to_host(c["r_s"], c["wa"], c["we"], c["s_r"], None, self.opt.nfe, a_cfg_scale, r_cfg_scale,
+                                       e_cfg_scale, noise=noise, out=out)
+        torch.cuda.current_stream(self.rank).synchronize()  # the frames are in host memory
+        return host
 
     @torch.no_grad()
     def run_inference(self, res_video_path, ref_img, ref_audio, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0,
                       emo="S2E", nfe=10, no_crop=False, seed=25):
-        """Reference signature (generate.py:154-173).  Returns (T,H,W,3) fp32 in [0,1] on the CPU.
+        """Reference signature (generate.py:154-173).  Returns (T,H,W,3) fp32 in [0,1] on the CPU (pinned).
         Like the reference, the grid size comes from opt.nfe, not from the `nfe` argument (FLOAT.py:188)."""
-        c = self.conditions(ref_img, ref_audio, emo, no_crop=no_crop)
-        n_chunks = int(math.ceil(c["T"] / self.cfg.num_frames_for_clip))
-        noise = draw_noise(n_chunks, 1, self.cfg, seed if seed is not None else self.opt.seed)
-        frames = self.G.generate(c["r_s"], c["wa"], c["we"], c["s_r"], c["feats"], self.opt.nfe, a_cfg_scale, r_cfg_scale,
-                                 e_cfg_scale, noise=noise)
-        host = torch.empty(frames.shape, dtype=torch.float32, pin_memory=frames.is_cuda)
-        host.copy_(frames)  # one D2H for the clip instead of one per frame (FLOAT.py:153,166)
-        return host
+        s, a = self.host_inputs(ref_img, ref_audio, no_crop)
+        return self.infer_device(s, a, a_cfg_scale, r_cfg_scale, e_cfg_scale, emo, seed)

@@ -119,4 +119,6 @@ class FloatProcess:
         else:
             cat = torch.cat([w.squeeze(0) for w in used_audio], dim=1).unsqueeze(0)
             out_audio = {'waveform': cat.to(audio_waveform.device), 'sample_rate': audio_sample_rate}
-        return (torch.cat(all_images, dim=0), out_audio, fps,)
+        # one item: hand the agent's (pinned) tensor on as it is - torch.cat would copy 786 MB for nothing
+        images = all_images[0] if target_batch_size == 1 else torch.cat(all_images, dim=0)
+        return (images, out_audio, fps,)

@@ -171,11 +171,16 @@ class ApplyFloatSynthesis:
         size = float_synthesis.inferred_size
         if r_d_latents.shape[1] == 0:
             return (torch.empty((0, size, size, BaseOptions().input_nc), dtype=torch.float32), float_synthesis)
-        out = []
-        for b in range(B):  # nodes_vadv.py:437-462: frame t of item b decodes s_r[b] + r_d[b, t]
-            frames = float_synthesis.decode_latent_into_processed_images(s_r[b:b + 1], r_d_latents[b], [f[b:b + 1] for f in feats])
-            out.append(frames.cpu())
-        return (torch.cat(out, dim=0), float_synthesis)
+        # nodes_vadv.py:437-462: frame t of item b decodes s_r[b] + r_d[b, t].  The frames of every item land in ONE pinned host
+        # tensor through float_dec_frames_host (the reference's pre-allocated CPU tensor, FLOAT.py:139), item b at rows b*T..
+        T = r_d_latents.shape[1]
+        host = torch.empty((B * T, size, size, BaseOptions().input_nc), dtype=torch.float32, pin_memory=True)
+        staging = None
+        for b in range(B):
+            float_synthesis.set_feats([f[b:b + 1] for f in feats])
+            staging = float_synthesis.decode_into_host(s_r[b:b + 1], r_d_latents[b], host[b * T:(b + 1) * T], staging)
+        torch.cuda.current_stream(float_synthesis.device).synchronize()
+        return (host, float_synthesis)
 
 
 class FloatAudioPreprocessAndFeatureExtract:

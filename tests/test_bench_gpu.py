@@ -10,7 +10,7 @@ import pytest
 from tests.util import ROOT
 
 pytestmark = pytest.mark.gpu
-SHORT = ["--seconds", "2", "--nfe", "6", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"]
+SHORT = ["--seconds", "2", "--nfe", "6", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-bf16"]
 
 
 def _run(args, env=None):

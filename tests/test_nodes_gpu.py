@@ -71,3 +71,27 @@ def test_float_process_errors(pipe):
     with pytest.raises(ValueError):
         pkg.NODE_CLASS_MAPPINGS["LoadFloatModelsOpt"]().loadmodel("x.safetensors", "cuda:0", False,
                                                                   {"torchdiffeq_ode_method": "dopri5"})
+
+
+def test_node_path_is_the_bench_path(pipe):
+    """the product must run what bench.py times.  FloatProcess -> InferenceAgent.run_inference ->
+    infer_device (the call bench.py times) -> FloatHotPath.generate_to_host -> float_dec_frames_host: the frames the node
+    returns are bit for bit those of infer_device on the same device-resident inputs, and those of the plain device-side decode
+    (float_dec_frames) copied out afterwards; the result is a pinned host tensor, and a second clip does not overwrite the
+    first one's frames (ComfyUI keeps node outputs alive)."""
+    img, audio = _inputs()
+    node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    images, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    assert images.is_pinned() and images.shape == (25, 512, 512, 3)
+    keep = images.clone()
+    s, a = pipe.host_inputs(img, audio, no_crop=True)
+    direct = pipe.infer_device(s, a, 2.0, pipe.opt.r_cfg_scale, 1.0, emo="happy", seed=7)
+    assert torch.equal(direct, images)
+    # the same clip through the device-side entry points
+    c = pipe.conditions_device(s, a, "happy")
+    noise = pkg.fmt.draw_noise(1, 1, pipe.cfg, 7)
+    frames = pipe.G.generate(c["r_s"], c["wa"], c["we"], c["s_r"], None, pipe.opt.nfe, 2.0, pipe.opt.r_cfg_scale, 1.0, noise=noise)
+    assert torch.equal(frames.cpu(), images)
+    other, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 8)
+    assert torch.equal(images, keep) and not torch.equal(other, images)
+    assert pipe.G.dec.saturation() == 0
