@@ -956,8 +956,10 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
       size_t lru = 0;
       for (size_t i = 1; i < h->graphs.size(); ++i)
         if (h->graphs[i].used < h->graphs[lru].used) lru = i;
-      // an executable that is still queued on a stream must not be destroyed under it
-      FH_CHECK_HIP(hipStreamSynchronize(s));
+      // an executable that is still queued must not be destroyed under it - and it may be queued on ANOTHER stream than `s`
+      // (the window sampler and the overlapped pipeline run the chain on side streams): eviction is rare (a ninth distinct
+      // chain shape), so wait for the whole device
+      FH_CHECK_HIP(hipDeviceSynchronize());
       (void)hipGraphExecDestroy(h->graphs[lru].exec);
       h->graphs.erase(h->graphs.begin() + lru);
     }

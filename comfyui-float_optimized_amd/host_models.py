@@ -38,6 +38,14 @@ def resample_sinc(w, orig_rate, new_rate, zeros=24, rolloff=0.945):
         return w
     g = math.gcd(orig_rate, new_rate)
     up, down = new_rate // g, orig_rate // g
+    if up * (2 * int(math.ceil(zeros * max(up, down) / (min(up, down) * rolloff))) + down) > 2e7:
+        # near-coprime rates (44099 -> 16000: up 16000, 44k taps per phase = 5.6 GB of kernel): quantise the source rate to
+        # the nearest multiple of 50 Hz by a linear-interpolation pre-pass (error band far above the wav2vec2 band's needs:
+        # a ratio change of <= 0.06 %), then run the polyphase filter at the friendly ratio
+        snapped = max(50, int(round(orig_rate / 50.0)) * 50)
+        n_mid = max(1, int(round(w.shape[-1] * snapped / float(orig_rate))))
+        w = F.interpolate(w[None, None].double(), size=n_mid, mode="linear", align_corners=False)[0, 0].to(w.dtype)
+        return resample_sinc(w, snapped, new_rate, zeros, rolloff)
     base = min(up, down) * rolloff          # cut-off in units of the common rate's Nyquist / max(up, down)
     width = int(math.ceil(zeros * down / base))
     # kernel[phase p of `up`, tap k]: output sample n * up + p reads input samples around n * down + p * down / up
@@ -84,7 +92,7 @@ def process_img(img_hwc, input_size, margin=1.6, index=1, logger=None):
         small = F.interpolate(img_hwc.permute(2, 0, 1)[None], scale_factor=mult, mode="area" if mult < 1.0 else "bicubic")
         small = (small[0].permute(1, 2, 0).clamp(0, 1) * 255).round().to(torch.uint8).cpu().numpy()
         det = fa.face_detector.detect_from_image(np.ascontiguousarray(small))
-        bboxes = [(int(x1 / mult), int(y1 / mult), int(x2 / mult), int(y2 / mult), sc) for (x1, y1, x2, y2, sc) in det if sc > 0.95]
+        bboxes = [(int(x1 / mult), int(y1 / mult), int(x2 / mult), int(y2 / mult), sc) for (x1, y1, x2, y2, sc) in (det or []) if sc > 0.95]
     except ImportError:
         if logger is not None:
             logger.warning("face_align=True, but the `face_alignment` package is not installed: no face detection, "

@@ -250,10 +250,11 @@ class LoadFMTModel:
         # widgets (nodes_vadv_loader.py:822-840), so attention_window / num_prev_frames / fps / wav2vec_sec steer the model
         sd = {k: v for k, v in sd.items() if k not in ("pos_embed", "alignment_mask")}
         cfg = FmtConfig.from_options(opt)
-        # the VA sampler takes batches (nodes_vadv.py:618-735): up to FLOAT_AMD_FMT_MAX_BATCH clips share one launch chain
-        # (default 4: ~3 GB of workspace per clip at the default shape; 1 = one clip at a time)
+        # the VA sampler takes batches (nodes_vadv.py:618-735): up to FLOAT_AMD_FMT_MAX_BATCH clips share one launch chain.
+        # Default 1 (one clip per chain, larger batches are cut into groups: 3.1 GB of workspace); every further clip of the
+        # stack costs another 3.1 GB at the default shape whether or not a workflow ever batches, so stacking is opt-in
         fmt = FlowMatchingTransformerHIP(sd, cfg, target_device, dtype=os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
-                                         max_batch=int(os.environ.get("FLOAT_AMD_FMT_MAX_BATCH", "4")))
+                                         max_batch=max(1, min(16, int(os.environ.get("FLOAT_AMD_FMT_MAX_BATCH", "1")))))
         fmt.opt = opt
         fmt.final_construction_options = {k: v for k, v in vars(opt).items() if not k.startswith("_")}
         fmt.cudnn_benchmark_setting = cudnn_benchmark
