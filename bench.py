@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--max-frames", type=int, default=32)
     ap.add_argument("--mode", default="replicas", choices=["replicas", "shard", "window"])
     ap.add_argument("--window-iters", type=int, default=1)
+    ap.add_argument("--window-resolve", type=int, default=1, help="windows of a rank re-solved after each boundary all_gather "
+                    "(the seam); 0 = the rank's whole range (with --window-iters N-1: the exact mode)")
     ap.add_argument("--dynamic-we", action="store_true", help="BASELINE configs[4]: per-window emotion, a=1 e=3")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,7 +234,7 @@ def main():
         s_r, r_s, wa = conditioning()
         if args.mode == "window" and world > 1:
             r_loc, _, rep = pkg.distributed.sample_window_parallel(hp.fmt, cfg, r_s, wa, we, noise, args.nfe, a_cfg, 1.0, e_cfg,
-                                                                   iters=args.window_iters)
+                                                                   iters=args.window_iters, resolve_chunks=args.window_resolve)
             seam.update(rep)
             last["host"] = hp.decode_to_host(s_r, r_loc[0])
         else:
@@ -259,9 +261,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         if args.mode == "window":
-            t = torch.as_tensor(seam.get("seam_rel_change", 0.0)).reshape(1).to(dev if backend == "nccl" else "cpu", torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            seam["seam_rel_change"] = float(t.item())
+            for key in ("seam_rel_change", "seam_next_rel_change"):
+                t = torch.as_tensor(seam.get(key, 0.0)).reshape(1).to(dev if backend == "nccl" else "cpu", torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                seam[key] = float(t.item())
     host = last["host"]
     assert host.shape[0] == n_local and host.is_pinned()
     assert float(host[0].min()) >= 0.0 and float(host[-1].max()) <= 1.0 and float(host.mean()) > 0.0
@@ -376,8 +379,10 @@ def main():
     if rank == 0:
         par = ("replicas x%d (one clip per GPU)" % world) if not one_clip else (
             "shard: one %d-frame clip, latent chain replicated, frames sharded x%d" % (T_total, world) if args.mode == "shard" else
-            "window: one %d-frame clip, windows sharded x%d, boundary all_gather x%d round(s), max seam change %.3e"
-            % (T_total, world, args.window_iters, seam.get("seam_rel_change", 0.0)))
+            "window: one %d-frame clip, windows sharded x%d, boundary all_gather x%d round(s) re-solving %s, max seam change %.3e, "
+            "max change of the hand-off frames at the next boundary %.3e"
+            % (T_total, world, args.window_iters, ("the first %d window(s) of a rank" % args.window_resolve) if args.window_resolve > 0
+               else "the rank's whole range", seam.get("seam_rel_change", 0.0), seam.get("seam_next_rel_change", 0.0)))
         out = {
             "metric": "512x512 frames/sec end-to-end audio->video @50 ODE steps",
             "value": round(fps, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -127,10 +127,10 @@ int pack_linear(float_fmt* h, const TensorTable& tt, const std::vector<std::stri
 constexpr int kWtRows = 256;  // LayerNorm / attention launches of at most this many rows store write-through (common.hpp, FMT_WT)
 // Wide-N path (fused adaLN projection): LDS-staged A, 128 columns per workgroup.
 int g_fmt_wide_variant = 7;  // FLOAT_FMT_WIDE_VARIANT: 6 / 7 = LDS-DMA 192 x 320 tile where the shape allows (else 2): lock step / wave rows half a step apart; register-staged 192 x 128 family: 0 = 96 rows x 4 k-blocks per chunk, 1 = 96 x 2, 2 = 192 x 2, 3 = 192 x 4, 4 / 5 = 8 waves
-template <class T, int MTW, int KCH, int NWV = 4, int EPI = EPI_F32>
+template <class T, int MTW, int KCH, int NWV = 4>
 int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   constexpr int smem = 2 * MTW * KCH * 1024;
-  auto kern = fmt_gemm_wide_kernel<T, MTW, KCH, NWV, EPI>;
+  auto kern = fmt_gemm_wide_kernel<T, MTW, KCH, NWV>;
   if (prime) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       (void)hipGetLastError();
@@ -138,11 +138,10 @@ int launch_wide_t(GemmArgs g, bool prime, hipStream_t s) {
   }
   const int mt_total = (g.M + 15) / 16;
   g.mblk = (mt_total + MTW - 1) / MTW;
-  if (EPI != EPI_PARTIAL || g.ksplit < 1) g.ksplit = 1;
-  const dim3 grid((g.N / 128) * g.mblk * (g.zcount > 1 ? g.zcount : 1) * g.ksplit);
+  g.ksplit = 1;
+  const dim3 grid((g.N / 128) * g.mblk * (g.zcount > 1 ? g.zcount : 1));
   hipEvent_t e0, e1;
-  // profiling class: the hoisted adaLN projection is its own (2), a chain GEMM counts with the chain's (0)
-  if (fh_prof_pair(EPI == EPI_F32 ? 2 : 0, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, e0, e1, 0, g);
+  if (fh_prof_pair(2, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, e0, e1, 0, g);
   else hipLaunchKernelGGL(kern, grid, dim3(NWV * 64), smem, s, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
@@ -214,29 +213,6 @@ int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
   return launch_wide_t<T, 5, 4>(g, false, s);
 }
 bool g_fmt_wide = true;  // FLOAT_FMT_WIDE=0 falls back to the generic tiling (A/B measurement)
-
-// The step chain's GEMMs on the LDS-staged large tile when clips are stacked (float_fmt_sample_batch): `rows16` row tiles of 16
-// per workgroup (6 = 96 rows, 12 = 192 rows), 128 columns, K in chunks of 2 k-blocks.  Returns FLOAT_E_INVALID without
-// launching when the shape does not tile (the caller then uses the 48 x 64 tiling).
-int g_fmt_big_rows = 0;  // FLOAT_FMT_BIG_ROWS: stacked rows from which the chain uses the large tile (0 = never, the default: measured slower)
-template <class T, int EPI>
-int launch_big(const GemmArgs& g, int rows16, bool prime, hipStream_t s) {
-  if (prime) {
-    (void)launch_wide_t<T, 6, 2, 4, EPI>(g, true, s);
-    (void)launch_wide_t<T, 12, 2, 4, EPI>(g, true, s);
-    return FLOAT_OK;
-  }
-  return rows16 == 6 ? launch_wide_t<T, 6, 2, 4, EPI>(g, false, s) : launch_wide_t<T, 12, 2, 4, EPI>(g, false, s);
-}
-// per-layer plan of the large-tile chain: "rows16,ksplit" (FLOAT_FMT_BIG_QKV / _PROJ / _FC1 / _FC2)
-struct BigPlan {
-  int rows16, ks;
-  BigPlan(const char* env, int r, int k) : rows16(r), ks(k) {
-    if (const char* e = getenv(env)) sscanf(e, "%d,%d", &rows16, &ks);
-    if (rows16 != 6) rows16 = 12;
-    if (ks != 1 && ks != 2 && ks != 4) ks = 1;
-  }
-};
 
 // ---- GEMM instantiation table: (row tiles, column tiles, waves splitting K) per workgroup ----
 template <class T, int MTW, int NT, int NW, int EPI>
@@ -334,9 +310,6 @@ void prime_kernels() {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     (void)launch_wide<T>(g, true, nullptr);
-    (void)launch_big<T, EPI_T16>(g, 12, true, nullptr);
-    (void)launch_big<T, EPI_GELU_P16>(g, 12, true, nullptr);
-    (void)launch_big<T, EPI_PARTIAL>(g, 12, true, nullptr);
   }
 }
 
@@ -643,23 +616,6 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
   }
   PendingRed pend;  // residual update left to the next LayerNorm launch
   auto split_ok = [&](int ks, const Lin& L) { return (ks == 1 || ks == 2 || ks == 4) && L.K % (128 * ks) == 0; };
-  // stacked clips: the LDS-staged large tile (launch_big) per layer, where the shape tiles
-  static const BigPlan big_qkv("FLOAT_FMT_BIG_QKV", 6, 1), big_proj("FLOAT_FMT_BIG_PROJ", 6, 4), big_fc1("FLOAT_FMT_BIG_FC1", 6, 1),
-      big_fc2("FLOAT_FMT_BIG_FC2", 6, 4);
-  auto big_ok = [&](const Lin& L, const BigPlan& p, bool partial) {
-    if (T::is32 || g_fmt_big_rows <= 0 || M < g_fmt_big_rows) return false;
-    const int mblk = ((M + 15) / 16 + p.rows16 - 1) / p.rows16, ks = partial ? p.ks : 1;
-    return L.N % 128 == 0 && L.K % (64 * ks) == 0 && mblk * p.rows16 * 16 <= h->Mpad;
-  };
-  auto big_partial = [&](const u16* A, const Lin& L, const BigPlan& p) {
-    GemmArgs g = base_args(A, L, M);
-    g.ksplit = p.ks;
-    g.out_f32 = h->slab;
-    g.ldo = g.N;
-    g.slab_stride = (size_t)h->Mpad * g.N;
-    if constexpr (!T::is32) return launch_big<T, EPI_PARTIAL>(g, p.rows16, false, s);
-    return (int)FLOAT_E_INVALID;
-  };
   for (int b = 0; b < c.depth; ++b) {
     const float* mod = modbuf + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
@@ -670,19 +626,10 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       g.ldo16 = 3 * D;
       if ((g_fmt_touch & 8) && !split_ok(g_fmt_proj_split, B.proj)) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       static const LayerPlan plan("FLOAT_FMT_PLAN_QKV");
-      if (big_ok(B.qkv, big_qkv, false)) {
-        if constexpr (!T::is32) rc = launch_big<T, EPI_T16>(g, big_qkv.rows16, false, s);
-      } else {
-        rc = run_gemm<T, EPI_T16>(g, s, false, &plan);
-      }
-      if (rc) return rc;
+      if ((rc = run_gemm<T, EPI_T16>(g, s, false, &plan))) return rc;
     }
     launch_attn<T>(h, M, (g_fmt_touch & 2) && !split_ok(g_fmt_proj_split, B.proj) ? &B.proj : nullptr, s);
-    if (big_ok(B.proj, big_proj, true)) {
-      if ((rc = big_partial(h->att16, B.proj, big_proj))) return rc;
-      pend.ks = big_proj.ks;
-      pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
-    } else if (split_ok(g_fmt_proj_split, B.proj)) {
+    if (split_ok(g_fmt_proj_split, B.proj)) {
       if ((rc = run_gemm_partial<T>(h, base_args(h->att16, B.proj, M), g_fmt_proj_split, s))) return rc;
       pend.ks = g_fmt_proj_split;
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
@@ -704,18 +651,9 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       if (g_fmt_touch & 4)
         g.touch = make_touch(B.fc2, M, split_ok(g_fmt_fc2_split, B.fc2) ? g_fmt_fc2_split : 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       static const LayerPlan plan("FLOAT_FMT_PLAN_FC1");
-      if (big_ok(B.fc1, big_fc1, false)) {
-        if constexpr (!T::is32) rc = launch_big<T, EPI_GELU_P16>(g, big_fc1.rows16, false, s);
-      } else {
-        rc = run_gemm<T, EPI_GELU_P16>(g, s, false, &plan);
-      }
-      if (rc) return rc;
+      if ((rc = run_gemm<T, EPI_GELU_P16>(g, s, false, &plan))) return rc;
     }
-    if (big_ok(B.fc2, big_fc2, true)) {
-      if ((rc = big_partial(h->hid16, B.fc2, big_fc2))) return rc;
-      pend.ks = big_fc2.ks;
-      pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.fc2.b, mod + 5 * D};
-    } else if (split_ok(g_fmt_fc2_split, B.fc2)) {
+    if (split_ok(g_fmt_fc2_split, B.fc2)) {
       GemmArgs g = base_args(h->hid16, B.fc2, M);
       if (g_fmt_touch & 32) {
         const unsigned lanes = gemm_lanes_per_xcd(M, g.N * g_fmt_fc2_split, g.K / g_fmt_fc2_split);
@@ -1189,7 +1127,6 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_HOIST")) g_fmt_hoist = atoi(v) != 0;
   if (const char* v = getenv("FLOAT_FMT_ZGROUP")) g_fmt_zgroup = std::max(0, atoi(v));
-  if (const char* v = getenv("FLOAT_FMT_BIG_ROWS")) g_fmt_big_rows = atoi(v);
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
     sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],
            &g_fmt_plan_override[3], &g_fmt_plan_override[4], &g_fmt_plan_override[5]);

@@ -277,14 +277,12 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
 //     the fp32 result is stored as float4.
 // NWV = 8: two waves per SIMD - waves 0..3 own the upper half of the row tiles, waves 4..7 the lower half, both halves the
 // same four 32-column slices (each weight fragment is then loaded by two waves, from L2; the LDS reads per MFMA do not change).
-//
-// EPI != EPI_F32: the same body as a GEMM of the step chain when clips are stacked (float_fmt_sample_batch, >= 360 rows): there
-// the 48 x 64 tiles of fmt_gemm_kernel re-read both operands from L2 per workgroup (229 KB for 3072 outputs), here a workgroup
-// reads 384 + 256 KB per K = 1024 for 24 576 outputs.  EPI_T16 / EPI_GELU_P16 write 4 consecutive 16-bit columns per lane
-// (row-major / the packed order of the consuming GEMM); EPI_PARTIAL cuts K into g.ksplit slices, one per workgroup, with the
-// slice <-> XCD affinity of fmt_gemm_kernel, and leaves the sum to the LayerNorm that follows.
-template <class T, int MTW, int KCH /* k-blocks (of 32) per LDS chunk */, int NWV = 4, int EPI = EPI_F32>
+// (Round 2 also ran this body with the step chain's epilogues for stacked clips - 96 / 192-row tiles, EPI_T16 / EPI_GELU_P16 /
+// EPI_PARTIAL - and it was slower than the 48 x 64 tiling at 360-720 rows: 167 / 194 ms per batch of 2 / 4 clips against
+// 118 / 181; removed in round 3, DESIGN.md "Negative results".)
+template <class T, int MTW, int KCH /* k-blocks (of 32) per LDS chunk */, int NWV = 4>
 __global__ __launch_bounds__(NWV * 64) void fmt_gemm_wide_kernel(GemmArgs g) {
+  constexpr int EPI = EPI_F32;
   constexpr int NF = MTW * KCH;            // 1-KiB A fragments per chunk
   constexpr int NFW = (NF + NWV - 1) / NWV;  // fragments staged by one wave
   constexpr int WR = NWV / 4, MTR = MTW / WR;  // row halves, row tiles per wave

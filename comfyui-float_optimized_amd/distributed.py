@@ -12,9 +12,10 @@ code); SURVEY.md section 8e defines the three modes.
                    range of 50-frame windows and first samples them from zero history, like window 0;
                    one all_gather of the boundary latents (last 10 frames of x, wa, we: ~41 KB per
                    rank, latency-bound on xGMI) gives every rank its predecessor's tail, and the rank
-                   re-solves its windows from that history.  `iters` such rounds make ranks 0..iters
-                   exact (world-1 rounds reproduce the sequential chain bit for bit); the residual
-                   seam error is reported, never hidden.
+                   re-solves from that history - its whole range (`iters` such rounds make ranks
+                   0..iters exact; world-1 rounds reproduce the sequential chain bit for bit), or only
+                   its first `resolve_chunks` windows, the seam (cost n + k instead of 2n windows per
+                   rank and round); the residual seam error is reported, never hidden.
 """
 import math
 
@@ -66,12 +67,24 @@ def sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg,
     return torch.cat(out, dim=1), (prev_x, prev_wa, prev_we)
 
 
-def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1.0, e_cfg=1.0, iters=1, group=None):
+def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1.0, e_cfg=1.0, iters=1, group=None,
+                           resolve_chunks=0):
     """Window-parallel sampling of one clip.  Every rank passes the FULL wa/we/noise (they are tiny);
-    returns (r_d_local, (t0, t1), report) where r_d_local are the rank's frames of r_d and report has
-    the seam error of the last round: rel-L2 change of the rank's latents caused by that exchange
-    (0 once the rank's history has converged to the sequential chain's), as a 0-dim tensor on the
-    latents' device - the caller converts it (float(...)) when it reports, not inside the timed loop."""
+    returns (r_d_local, (t0, t1), report).
+
+    Each of the `iters` rounds is one all_gather of the boundary latents followed by a re-solve from the predecessor's tail:
+      resolve_chunks = 0  the rank's WHOLE window range (cost: (1 + iters) x its windows).  Rank k is exact after k rounds, so
+                          iters = world - 1 reproduces the sequential chain bit for bit: the exact mode.
+      resolve_chunks = k  only the rank's first k windows - the seam - (cost: n + iters * k windows for a rank of n; SURVEY 8e's
+                          first-chunk re-solve).  The windows behind them keep the history they were solved with; whether
+                          that matters is what `seam_next_rel_change` measures.
+    report (0-dim tensors on the latents' device - the caller converts them when it reports, not inside the timed loop):
+      seam_rel_change       rel-L2 change of the re-solved latents caused by the last exchange (0 once the rank's history has
+                            converged to the sequential chain's);
+      seam_next_rel_change  the error metric of the seam re-solve: rel-L2 change, in the last round, of the hand-off frames
+                            (last num_prev_frames frames) of the last re-solved window - the history the NEXT, not re-solved
+                            window was computed from.  0 means the rest of the rank's range is what a full re-solve would give;
+      windows_solved        windows this rank solved in total (the cost)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
@@ -79,7 +92,10 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
     n_win = int(math.ceil(T / L))
     w0, w1 = window_shard(n_win, world, rank)
     xs, tail = sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, None)
+    solved = w1 - w0
     seam = torch.zeros((), device=xs.device, dtype=torch.float32)  # stays on the device: no host sync per round
+    seam_next = torch.zeros((), device=xs.device, dtype=torch.float32)
+    k = (w1 - w0) if resolve_chunks <= 0 else min(int(resolve_chunks), w1 - w0)
     for _ in range(iters if world > 1 else 0):
         # boundary latents of every rank: [x tail | wa tail | we tail] flattened, one all_gather
         mine = torch.cat([t.reshape(t.shape[0], -1) for t in tail], dim=1).contiguous()
@@ -91,11 +107,18 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
             nx, na = P * cfg.dim_w, P * cfg.dim_a
             hist = (g[:, :nx].reshape(B, P, cfg.dim_w), g[:, nx:nx + na].reshape(B, P, cfg.dim_a),
                     g[:, nx + na:].reshape(B, P, cfg.dim_e))
-            new_xs, new_tail = sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, hist)
-            seam = ((new_xs - xs).norm() / (new_xs.norm() + 1e-30)).float()
-            xs, tail = new_xs, new_tail
+            new_xs, new_tail = sample_range(fmt, cfg, r_s, wa, we, noise, w0, w0 + k, nfe, a_cfg, r_cfg, e_cfg, hist)
+            solved += k
+            old = xs[:, :k * L]
+            seam = ((new_xs - old).norm() / (new_xs.norm() + 1e-30)).float()
+            seam_next = ((new_xs[:, -P:] - old[:, -P:]).norm() / (new_xs[:, -P:].norm() + 1e-30)).float()
+            if k == w1 - w0:
+                xs, tail = new_xs, new_tail
+            else:  # the seam windows replace their first versions; the rank's own tail (its LAST window) is unchanged
+                xs = torch.cat([new_xs, xs[:, k * L:]], dim=1)
     t0, t1 = w0 * L, min(T, w1 * L)
-    return xs[:, :t1 - t0], (t0, t1), {"seam_rel_change": seam, "windows": (w0, w1), "rounds": iters}
+    return xs[:, :t1 - t0], (t0, t1), {"seam_rel_change": seam, "seam_next_rel_change": seam_next, "windows": (w0, w1),
+                                       "rounds": iters, "resolve_chunks": k, "windows_solved": solved}
 
 
 def broadcast_latents(r_d, src=0, group=None):

@@ -37,6 +37,7 @@ def test_dec_64_golden(dtype):
         p, m, float((frames - g["frames"]).abs().max()), float((raw - g["raw0"]).abs().max())))
     assert p >= LIMITS[dtype]["psnr"] and m <= LIMITS[dtype]["mean"]
     assert frames.min() >= 0 and frames.max() <= 1
+    assert float((frames - g["frames"]).abs().max()) <= 2.0 / 255  # 64 px: the per-pixel bound of SURVEY 8d holds outright
     assert dec.saturation() == 0  # nothing had to be clamped at fp16's range
 
 
@@ -54,6 +55,12 @@ def test_dec_512_golden_lattice(dtype):
     print(dtype, "512px: PSNR %.1f dB mean|d| %.2e max|d| %.2e mean err of means %.2e" % (
         p, m, float((lat - g["lattice"]).abs().max()), float((frames.mean(dim=(1, 2, 3)) - g["mean"]).abs().max())))
     assert p >= LIMITS[dtype]["psnr"] and m <= LIMITS[dtype]["mean"]
+    # per-pixel bound ("max-abs <= 2/255"): measured max 2.6e-2 at isolated pixels (a flow value that rounds the
+    # other way moves a bilinear tap across a feature edge); held: <= 0.1 % of the pixels beyond 2/255, none beyond 0.05
+    d = (lat - g["lattice"]).abs()
+    frac = float((d > 2.0 / 255).float().mean())
+    print("  pixels off by > 2/255: %.4f %%, max %.3e" % (100 * frac, float(d.max())))
+    assert frac <= 1e-3 and float(d.max()) <= 0.05
     assert dec.saturation() == 0
 
 

