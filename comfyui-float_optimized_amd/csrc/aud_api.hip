@@ -220,10 +220,10 @@ int create_impl(float_aud* h, const TensorTable& tt) {
   return FLOAT_OK;
 }
 
-// One row of attention scores per wave lives in LDS: 4 waves x (64 + Tn) floats <= 160 KiB (gfx950) -> 10 000 frames per call
-// = 400 s of audio conditioning at 25 fps, 200 s for the 50 Hz speech-emotion model (round 1 stopped at the 64 KiB default:
-// 3900 frames).
-constexpr int kAudMaxFrames = 10000;
+// Frames per call: the attention kernel tiles the keys (aud_kernels.hpp), so nothing in the operator depends on the clip
+// length any more; what is left is 32-bit element indices in the row-major buffers (Tn * 3 * D and Tn * intermediate must
+// stay below 2^31) and the O(Tn^2) cost of full attention: 200 000 frames per call = 2.2 h of audio at 25 fps.
+constexpr int kAudMaxFrames = 200000;
 
 // float_aud_reserve: the only place the operator allocates after create.  Run-time calls check the capacity and refuse.
 int ensure_workspace(float_aud* h, int n_samples, int Tn, hipStream_t st) {
@@ -299,7 +299,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   const int Lfeat = feature_len(c, n_samples);
   FH_REQUIRE(Lfeat >= 1, "audio too short for the feature extractor (%d samples)", n_samples);
   if (Tn <= 0) Tn = Lfeat;
-  FH_REQUIRE(Tn <= kAudMaxFrames, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit %d frames per call)", Tn, kAudMaxFrames);
+  FH_REQUIRE(Tn <= kAudMaxFrames, "%d frames: one call takes at most %d transformer frames (32-bit element indices)", Tn, kAudMaxFrames);
   FH_REQUIRE((size_t)n_samples <= h->cap_samples && Tn <= h->cap_T,
              "clip of %d samples / %d frames exceeds the reserved workspace (%zu samples / %d frames): call float_aud_reserve "
              "first (run-time calls do not allocate)", n_samples, Tn, h->cap_samples, h->cap_T);
@@ -399,16 +399,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
       if ((rc = fmt_gemm_run(c.dtype, EPI_T16, g, st))) return rc;
     }
     {
-      const size_t smem = (size_t)4 * (64 + Tn) * sizeof(float);
-      if (smem > 48 * 1024) {  // beyond the default dynamic-LDS limit: once per process and operand type
-        static bool raised = false;
-        if (!raised) {
-          FH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aud_attn_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024));
-          raised = true;
-        }
-      }
-      hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), smem, st, h->qkv16, Tn, D, c.heads, h->att16);
+      hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), 0, st, h->qkv16, Tn, D, c.heads, h->att16);
     }
     {
       GemmArgs g = fmt_gemm_args(h->att16, Ly.out, Tn);
@@ -521,7 +512,7 @@ int float_aud_reserve(float_aud_t* h, int32_t n_samples, int32_t seq_len, void* 
   FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
   const int Lfeat = feature_len(h->cfg, n_samples);
   const int Tn = seq_len > 0 ? seq_len : Lfeat;
-  FH_REQUIRE(Tn >= 1 && Tn <= kAudMaxFrames, "%d frames: the attention kernel keeps one row of scores per wave in LDS (limit %d frames per call)", Tn, kAudMaxFrames);
+  FH_REQUIRE(Tn >= 1 && Tn <= kAudMaxFrames, "%d frames: one call takes at most %d transformer frames (32-bit element indices)", Tn, kAudMaxFrames);
   return ensure_workspace(h, n_samples, Tn, (hipStream_t)stream);
 }
 

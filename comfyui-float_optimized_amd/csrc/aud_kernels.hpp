@@ -380,54 +380,70 @@ __global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restric
 // Wav2Vec2Attention (eager): softmax(q k^T * head_dim^-0.5) v over ALL frames, no mask.  One wave per (query,
 // head): lanes own keys (scores) and then head dimensions (weighted sum of V).  Head dim 64.  qkv is row-major
 // 16-bit [T][3*D] (q | k | v); the output is the packed A operand of out_proj (K = D).
+// Keys go through in tiles of kAudKeyTile with an online softmax (running max m, running sum l, the accumulator rescaled by
+// exp(m_old - m_new) when a tile raises the max), so the LDS score row is one tile long whatever the clip length: the
+// reference has no length limit (FLOAT.py:190-198) and neither has this kernel (rounds 1-2 kept the whole row in LDS and
+// stopped at 3900 / 10 000 frames).  A clip of at most one tile takes the same arithmetic path as before.
+constexpr int kAudKeyTile = 2048;
 template <class T>
 __global__ __launch_bounds__(256) void aud_attn_kernel(const u16* __restrict__ qkv, int Tn, int D, int heads, u16* __restrict__ out) {
   constexpr int HD = 64;
-  extern __shared__ float sm[];  // per wave: q[64] + p[Tn]
+  __shared__ float sm[4 * (HD + kAudKeyTile)];  // per wave: q[64] + p[tile]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int qi = blockIdx.x * 4 + w, h = blockIdx.y;
-  float* sq = sm + (size_t)w * (HD + Tn);
+  float* sq = sm + (size_t)w * (HD + kAudKeyTile);
   float* sp = sq + HD;
   const bool live = qi < Tn;
   const int ld = 3 * D;
   if (live) sq[lane] = T::to_float(qkv[(size_t)qi * ld + h * HD + lane]) * 0.125f;  // head_dim^-0.5 = 1/8
   __syncthreads();
   if (!live) return;
-  float mx = -INFINITY;
-  for (int j = lane; j < Tn; j += 64) {
-    const u16* kp = qkv + (size_t)j * ld + D + h * HD;
-    float dot = 0.f;
+  float m = -INFINITY, l = 0.f, acc = 0.f;
+  const u16* vbase = qkv + 2 * D + h * HD + lane;
+  for (int j0 = 0; j0 < Tn; j0 += kAudKeyTile) {
+    const int nt = min(kAudKeyTile, Tn - j0);
+    float mx = -INFINITY;
+    for (int j = lane; j < nt; j += 64) {
+      const u16* kp = qkv + (size_t)(j0 + j) * ld + D + h * HD;
+      float dot = 0.f;
 #pragma unroll
-    for (int c = 0; c < HD; c += 8) {
-      const uint4 u = *reinterpret_cast<const uint4*>(kp + c);
-      const u16* e = reinterpret_cast<const u16*>(&u);
+      for (int c = 0; c < HD; c += 8) {
+        const uint4 u = *reinterpret_cast<const uint4*>(kp + c);
+        const u16* e = reinterpret_cast<const u16*>(&u);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) dot += sq[c + i] * T::to_float(e[i]);
+        for (int i = 0; i < 8; ++i) dot += sq[c + i] * T::to_float(e[i]);
+      }
+      sp[j] = dot;
+      mx = fmaxf(mx, dot);
     }
-    sp[j] = dot;
-    mx = fmaxf(mx, dot);
-  }
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-  float sum = 0.f;
-  for (int j = lane; j < Tn; j += 64) {
-    const float p = __expf(sp[j] - mx);
-    sp[j] = p;
-    sum += p;
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    const float mn = fmaxf(m, mx);
+    const float alpha = __expf(m - mn);  // first tile: exp(-inf) = 0 on acc = l = 0
+    float sum = 0.f;
+    for (int j = lane; j < nt; j += 64) {
+      const float p = __expf(sp[j] - mn);
+      sp[j] = p;
+      sum += p;
+    }
+    l = l * alpha + wave_sum(sum);
+    m = mn;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    const u16* vp = vbase + (size_t)j0 * ld;
+    float a = 0.f;
+    int j = 0;
+    for (; j + 4 <= nt; j += 4) {
+      const float v0 = T::to_float(vp[(size_t)(j + 0) * ld]), v1 = T::to_float(vp[(size_t)(j + 1) * ld]);
+      const float v2 = T::to_float(vp[(size_t)(j + 2) * ld]), v3 = T::to_float(vp[(size_t)(j + 3) * ld]);
+      a += sp[j] * v0 + sp[j + 1] * v1 + sp[j + 2] * v2 + sp[j + 3] * v3;
+    }
+    for (; j < nt; ++j) a += sp[j] * T::to_float(vp[(size_t)j * ld]);
+    acc = acc * alpha + a;
+    __builtin_amdgcn_wave_barrier();  // the next tile overwrites the score row
+    __threadfence_block();
   }
-  sum = wave_sum(sum);
-  __builtin_amdgcn_wave_barrier();
-  __threadfence_block();
-  const u16* vp = qkv + 2 * D + h * HD + lane;
-  float acc = 0.f;
-  int j = 0;
-  for (; j + 4 <= Tn; j += 4) {
-    const float v0 = T::to_float(vp[(size_t)(j + 0) * ld]), v1 = T::to_float(vp[(size_t)(j + 1) * ld]);
-    const float v2 = T::to_float(vp[(size_t)(j + 2) * ld]), v3 = T::to_float(vp[(size_t)(j + 3) * ld]);
-    acc += sp[j] * v0 + sp[j + 1] * v1 + sp[j + 2] * v2 + sp[j + 3] * v3;
-  }
-  for (; j < Tn; ++j) acc += sp[j] * T::to_float(vp[(size_t)j * ld]);
-  out[fmt_pack_off(qi, h * HD + lane, D / 32)] = T::from_float(acc / sum);
+  out[fmt_pack_off(qi, h * HD + lane, D / 32)] = T::from_float(acc / l);
 }
 
 // ------------------------------------------------------------------------------------------

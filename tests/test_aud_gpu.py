@@ -125,9 +125,9 @@ def test_run_time_calls_do_not_allocate():
 
 
 def test_long_audio_beyond_the_round1_frame_limit():
-    """More than 3900 transformer frames per call (round 1's limit: one score row per wave in 64 KiB of LDS; now 160 KiB,
-    10 000 frames): 84 s through the 50 Hz speech-emotion model (4199 frames) and 170 s of audio conditioning at 25 fps
-    (4250 frames), small configs, against the oracle; one frame more than the limit is refused with a ValueError."""
+    """More than 3900 transformer frames per call (round 1's limit: one score row per wave in 64 KiB of LDS): 84 s through the
+    50 Hz speech-emotion model (4199 frames) and 170 s of audio conditioning at 25 fps (4250 frames), small configs, against
+    the oracle."""
     cfg = C.small_emotion_config()
     sd = W.synth_audio_state(cfg, seed=43)
     ser = pkg.audio.Audio2EmotionHIP(sd, cfg, "cuda:0", "fp16")
@@ -140,5 +140,23 @@ def test_long_audio_beyond_the_round1_frame_limit():
     a = W.synth_waveform(170.0, seed=6)
     wa = enc.inference(a, 4250).cpu()
     assert rel_l2(wa, O.audio_encoder_inference(asd, acfg, a, 4250)) < 3e-3
-    with pytest.raises(ValueError, match="10000"):
-        enc.inference(W.synth_waveform(8.0, seed=7), 10001)
+
+
+def test_audio_length_is_not_capped_by_lds():
+    """the reference has no audio length limit (FLOAT.py:190-198); rounds 1-2 stopped at 3900 / 10 000 frames
+    because the attention kernel kept a whole score row in LDS.  The keys are tiled now (online softmax): 12 000 frames =
+    480 s at 25 fps = six key tiles, against the oracle; and a clip whose length is not a multiple of the tile."""
+    acfg = C.small_audio_config()
+    asd = W.synth_audio_state(acfg, seed=45)
+    enc = pkg.audio.AudioEncoderHIP(asd, acfg, "cuda:0", "fp16")
+    a = W.synth_waveform(480.0, seed=8)
+    wa = enc.inference(a, 12000).cpu()
+    ref = O.audio_encoder_inference(asd, acfg, a, 12000)
+    e = rel_l2(wa, ref)
+    print("12 000 frames: rel-L2 %.2e" % e)
+    assert wa.shape == (1, 12000, acfg.dim_w) and e < 3e-3
+    a = W.synth_waveform(100.0, seed=9)
+    wa = enc.inference(a, 2500).cpu()  # one tile + 452 keys
+    assert rel_l2(wa, O.audio_encoder_inference(asd, acfg, a, 2500)) < 3e-3
+    with pytest.raises(ValueError, match="200000"):
+        enc.inference(W.synth_waveform(8.0, seed=7), 200001)
