@@ -8,7 +8,7 @@
 namespace {
 
 struct EConv {
-  u16* W = nullptr;      // [k*k][Cout][Cin] 16-bit, equalised-lr scale folded in
+  void* W = nullptr;     // [k*k][Cout][Cin] T::elem, equalised-lr scale folded in
   float* bias = nullptr; // [Cout] FusedLeakyReLU bias or nullptr
   int cin = 0, cout = 0, k = 0;
 };
@@ -37,9 +37,9 @@ struct float_enc {
   float* Q = nullptr;                  // [dim][dim_motion] of QR(direction.weight + 1e-8), or nullptr
   // activations: res[i] (NHWC 16-bit) for i = 0..n_blocks (res[0] = convs.0 output), scratch for
   // conv1 output, the two blurred images and the skip branch
-  std::vector<u16*> res;
+  std::vector<void*> res;  // T::elem
   std::vector<int> resR, resC;
-  u16 *t1 = nullptr, *tb = nullptr, *tsk = nullptr;
+  void *t1 = nullptr, *tb = nullptr, *tsk = nullptr;
   float *s_r = nullptr, *fcA = nullptr, *fcB = nullptr;
 };
 
@@ -56,14 +56,17 @@ int pack_conv(float_enc* h, const TensorTable& tt, const std::string& wname, con
   const int co = (int)w->shape[0], ci = (int)w->shape[1], k = (int)w->shape[2];
   FH_REQUIRE(ci % 32 == 0 && co % 32 == 0, "'%s': channel counts must be multiples of 32 (got %d -> %d)", wname.c_str(), ci, co);
   const float scale = 1.0f / sqrtf((float)(ci * k * k));  // EqualConv2d.scale (encoder.py:93)
-  std::vector<u16> hw((size_t)k * k * co * ci);
+  typedef typename T::elem E;
+  std::vector<E> hw((size_t)k * k * co * ci);
   for (int o = 0; o < co; ++o)
     for (int i = 0; i < ci; ++i)
       for (int t = 0; t < k * k; ++t)
         hw[((size_t)t * co + o) * ci + i] = T::host_from_float(w->data[((size_t)o * ci + i) * k * k + t] * scale);
   int rc;
-  if ((rc = h->pool.alloc(&out->W, hw.size(), false))) return rc;
-  FH_CHECK_HIP(hipMemcpy(out->W, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
+  E* dW = nullptr;
+  if ((rc = h->pool.alloc(&dW, hw.size(), false))) return rc;
+  out->W = dW;
+  FH_CHECK_HIP(hipMemcpy(dW, hw.data(), hw.size() * sizeof(E), hipMemcpyHostToDevice));
   out->cin = ci;
   out->cout = co;
   out->k = k;
@@ -192,14 +195,21 @@ int create_impl(float_enc* h, const TensorTable& tt) {
     if ((rc = h->pool.alloc(&h->Q, Qf.size(), false))) return rc;
     FH_CHECK_HIP(hipMemcpy(h->Q, Qf.data(), Qf.size() * sizeof(float), hipMemcpyHostToDevice));
   }
+  typedef typename T::elem E;
+  auto alloc_e = [&](void** p, size_t n) {
+    E* b = nullptr;
+    const int r = h->pool.alloc(&b, n, true);
+    *p = b;
+    return r;
+  };
   for (size_t l = 0; l < h->resR.size(); ++l) {
-    u16* b = nullptr;
-    if ((rc = h->pool.alloc(&b, (size_t)h->resR[l] * h->resR[l] * h->resC[l], true))) return rc;
+    void* b = nullptr;
+    if ((rc = alloc_e(&b, (size_t)h->resR[l] * h->resR[l] * h->resC[l]))) return rc;
     h->res.push_back(b);
   }
-  if ((rc = h->pool.alloc(&h->t1, max_t1, true))) return rc;
-  if ((rc = h->pool.alloc(&h->tb, max_tb, true))) return rc;
-  if ((rc = h->pool.alloc(&h->tsk, max_sk, true))) return rc;
+  if ((rc = alloc_e(&h->t1, max_t1))) return rc;
+  if ((rc = alloc_e(&h->tb, max_tb))) return rc;
+  if ((rc = alloc_e(&h->tsk, max_sk))) return rc;
   if ((rc = h->pool.alloc(&h->s_r, (size_t)c.dim, true))) return rc;
   if ((rc = h->pool.alloc(&h->fcA, (size_t)std::max(c.dim, 64), true))) return rc;
   if ((rc = h->pool.alloc(&h->fcB, (size_t)std::max(c.dim, 64), true))) return rc;
@@ -207,7 +217,7 @@ int create_impl(float_enc* h, const TensorTable& tt) {
 }
 
 template <class T>
-int launch_conv(const EConv& L, const u16* X, int Hi, int Wi, int stride, int pad, u16* Y, float* Yf32, const u16* skip,
+int launch_conv(const EConv& L, const void* X, int Hi, int Wi, int stride, int pad, void* Y, float* Yf32, const void* skip,
                 hipStream_t st) {
   EncConvArgs g;
   memset(&g, 0, sizeof(g));
@@ -245,27 +255,29 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
     return (feats && i >= 0 && i < n_feats) ? feats[i] : nullptr;
   };
   int rc;
+  typedef typename T::elem E;
   {
     const int HW = c.size * c.size;
     const size_t tot = (size_t)HW * (h->C0 / 8);
-    hipLaunchKernelGGL((enc_first_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, img, h->w0, h->b0, h->res[0],
-                       feat_out(0), HW, h->C0);
+    hipLaunchKernelGGL((enc_first_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, img, h->w0, h->b0,
+                       reinterpret_cast<E*>(h->res[0]), feat_out(0), HW, h->C0);
   }
   for (int b = 0; b < nb; ++b) {
     const ResBlk& B = h->blocks[b];
     const int R = B.R, C = B.conv1.cin;
-    const u16* x = h->res[b];
+    const E* x = reinterpret_cast<const E*>(h->res[b]);
     // skip: Blur pad (1,1) -> 1x1 stride 2, no bias / activation (encoder.py:191)
     {
       const size_t tot = (size_t)(R - 1) * (R - 1) * (C / 8);
-      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, h->tb, R, C, 1);
+      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, reinterpret_cast<E*>(h->tb), R, C, 1);
     }
     if ((rc = launch_conv<T>(B.skip, h->tb, R - 1, R - 1, 2, 0, h->tsk, nullptr, nullptr, st))) return rc;
     // conv1 3x3 + act; conv2: Blur pad (2,2) -> 3x3 stride 2 + act; (out + skip) / sqrt(2)
     if ((rc = launch_conv<T>(B.conv1, x, R, R, 1, 1, h->t1, nullptr, nullptr, st))) return rc;
     {
       const size_t tot = (size_t)(R + 1) * (R + 1) * (C / 8);
-      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, h->t1, h->tb, R, C, 2);
+      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const E*>(h->t1),
+                         reinterpret_cast<E*>(h->tb), R, C, 2);
     }
     if ((rc = launch_conv<T>(B.conv2, h->tb, R + 1, R + 1, 2, 0, h->res[b + 1], feat_out(b + 1), h->tsk, st))) return rc;
   }
@@ -313,11 +325,12 @@ int float_enc_create(const float_enc_cfg_t* cfg, const float_tensor_t* tensors, 
   FH_REQUIRE(cfg->size >= 64 && cfg->size <= 1024 && (cfg->size & (cfg->size - 1)) == 0,
              "encoder size must be a power of two in [64, 1024] (got %d)", cfg->size);
   FH_REQUIRE(cfg->dim > 0 && cfg->dim % 32 == 0 && cfg->dim_motion > 0 && cfg->dim_motion <= cfg->dim, "bad dim / dim_motion");
-  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
+  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16 || cfg->dtype == FLOAT_DT_FP32, "unknown dtype %d", cfg->dtype);
   float_enc* h = new float_enc();
   h->cfg = *cfg;
   TensorTable tt(tensors, n_tensors);
-  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);
+  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt)
+           : (cfg->dtype == FLOAT_DT_FP32) ? create_impl<FP32>(h, tt) : create_impl<FP16>(h, tt);
   if (rc) {
     float_enc_destroy(h);
     return rc;
@@ -338,6 +351,7 @@ int float_enc_forward(float_enc_t* h, const float* img, float* s_r, float* lam, 
   FH_REQUIRE(n_feats == 0 || feats != nullptr, "feats is null but n_feats = %d", n_feats);
   FH_REQUIRE(n_feats <= (int)h->blocks.size(), "at most %d feature maps (8..%d), got %d", (int)h->blocks.size(), h->cfg.size, n_feats);
   hipStream_t st = (hipStream_t)stream;
+  if (h->cfg.dtype == FLOAT_DT_FP32) return forward_impl<FP32>(h, img, s_r, lam, r_s, feats, n_feats, st);
   return h->cfg.dtype == FLOAT_DT_BF16 ? forward_impl<BF16>(h, img, s_r, lam, r_s, feats, n_feats, st)
                                        : forward_impl<FP16>(h, img, s_r, lam, r_s, feats, n_feats, st);
 }

@@ -1,6 +1,7 @@
 // HIP kernels of the appearance encoder (reference encoder.py:146-247: ConvLayer / ResBlock /
-// EncoderApp / Encoder.fc), run once per clip.  Activations are NHWC 16-bit like the decoder's, so
-// the skip features can be handed to the decoder without an fp32 round trip; accumulation is fp32.
+// EncoderApp / Encoder.fc), run once per clip.  Activations are NHWC in the operand type T like the decoder's (16-bit in
+// production, fp32 in the verification mode: the same kernels on T::elem / T::pack8), so the skip features can be handed to
+// the decoder without a round trip; accumulation is fp32.
 #pragma once
 #include "common.hpp"
 
@@ -9,7 +10,7 @@
 // (encoder.py:212, 146-181).  Reads the fp32 NCHW image, writes NHWC 16-bit (+ optional fp32 NCHW).
 template <class T>
 __global__ __launch_bounds__(256) void enc_first_kernel(const float* __restrict__ img, const float* __restrict__ w /*[C][3] scaled*/,
-                                                        const float* __restrict__ bias, u16* __restrict__ out,
+                                                        const float* __restrict__ bias, typename T::elem* __restrict__ out,
                                                         float* __restrict__ out_f32, int HW, int C) {
   const int c8 = C >> 3;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -17,23 +18,23 @@ __global__ __launch_bounds__(256) void enc_first_kernel(const float* __restrict_
   const int cg = (int)(idx % c8);
   const size_t p = idx / c8;
   const float r = img[p], g = img[(size_t)HW + p], b = img[2 * (size_t)HW + p];
-  uint4 o;
-  u16* oe = reinterpret_cast<u16*>(&o);
+  typename T::pack8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = cg * 8 + i;
     const float v = fh_lrelu_s2(w[c * 3 + 0] * r + w[c * 3 + 1] * g + w[c * 3 + 2] * b + bias[c]);
-    oe[i] = T::from_float(v);
+    T::set(o, i, v);
     if (out_f32) out_f32[(size_t)c * HW + p] = v;
   }
-  *reinterpret_cast<uint4*>(out + p * C + cg * 8) = o;
+  T::store8(out + p * C + cg * 8, o);
 }
 
 // ------------------------------------------------------------------------------------------
 // Blur([1,3,3,1], pad=(p,p)) of a down-sampling ConvLayer (encoder.py:59-75, 160-166): zero-pad by p,
 // correlate with the separable 4x4 FIR / 64; output (R + 2p - 3)^2.  One thread = one pixel x 8 channels.
 template <class T>
-__global__ __launch_bounds__(256) void enc_blur_kernel(const u16* __restrict__ in, u16* __restrict__ out, int R, int C, int pad) {
+__global__ __launch_bounds__(256) void enc_blur_kernel(const typename T::elem* __restrict__ in, typename T::elem* __restrict__ out,
+                                                       int R, int C, int pad) {
   const int Ro = R + 2 * pad - 3, c8 = C >> 3;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)Ro * Ro * c8) return;
@@ -52,18 +53,16 @@ __global__ __launch_bounds__(256) void enc_blur_kernel(const u16* __restrict__ i
     for (int b = 0; b < 4; ++b) {
       const int ix = X + b - pad;
       if (ix < 0 || ix >= R) continue;
-      const uint4 u = *reinterpret_cast<const uint4*>(in + ((size_t)iy * R + ix) * C + cg * 8);
-      const u16* e = reinterpret_cast<const u16*>(&u);
+      const typename T::pack8 u = T::load8(in + ((size_t)iy * R + ix) * C + cg * 8);
       const float kk = k1[a] * k1[b];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc[i] += kk * T::to_float(e[i]);
+      for (int i = 0; i < 8; ++i) acc[i] += kk * T::get(u, i);
     }
   }
-  uint4 o;
-  u16* oe = reinterpret_cast<u16*>(&o);
+  typename T::pack8 o;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) oe[i] = T::from_float(acc[i]);
-  *reinterpret_cast<uint4*>(out + p * C + cg * 8) = o;
+  for (int i = 0; i < 8; ++i) T::set(o, i, acc[i]);
+  T::store8(out + p * C + cg * 8, o);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -77,17 +76,21 @@ __global__ __launch_bounds__(256) void enc_blur_kernel(const u16* __restrict__ i
 // Epilogue (all optional): + bias, leaky_relu(0.2) * sqrt(2); (y + skip) / sqrt(2) of the ResBlock
 // (encoder.py:196-197); NHWC 16-bit store and/or fp32 NCHW store (the reference's feature format).
 struct EncConvArgs {
-  const u16* X;     // [Hi][Wi][Cin]
-  const u16* W;     // [k*k][Cout][Cin], 1/sqrt(Cin k^2) folded in
-  u16* Y;           // [Ho][Wo][Cout] or nullptr
+  const void* X;    // [Hi][Wi][Cin] T::elem
+  const void* W;    // [k*k][Cout][Cin] T::elem, 1/sqrt(Cin k^2) folded in
+  void* Y;          // [Ho][Wo][Cout] T::elem or nullptr
   float* Yf32;      // [Cout][Ho][Wo] or nullptr
   const float* bias;  // [Cout] or nullptr (with act)
-  const u16* skip;    // [Ho][Wo][Cout] or nullptr
+  const void* skip;   // [Ho][Wo][Cout] T::elem or nullptr
   int Hi, Wi, Cin, Cout, Ho, Wo, k, stride, pad, act;
 };
 
 template <class T, int NT>
 __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs g) {
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  const E* const gX = reinterpret_cast<const E*>(g.X);
+  const E* const gW = reinterpret_cast<const E*>(g.W);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int npix = g.Ho * g.Wo;
@@ -104,17 +107,16 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs g) {
     for (int tx = 0; tx < g.k; ++tx) {
       const int ix = ox * g.stride - g.pad + tx;
       const bool ok = mvalid && iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi;
-      const u16* xa = g.X + ((size_t)(ok ? iy : 0) * g.Wi + (ok ? ix : 0)) * g.Cin + q * 8;
-      const u16* wb = g.W + ((size_t)(ty * g.k + tx) * g.Cout + n0 + r16) * g.Cin + q * 8;
+      const E* xa = gX + ((size_t)(ok ? iy : 0) * g.Wi + (ok ? ix : 0)) * g.Cin + q * 8;
+      const E* wb = gW + ((size_t)(ty * g.k + tx) * g.Cout + n0 + r16) * g.Cin + q * 8;
       for (int c = 0; c < nchunk; c += 2) {
-        u32x4 a[2], b[2][NT];
+        P8 a[2], b[2][NT];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const bool live = c + h < nchunk;
-          a[h] = (ok && live) ? *reinterpret_cast<const u32x4*>(xa + (c + h) * 32) : u32x4{0u, 0u, 0u, 0u};
+          a[h] = (ok && live) ? T::load8(xa + (c + h) * 32) : T::zero8();
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            b[h][j] = live ? *reinterpret_cast<const u32x4*>(wb + (size_t)j * 16 * g.Cin + (c + h) * 32) : u32x4{0u, 0u, 0u, 0u};
+          for (int j = 0; j < NT; ++j) b[h][j] = live ? T::load8(wb + (size_t)j * 16 * g.Cin + (c + h) * 32) : T::zero8();
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -137,20 +139,11 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs g) {
       v[3] = fh_lrelu_s2(v[3] + bb.w);
     }
     if (g.skip) {
-      const ushort4 s = *reinterpret_cast<const ushort4*>(g.skip + (size_t)m * g.Cout + co);
-      v[0] = (v[0] + T::to_float(s.x)) * inv_s2;
-      v[1] = (v[1] + T::to_float(s.y)) * inv_s2;
-      v[2] = (v[2] + T::to_float(s.z)) * inv_s2;
-      v[3] = (v[3] + T::to_float(s.w)) * inv_s2;
+      const E* sp = reinterpret_cast<const E*>(g.skip) + (size_t)m * g.Cout + co;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (v[r] + T::to_float(sp[r])) * inv_s2;
     }
-    if (g.Y) {
-      ushort4 o;
-      o.x = T::from_float(v[0]);
-      o.y = T::from_float(v[1]);
-      o.z = T::from_float(v[2]);
-      o.w = T::from_float(v[3]);
-      *reinterpret_cast<ushort4*>(g.Y + (size_t)m * g.Cout + co) = o;
-    }
+    if (g.Y) T::store4(reinterpret_cast<E*>(g.Y) + (size_t)m * g.Cout + co, v[0], v[1], v[2], v[3]);
     if (g.Yf32) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) g.Yf32[(size_t)(co + r) * npix + m] = v[r];
@@ -174,7 +167,7 @@ __global__ __launch_bounds__(256) void enc_linear_kernel(const float* __restrict
 
 // NHWC 16-bit -> fp32 NCHW (reference feature format), for callers that want the reference's tensors.
 template <class T>
-__global__ void enc_unpack_kernel(const u16* __restrict__ in, float* __restrict__ out, int HW, int C) {
+__global__ void enc_unpack_kernel(const typename T::elem* __restrict__ in, float* __restrict__ out, int HW, int C) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)HW * C) return;
   const int c = (int)(idx / HW);

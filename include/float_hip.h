@@ -47,7 +47,7 @@ enum {
 };
 
 /* MFMA operand type; accumulation, statistics, softmax, residual stream and ODE state are fp32 in every mode.
- * FLOAT_DT_FP32 (FMT and decoder): the verification mode - fp32 operands on v_mfma_f32_16x16x4_f32, the same launch chain and
+ * FLOAT_DT_FP32 (FMT, decoder, appearance encoder): the verification mode - fp32 operands on v_mfma_f32_16x16x4_f32, the same launch chain and
  * the same kernels with 4-byte elements, held to the reference goldens at 1e-4 (tests/test_fmt_fp32_gpu.py,
  * tests/test_dec_fp32_gpu.py); 1/16 of the 16-bit MFMA rate, no tuned tilings. */
 enum { FLOAT_DT_BF16 = 0, FLOAT_DT_FP16 = 1, FLOAT_DT_FP32 = 2 };
@@ -262,7 +262,8 @@ typedef struct {
   int32_t size;        /* input resolution, power of two in [64, 1024] */
   int32_t dim;         /* 512 */
   int32_t dim_motion;  /* 20 */
-  int32_t dtype;       /* FLOAT_DT_* of activations / conv weights; accumulation, s_r, fc are fp32 */
+  int32_t dtype;       /* FLOAT_DT_* of activations / conv weights (FLOAT_DT_FP32 = verification mode, feeds an fp32 decoder);
+                          accumulation, s_r, fc are fp32 */
 } float_enc_cfg_t;
 
 typedef struct float_enc float_enc_t;

@@ -56,3 +56,23 @@ def test_dec_fp32_stress(kind, size):
     print("fp32 stress %s %d: max|d| %.2e (limit %.2e; reference fp32 vs fp64 %.2e) rel %.2e (limit %.2e), raw std %.1f" % (
         kind, size, m, lim_m, g["ref_vs_f64_max"], r, lim_r, g["raw_std"]))
     assert m <= lim_m and r <= lim_r and dec.saturation() == 0
+
+
+def test_config1_end_to_end_fp32_chain():
+    """BASELINE configs[0] (1 s, 25 frames, nfe 10) through the WHOLE hot path in the verification modes - FMT fp32 + decoder
+    fp32 - against the frames the reference itself produced on the CPU (tests/golden/e2e_config1.npz): the HIP logic end to
+    end.  r_d rel-L2 <= 2e-5 (measured 3.4e-7); frames max-abs <= 5e-4 (measured 2.6e-4: the decoder alone sits at 9.7e-5 on
+    its 512-px golden - SURVEY 8d's 1e-4 - and turns the 3.4e-7 of the latents into the rest; 16-bit operands give 0.107)."""
+    g = golden("e2e_config1")
+    cfg = pkg.config.FmtConfig()
+    fmt_sd = W.synth_fmt_state(cfg, g["seed"])
+    dec_sd = W.synth_decoder_state(512, seed=g["seed"])
+    hp = pkg.pipeline.FloatHotPath(fmt_sd, dec_sd, cfg, "cuda:0", 512, fmt_dtype="fp32", dec_dtype="fp32", max_frames=5)
+    feats = W.synth_feats(512, seed=g["seed"])
+    frames, r_d = hp.generate(g["r_s"], g["wa"], g["we"], g["s_r"], feats, 10, noise=g["noise"], return_rd=True)
+    e_rd = rel_l2(r_d.cpu(), g["r_d"])
+    pick = [int(i) for i in g["pick"]]
+    fr = frames.cpu()[pick]
+    m = max_abs(fr[:, ::7, ::5], g["lattice"])
+    print("config1 fp32 chain: r_d rel-L2 %.2e, frames max|d| %.2e" % (e_rd, m))
+    assert e_rd <= 2e-5 and m <= 5e-4

@@ -15,14 +15,14 @@ pkg = load_pkg()
 W = pkg.weights
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp16": 2e-3, "bf16": 1.5e-2}
+TOL = {"fp16": 2e-3, "bf16": 1.5e-2, "fp32": 2e-5}  # fp32 = the verification mode (SURVEY 8d asks 1e-4; measured <= 2e-6)
 
 
 def _image(seed, size):
     return torch.from_numpy(np.random.RandomState(seed).rand(1, 3, size, size).astype(np.float32)) * 2 - 1
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("size", [64, 512])
 def test_encoder_golden(size, dtype):
     g = golden("enc_%d" % size)
@@ -88,3 +88,29 @@ def test_encoder_errors():
     enc = pkg.encoder.EncoderHIP(esd, 64, 512, 20, "cuda:0")
     with pytest.raises(ValueError):
         enc.encode_image_into_latent(torch.zeros(1, 3, 32, 32))
+
+
+def test_encoder_fp32_feeds_decoder_fp32():
+    """The fp32 verification modes chain: encoder (fp32 NHWC skip features) -> float_dec_set_feats16 with dtype fp32 -> decoder.
+    Image -> frames against the oracle (which is bit-identical to the reference's Encoder and Synthesis on the goldens) at 1e-4,
+    and a 16-bit encoder is refused by an fp32 decoder."""
+    size = 64
+    esd = W.synth_encoder_state(size, seed=9)
+    dsd = W.synth_decoder_state(size, seed=9)
+    enc = pkg.encoder.EncoderHIP(esd, size, 512, 20, "cuda:0", "fp32")
+    dec = pkg.decoder.SynthesisHIP(dsd, size, 512, "cuda:0", "fp32", max_frames=4)
+    img = _image(3, size)
+    s_r, lam, feats, _ = enc.encode_image_into_latent(img)
+    enc.hand_feats_to(dec)
+    g = torch.Generator().manual_seed(0)
+    r_d = torch.randn(1, 3, 512, generator=g) * 0.3
+    frames = dec.decode_latent_into_processed_images(s_r, r_d).cpu()
+    o_s, o_f, _ = O.encode_appearance(esd, img)
+    want = O.decode_frames(dsd, o_s, r_d, o_f)
+    m = float((frames - want).abs().max())
+    print("image -> frames, fp32 chain: max|d| %.2e" % m)
+    assert m <= 1e-4
+    enc16 = pkg.encoder.EncoderHIP(esd, size, 512, 20, "cuda:0", "fp16")
+    enc16.encode_image_into_latent(img)
+    with pytest.raises(ValueError, match="dtype"):
+        enc16.hand_feats_to(dec)
