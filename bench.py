@@ -101,11 +101,12 @@ def launch_ranks(n):
 
 
 def source_hash():
-    """Identity of the kernels a profile summary belongs to: sha256 over the HIP sources (the GPU box has no .git)."""
+    """Identity of the kernels a profile summary belongs to: sha256 over the HIP sources of the profiled kernel classes - the
+    FMT and decoder operators and what they share (the GPU box has no .git; the encoder / audio operators have no counters)."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "comfyui-float_optimized_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".hpp")):
+        if f.endswith((".hip", ".hpp")) and f.startswith(("fmt_", "dec_", "common")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
@@ -341,11 +342,11 @@ def main():
             mod_roof["frac"] = round(mod_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
         # HBM traffic per launch / MFMA pipe utilisation from the committed rocprofv3 --pmc passes (tools/profile_round.sh),
         # only when they were taken on these kernel sources
-        pmc = load_profile_json("r02_pmc_traffic.json", warnings)
+        pmc = load_profile_json("r03_pmc_traffic.json", warnings)
         if pmc:
             gemm_roof["traffic"] = pmc.get("fmt_gemm", {}).get("hbm_bytes_per_launch")
             conv_roof["traffic"] = pmc.get("dec_conv", {}).get("hbm_bytes_per_launch")
-        mf = load_profile_json("r02_pmc_mfma.json", warnings)
+        mf = load_profile_json("r03_pmc_mfma.json", warnings)
         if mf:
             gemm_roof["mfma_util_pmc"] = mf.get("fmt_gemm", {}).get("mfma_util")
             conv_roof["mfma_util_pmc"] = mf.get("dec_conv", {}).get("mfma_util")

@@ -1,6 +1,6 @@
 #!/bin/sh
 # Copy the summaries of a tools/profile_round.sh run (gpurun_out/<dir>, scratch) into profiles/ (tracked).
-#   sh tools/collect_profiles.sh r02_prof r02
+#   sh tools/collect_profiles.sh r03_prof r03
 set -e
 S=gpurun_out/$1; P=profiles/$2
 if [ -s $S/bench_final.json ]; then cp $S/bench_final.json ${P}_bench.json; else cp $S/bench.json ${P}_bench.json; fi
