@@ -13,7 +13,7 @@ struct LnP {
 };
 
 struct ConvL {
-  u16* W = nullptr;  // [N][k*Cin], K ordered (tap, channel)
+  void* W = nullptr;  // [N][k*Cin] T::elem, K ordered (tap, channel)
   float* bias = nullptr;  // conv_bias = true (speech-emotion model)
   LnP ln;                 // feat_extract_norm = "layer": LayerNorm over channels after the conv
   int cin = 0, cout = 0, k = 0, stride = 0;
@@ -41,7 +41,7 @@ struct float_aud {
   std::vector<ConvL> convs;  // layers 1..n-1
   LnP fp_ln;
   FmtLin fp_proj;
-  u16* pos_w = nullptr;  // [pairs][taps][GP][GP]
+  void* pos_w = nullptr;  // [pairs][taps][GP][GP] T::elem
   float* pos_b = nullptr;
   int pos_gp = 0, pos_pairs = 0;
   LnP enc_ln;
@@ -51,9 +51,9 @@ struct float_aud {
   // workspace
   size_t cap_samples = 0;
   int cap_T = 0, Mp = 0;
-  u16 *fa = nullptr, *fb = nullptr;
+  void *fa = nullptr, *fb = nullptr;  // T::elem (every activation buffer below: bytes = elements * element size of cfg.dtype)
   float *part = nullptr, *scsh = nullptr;
-  u16 *x16 = nullptr, *hp16 = nullptr, *qkv16 = nullptr, *att16 = nullptr, *hid16 = nullptr, *stack16 = nullptr;
+  void *x16 = nullptr, *hp16 = nullptr, *qkv16 = nullptr, *att16 = nullptr, *hid16 = nullptr, *stack16 = nullptr;
   float *hproj = nullptr, *pos = nullptr, *h = nullptr, *h1 = nullptr, *y = nullptr, *yproj = nullptr;
 };
 
@@ -119,12 +119,15 @@ int create_impl(float_aud* h, const TensorTable& tt) {
     FH_REQUIRE((tt.find(p + "layer_norm.weight") != nullptr) == (c.feat_norm_layer != 0),
                "feat_norm_layer=%d does not match the checkpoint (conv layer %d)", c.feat_norm_layer, i);
     if (c.feat_norm_layer && (rc = load_ln(h, tt, p + "layer_norm", L.cout, &L.ln))) return rc;
-    std::vector<u16> hw((size_t)L.cout * L.k * L.cin);
+    typedef typename T::elem E;
+    std::vector<E> hw((size_t)L.cout * L.k * L.cin);
     for (int n = 0; n < L.cout; ++n)
       for (int ci = 0; ci < L.cin; ++ci)
         for (int t = 0; t < L.k; ++t) hw[((size_t)n * L.k + t) * L.cin + ci] = T::host_from_float(w->data[((size_t)n * L.cin + ci) * L.k + t]);
-    if ((rc = h->pool.alloc(&L.W, hw.size(), false))) return rc;
-    FH_CHECK_HIP(hipMemcpy(L.W, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
+    E* dW = nullptr;
+    if ((rc = h->pool.alloc(&dW, hw.size(), false))) return rc;
+    L.W = dW;
+    FH_CHECK_HIP(hipMemcpy(dW, hw.data(), hw.size() * sizeof(E), hipMemcpyHostToDevice));
     h->convs.push_back(L);
   }
   // ---- feature projection (LayerNorm + Linear)
@@ -166,7 +169,8 @@ int create_impl(float_aud* h, const TensorTable& tt) {
     FH_REQUIRE(GP % 32 == 0 && GP <= 128 && c.pos_groups % merge == 0, "positional conv with %d channels per group is not supported", cpg);
     h->pos_gp = GP;
     h->pos_pairs = c.pos_groups / merge;
-    std::vector<u16> hw((size_t)h->pos_pairs * K * GP * GP, T::host_from_float(0.f));
+    typedef typename T::elem E;
+    std::vector<E> hw((size_t)h->pos_pairs * K * GP * GP, T::host_from_float(0.f));
     for (int o = 0; o < h->D; ++o) {
       const int grp = o / cpg, pair = grp / merge, ol = o - pair * GP;
       for (int ci = 0; ci < cpg; ++ci) {
@@ -174,8 +178,10 @@ int create_impl(float_aud* h, const TensorTable& tt) {
         for (int t = 0; t < K; ++t) hw[(((size_t)pair * K + t) * GP + ol) * GP + cl] = T::host_from_float(wf[((size_t)o * cpg + ci) * K + t]);
       }
     }
-    if ((rc = h->pool.alloc(&h->pos_w, hw.size(), false))) return rc;
-    FH_CHECK_HIP(hipMemcpy(h->pos_w, hw.data(), hw.size() * sizeof(u16), hipMemcpyHostToDevice));
+    E* dPW = nullptr;
+    if ((rc = h->pool.alloc(&dPW, hw.size(), false))) return rc;
+    h->pos_w = dPW;
+    FH_CHECK_HIP(hipMemcpy(dPW, hw.data(), hw.size() * sizeof(E), hipMemcpyHostToDevice));
     const float_tensor_t* b = need(tt, p + "bias");
     if (!b) return FLOAT_E_MISSING;
     if ((rc = upload(&h->pool, b->data, h->D, &h->pos_b))) return rc;
@@ -242,16 +248,22 @@ int ensure_workspace(float_aud* h, int n_samples, int Tn, hipStream_t st) {
   auto A = [&](auto** p, size_t n) {
     if (!rc) rc = h->ws.alloc(p, n, true);
   };
-  A(&h->fa, L0 * C + 64);
-  A(&h->fb, L1 * C + 64);
+  const size_t esz = c.dtype == FLOAT_DT_FP32 ? 4 : 2;  // bytes per activation element
+  auto AE = [&](void** p, size_t n) {  // n elements of the operand type
+    unsigned char* b = nullptr;
+    if (!rc) rc = h->ws.alloc(&b, n * esz, true);
+    *p = b;
+  };
+  AE(&h->fa, L0 * C + 64);
+  AE(&h->fb, L1 * C + 64);
   A(&h->part, ((L0 + 63) / 64) * C * 2);
   A(&h->scsh, (size_t)2 * C);
-  A(&h->x16, (size_t)Mp * C);
-  A(&h->hp16, (size_t)Mp * D);
-  A(&h->qkv16, (size_t)Mp * 3 * D);
-  A(&h->att16, (size_t)Mp * D);
-  A(&h->hid16, (size_t)Mp * c.intermediate);
-  A(&h->stack16, (size_t)Mp * std::max(h->aproj.K, 128));
+  AE(&h->x16, (size_t)Mp * C);
+  AE(&h->hp16, (size_t)Mp * D);
+  AE(&h->qkv16, (size_t)Mp * 3 * D);
+  AE(&h->att16, (size_t)Mp * D);
+  AE(&h->hid16, (size_t)Mp * c.intermediate);
+  AE(&h->stack16, (size_t)Mp * std::max(h->aproj.K, 128));
   A(&h->hproj, (size_t)Mp * D);
   A(&h->pos, (size_t)Mp * D);
   A(&h->h, (size_t)Mp * D);
@@ -293,6 +305,7 @@ int feature_len(const float_aud_cfg_t& c, int n_samples) {
 // extractor's own length (speech-emotion model, no interpolation).  wa: (Tn, dim_w) or scores: (num_labels).
 template <class T>
 int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* out, hipStream_t st) {
+  typedef typename T::elem E;
   const float_aud_cfg_t& c = h->cfg;
   const int C = h->C, D = h->D;
   int rc;
@@ -308,7 +321,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   FH_REQUIRE(c.conv_kernel[0] == 10, "first conv kernel must be 10 (got %d)", c.conv_kernel[0]);
   if (c.feat_norm_layer) {
     hipLaunchKernelGGL((aud_conv0_ln_kernel<T, 10>), dim3((L + 3) / 4), dim3(256), 0, st, a, h->w0, h->b0, c.conv_stride[0], L, C, h->gn.g, h->gn.b,
-                       1e-5f, h->fa);
+                       1e-5f, reinterpret_cast<E*>(h->fa));
   } else {
     const int tchunk = 64, nchunk = (L + tchunk - 1) / tchunk;
     hipLaunchKernelGGL((aud_conv0_stats_kernel<10>), dim3(nchunk, (C + 255) / 256), dim3(256), 0, st, a, n_samples, h->w0, c.conv_stride[0], L, C,
@@ -316,9 +329,9 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     hipLaunchKernelGGL(aud_gn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, h->part, nchunk, C, L, h->gn.g, h->gn.b, 1e-5f, h->scsh);
     const size_t tot = (size_t)L * (C / 8);
     hipLaunchKernelGGL((aud_conv0_apply_kernel<T, 10>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, h->w0, c.conv_stride[0], L, C,
-                       h->scsh, h->fa);
+                       h->scsh, reinterpret_cast<E*>(h->fa));
   }
-  u16 *cur = h->fa, *nxt = h->fb;
+  E *cur = reinterpret_cast<E*>(h->fa), *nxt = reinterpret_cast<E*>(h->fb);
   for (const ConvL& Lc : h->convs) {
     const int Lo = (L - Lc.k) / Lc.stride + 1;
     AudGemmArgs g;
@@ -333,7 +346,15 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     g.K = Lc.k * Lc.cin;
     g.ldc = Lc.cout;
     g.act = c.feat_norm_layer ? 0 : 1;
-    hipLaunchKernelGGL((aud_gemm_tile_kernel<T>), dim3((Lo + 127) / 128, Lc.cout / 64), dim3(256), 0, st, g);
+    {
+      constexpr int smem = 2 * (128 + 64) * 64 * T::EB;  // 48 KiB with 16-bit operands, 96 KiB in the fp32 mode
+      static const bool raised = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(aud_gemm_tile_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        return true;
+      }();
+      (void)raised;
+      hipLaunchKernelGGL((aud_gemm_tile_kernel<T>), dim3((Lo + 127) / 128, Lc.cout / 64), dim3(256), smem, st, g);
+    }
     if (c.feat_norm_layer) {  // LayerNorm over channels + GELU, in place
       dim3 grid((Lo + 3) / 4);
       if (Lc.cout == 512) hipLaunchKernelGGL((aud_rowln_gelu_kernel<T, 2>), grid, dim3(256), 0, st, nxt, Lo, Lc.ln.g, Lc.ln.b, 1e-5f);
@@ -347,11 +368,11 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   {
     dim3 grid((Tn + 3) / 4);
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 1>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, h->x16); break;
-      case 2: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 2>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, h->x16); break;
+      case 1: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 1>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, reinterpret_cast<E*>(h->x16)); break;
+      case 2: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 2>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, reinterpret_cast<E*>(h->x16)); break;
       default: fh_set_error("conv_dim %d unsupported", C); return FLOAT_E_INVALID;
     }
-    GemmArgs g = fmt_gemm_args(h->x16, h->fp_proj, Tn);
+    GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->x16), h->fp_proj, Tn);
     g.out_f32 = h->hproj;
     g.ldo = D;
     if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
@@ -360,7 +381,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   // h = LN(h + attn(h)); h = LN(h + ffn(h)).  Stable (pre-)LayerNorm (the speech-emotion model): hidden += pos, per layer
   // h += attn(LN(h)); h += ffn(LN(h)); one LayerNorm after the last layer.  `h->h` is the fp32 residual stream,
   // `h->hp16` the packed operand of the next GEMM in both cases.
-  auto ln = [&](const float* a_in, const float* res, const LnP& p, float* o32, u16* o16, int keep_sum, u16* stack, int stack_col) {
+  auto ln = [&](const float* a_in, const float* res, const LnP& p, float* o32, void* o16, int keep_sum, void* stack, int stack_col) {
     AudLnArgs g;
     memset(&g, 0, sizeof(g));
     g.a = a_in;
@@ -380,7 +401,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   {
     dim3 grid((Tn + 15) / 16, h->pos_pairs);
 #define POS_CASE(GP) \
-  case GP: hipLaunchKernelGGL((aud_posconv_kernel<T, GP>), grid, dim3(256), 0, st, h->hproj, Tn, D, h->pos_w, h->pos_b, c.pos_k, c.pos_k / 2, h->pos); break;
+  case GP: hipLaunchKernelGGL((aud_posconv_kernel<T, GP>), grid, dim3(256), 0, st, h->hproj, Tn, D, reinterpret_cast<const E*>(h->pos_w), h->pos_b, c.pos_k, c.pos_k / 2, h->pos); break;
     switch (h->pos_gp) {
       POS_CASE(32) POS_CASE(64) POS_CASE(96) POS_CASE(128)
       default: fh_set_error("merged positional group width %d unsupported", h->pos_gp); return FLOAT_E_INVALID;
@@ -393,16 +414,17 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   for (int l = 0; l < c.layers; ++l) {
     const TLayer& Ly = h->layers[l];
     {
-      GemmArgs g = fmt_gemm_args(h->hp16, Ly.qkv, Tn);
-      g.out16 = h->qkv16;
+      GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->hp16), Ly.qkv, Tn);
+      g.out16 = reinterpret_cast<u16*>(h->qkv16);
       g.ldo16 = 3 * D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_T16, g, st))) return rc;
     }
     {
-      hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), 0, st, h->qkv16, Tn, D, c.heads, h->att16);
+      hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), 0, st, reinterpret_cast<const E*>(h->qkv16), Tn, D, c.heads,
+                         reinterpret_cast<E*>(h->att16));
     }
     {
-      GemmArgs g = fmt_gemm_args(h->att16, Ly.out, Tn);
+      GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->att16), Ly.out, Tn);
       g.out_f32 = h->y;
       g.ldo = D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
@@ -410,13 +432,13 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     // post-LN: h1 = layer_norm(h + attn);  stable: h1 = h + attn, operand = final_layer_norm(h1)
     if ((rc = ln(h->y, h->h, c.stable_ln ? Ly.ln2 : Ly.ln1, h->h1, h->hp16, c.stable_ln, nullptr, 0))) return rc;
     {
-      GemmArgs g = fmt_gemm_args(h->hp16, Ly.ff1, Tn);
-      g.out16 = h->hid16;
+      GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->hp16), Ly.ff1, Tn);
+      g.out16 = reinterpret_cast<u16*>(h->hid16);
       g.ldo16 = Ly.ff2.K / 32;
       if ((rc = fmt_gemm_run(c.dtype, EPI_GELUERF_P16, g, st))) return rc;
     }
     {
-      GemmArgs g = fmt_gemm_args(h->hid16, Ly.ff2, Tn);
+      GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->hid16), Ly.ff2, Tn);
       g.out_f32 = h->y;
       g.ldo = D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
@@ -440,7 +462,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     hipLaunchKernelGGL(aud_softmax_kernel, dim3(1), dim3(64), 0, st, h->cls_logits, out, c.num_labels);
   } else {
     // ---- audio projection: Linear -> LayerNorm -> SiLU
-    GemmArgs g = fmt_gemm_args(h->stack16, h->aproj, Tn);
+    GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->stack16), h->aproj, Tn);
     g.out_f32 = h->yproj;
     g.ldo = c.dim_w;
     if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
@@ -478,11 +500,12 @@ int float_aud_create(const float_aud_cfg_t* cfg, const float_tensor_t* tensors, 
   FH_REQUIRE(cfg->pos_k % 4 == 0 && cfg->pos_groups >= 1 && cfg->hidden % cfg->pos_groups == 0, "bad positional conv shape");
   FH_REQUIRE(cfg->num_labels > 0 || (cfg->dim_w % 256 == 0 && cfg->dim_w <= 1024), "dim_w %d unsupported", cfg->dim_w);
   FH_REQUIRE(cfg->num_labels >= 0 && cfg->num_labels <= 64, "num_labels %d unsupported", cfg->num_labels);
-  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16, "unknown dtype %d", cfg->dtype);
+  FH_REQUIRE(cfg->dtype == FLOAT_DT_BF16 || cfg->dtype == FLOAT_DT_FP16 || cfg->dtype == FLOAT_DT_FP32, "unknown dtype %d", cfg->dtype);
   float_aud* h = new float_aud();
   h->cfg = *cfg;
   TensorTable tt(tensors, n_tensors);
-  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt) : create_impl<FP16>(h, tt);
+  int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt)
+           : (cfg->dtype == FLOAT_DT_FP32) ? create_impl<FP32>(h, tt) : create_impl<FP16>(h, tt);
   if (rc) {
     float_aud_destroy(h);
     return rc;
@@ -503,6 +526,7 @@ int float_aud_classify(float_aud_t* h, const float* a, int32_t n_samples, float*
   FH_REQUIRE(h->cfg.num_labels > 0, "this handle was created with the audio projection head (num_labels = 0)");
   FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
   hipStream_t st = (hipStream_t)stream;
+  if (h->cfg.dtype == FLOAT_DT_FP32) return inference_impl<FP32>(h, a, n_samples, 0, scores, st);
   return h->cfg.dtype == FLOAT_DT_BF16 ? inference_impl<BF16>(h, a, n_samples, 0, scores, st)
                                        : inference_impl<FP16>(h, a, n_samples, 0, scores, st);
 }
@@ -522,6 +546,7 @@ int float_aud_inference(float_aud_t* h, const float* a, int32_t n_samples, int32
   FH_REQUIRE(seq_len >= 1, "seq_len must be >= 1 (got %d)", seq_len);
   FH_REQUIRE(n_samples >= 400, "audio too short: %d samples (the feature extractor needs >= 400)", n_samples);
   hipStream_t st = (hipStream_t)stream;
+  if (h->cfg.dtype == FLOAT_DT_FP32) return inference_impl<FP32>(h, a, n_samples, seq_len, wa, st);
   return h->cfg.dtype == FLOAT_DT_BF16 ? inference_impl<BF16>(h, a, n_samples, seq_len, wa, st)
                                        : inference_impl<FP16>(h, a, n_samples, seq_len, wa, st);
 }

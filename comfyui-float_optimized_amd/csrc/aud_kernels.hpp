@@ -5,6 +5,8 @@
 // from its published module definitions (Wav2Vec2FeatureEncoder / FeatureProjection / PositionalConvEmbedding /
 // EncoderLayer, feat_extract_norm = "group", do_stable_layer_norm = false: the bundled wav2vec2_base config).
 // The transformer's Linear layers run on the FMT's weight-streaming GEMM (fmt_gemm.hpp); this file holds the rest.
+// Every kernel is written against the operand type T (T::elem / T::pack8): 16-bit activations in production, FP32 = the
+// verification mode (the same launch chain with 4-byte elements on v_mfma_f32_16x16x4_f32).
 #pragma once
 #include "common.hpp"
 #include "fmt_pack.hpp"
@@ -56,7 +58,8 @@ __global__ void aud_gn_final_kernel(const float* __restrict__ part, int nchunk, 
 // Pass 3: y = gelu(conv * scale + shift) -> NLC 16-bit [L][C]; one thread = one time step x 8 channels.
 template <class T, int KW>
 __global__ __launch_bounds__(256) void aud_conv0_apply_kernel(const float* __restrict__ x, const float* __restrict__ w, int stride, int L,
-                                                              int C, const float* __restrict__ scale_shift, u16* __restrict__ out) {
+                                                              int C, const float* __restrict__ scale_shift,
+                                                              typename T::elem* __restrict__ out) {
   const int c8 = C >> 3;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)L * c8) return;
@@ -65,17 +68,16 @@ __global__ __launch_bounds__(256) void aud_conv0_apply_kernel(const float* __res
   float xv[KW];
 #pragma unroll
   for (int k = 0; k < KW; ++k) xv[k] = x[t * stride + k];
-  uint4 o;
-  u16* oe = reinterpret_cast<u16*>(&o);
+  typename T::pack8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     const int c = cg * 8 + i;
     float y = 0.f;
 #pragma unroll
     for (int k = 0; k < KW; ++k) y += w[c * KW + k] * xv[k];
-    oe[i] = T::from_float(fh_gelu_erf(y * scale_shift[c] + scale_shift[C + c]));
+    T::set(o, i, fh_gelu_erf(y * scale_shift[c] + scale_shift[C + c]));
   }
-  *reinterpret_cast<uint4*>(out + t * C + cg * 8) = o;
+  T::store8(out + t * C + cg * 8, o);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -87,50 +89,55 @@ __global__ __launch_bounds__(256) void aud_conv0_apply_kernel(const float* __res
 // the global loads of step s+1 are issued before the MFMAs of step s.  Operands swapped (D = W A^T) so a lane
 // holds 4 consecutive output channels of one row.
 struct AudGemmArgs {
-  const u16* A;
+  const void* A;  // T::elem
   long long lda;  // elements between consecutive rows of A
-  const u16* W;   // [N][K]
+  const void* W;  // [N][K] T::elem
   const float* bias;  // [N] or nullptr
-  u16* out;       // [M][ldc]
+  void* out;      // [M][ldc] T::elem
   int M, N, K, ldc, act;  // act 1: GELU(erf)
 };
 
 template <class T>
 __global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
   constexpr int BM = 128, BN = 64, BK = 64;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (BM + BN) * BK * 2];
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  constexpr int EB = T::EB, CB = 8 * EB;  // bytes per element / per pack of 8
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // [2][(BM + BN) * BK * EB]
+  const E* const gA = reinterpret_cast<const E*>(g.A);
+  const E* const gW = reinterpret_cast<const E*>(g.W);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   // staging: A tile = 128 rows x 8 chunks (16 B) = 1024 chunks -> 4 per thread; B tile = 64 x 8 = 512 -> 2 per thread
   // LDS image per operand: [half h = chunk>>2][row][4 chunks], chunk' = (chunk&3) ^ ((row>>1)&3)
-  auto lds_off = [](int rows, int row, int chunk) { return ((chunk >> 2) * rows + row) * 64 + (((chunk & 3) ^ ((row >> 1) & 3)) << 4); };
-  u32x4 ra[4], rb[2];
+  auto lds_off = [](int rows, int row, int chunk) { return ((chunk >> 2) * rows + row) * (4 * CB) + ((chunk & 3) ^ ((row >> 1) & 3)) * CB; };
+  P8 ra[4], rb[2];
   auto issue = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + i * 256, row = e >> 3, ch = e & 7;
       const int m = m0 + row;
-      ra[i] = (m < g.M) ? *reinterpret_cast<const u32x4*>(g.A + (size_t)m * g.lda + k0 + ch * 8) : u32x4{0u, 0u, 0u, 0u};
+      ra[i] = (m < g.M) ? T::load8(gA + (size_t)m * g.lda + k0 + ch * 8) : T::zero8();
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * 256, row = e >> 3, ch = e & 7;
-      rb[i] = *reinterpret_cast<const u32x4*>(g.W + (size_t)(n0 + row) * g.K + k0 + ch * 8);
+      rb[i] = T::load8(gW + (size_t)(n0 + row) * g.K + k0 + ch * 8);
     }
   };
   auto commit = [&](int buf) {
-    unsigned char* sA = smem + buf * (BM + BN) * BK * 2;
-    unsigned char* sB = sA + BM * BK * 2;
+    unsigned char* sA = smem + buf * (BM + BN) * BK * EB;
+    unsigned char* sB = sA + BM * BK * EB;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int e = tid + i * 256;
-      *reinterpret_cast<u32x4*>(sA + lds_off(BM, e >> 3, e & 7)) = ra[i];
+      *reinterpret_cast<P8*>(sA + lds_off(BM, e >> 3, e & 7)) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int e = tid + i * 256;
-      *reinterpret_cast<u32x4*>(sB + lds_off(BN, e >> 3, e & 7)) = rb[i];
+      *reinterpret_cast<P8*>(sB + lds_off(BN, e >> 3, e & 7)) = rb[i];
     }
   };
   f32x4 acc[2][4];
@@ -145,15 +152,15 @@ __global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
   for (int s = 0; s < nsteps; ++s) {
     const int buf = s & 1;
     if (s + 1 < nsteps) issue((s + 1) * BK);
-    const unsigned char* sA = smem + buf * (BM + BN) * BK * 2;
-    const unsigned char* sB = sA + BM * BK * 2;
+    const unsigned char* sA = smem + buf * (BM + BN) * BK * EB;
+    const unsigned char* sB = sA + BM * BK * EB;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-      u32x4 a[2], b[4];
+      P8 a[2], b[4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const u32x4*>(sA + lds_off(BM, w * 32 + i * 16 + r16, kb * 4 + q));
+      for (int i = 0; i < 2; ++i) a[i] = *reinterpret_cast<const P8*>(sA + lds_off(BM, w * 32 + i * 16 + r16, kb * 4 + q));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u32x4*>(sB + lds_off(BN, j * 16 + r16, kb * 4 + q));
+      for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const P8*>(sB + lds_off(BN, j * 16 + r16, kb * 4 + q));
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -183,12 +190,7 @@ __global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fh_gelu_erf(v[r]);
       }
-      ushort4 o;
-      o.x = T::from_float(v[0]);
-      o.y = T::from_float(v[1]);
-      o.z = T::from_float(v[2]);
-      o.w = T::from_float(v[3]);
-      *reinterpret_cast<ushort4*>(g.out + (size_t)m * g.ldc + n) = o;
+      T::store4(reinterpret_cast<E*>(g.out) + (size_t)m * g.ldc + n, v[0], v[1], v[2], v[3]);
     }
   }
 }
@@ -198,8 +200,9 @@ __global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
 // along time) fused with the feature projection's LayerNorm (Wav2Vec2FeatureProjection.layer_norm, affine).
 // One wave per output frame; writes the packed 16-bit A operand of the projection GEMM (K = C).
 template <class T, int NV>
-__global__ __launch_bounds__(256) void aud_interp_ln_kernel(const u16* __restrict__ f, int L, int Tn, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps, u16* __restrict__ out) {
+__global__ __launch_bounds__(256) void aud_interp_ln_kernel(const typename T::elem* __restrict__ f, int L, int Tn,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            typename T::elem* __restrict__ out) {
   constexpr int C = NV * 256;
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -213,12 +216,10 @@ __global__ __launch_bounds__(256) void aud_interp_ln_kernel(const u16* __restric
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
-    const ushort4 a = *reinterpret_cast<const ushort4*>(f + (size_t)i0 * C + c);
-    const ushort4 b = *reinterpret_cast<const ushort4*>(f + (size_t)i1 * C + c);
-    v[i][0] = l0 * T::to_float(a.x) + l1 * T::to_float(b.x);
-    v[i][1] = l0 * T::to_float(a.y) + l1 * T::to_float(b.y);
-    v[i][2] = l0 * T::to_float(a.z) + l1 * T::to_float(b.z);
-    v[i][3] = l0 * T::to_float(a.w) + l1 * T::to_float(b.w);
+    const typename T::elem* a = f + (size_t)i0 * C + c;
+    const typename T::elem* b = f + (size_t)i1 * C + c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = l0 * T::to_float(a[e]) + l1 * T::to_float(b[e]);
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   const float mu = wave_sum(s) * (1.f / C);
@@ -233,12 +234,8 @@ __global__ __launch_bounds__(256) void aud_interp_ln_kernel(const u16* __restric
     const int c = i * 256 + lane * 4;
     const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
     const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-    ushort4 o;
-    o.x = T::from_float((v[i][0] - mu) * rstd * gm.x + bt.x);
-    o.y = T::from_float((v[i][1] - mu) * rstd * gm.y + bt.y);
-    o.z = T::from_float((v[i][2] - mu) * rstd * gm.z + bt.z);
-    o.w = T::from_float((v[i][3] - mu) * rstd * gm.w + bt.w);
-    *reinterpret_cast<ushort4*>(out + fmt_pack_off(t, c, C / 32)) = o;
+    T::store4(out + fmt_pack_off(t, c, C / 32), (v[i][0] - mu) * rstd * gm.x + bt.x, (v[i][1] - mu) * rstd * gm.y + bt.y,
+              (v[i][2] - mu) * rstd * gm.z + bt.z, (v[i][3] - mu) * rstd * gm.w + bt.w);
   }
 }
 
@@ -255,8 +252,8 @@ struct AudLnArgs {
   const float *gamma, *beta;
   float eps;
   float* out_f32;
-  u16* out_p16;
-  u16* out_stack;
+  void* out_p16;    // T::elem
+  void* out_stack;  // T::elem
   int stack_col, stack_kb;
   int M, silu;
   int keep_sum;  // 1: out_f32 = a + res (the un-normalised residual stream of a pre-LayerNorm encoder), 0: the LayerNorm output
@@ -308,15 +305,9 @@ __global__ __launch_bounds__(256) void aud_ln_kernel(AudLnArgs g) {
       y.w = fh_silu(y.w);
     }
     if (g.out_f32) *reinterpret_cast<float4*>(g.out_f32 + (size_t)row * D + c) = g.keep_sum ? v[i] : y;
-    if (g.out_p16 || g.out_stack) {
-      ushort4 o;
-      o.x = T::from_float(y.x);
-      o.y = T::from_float(y.y);
-      o.z = T::from_float(y.z);
-      o.w = T::from_float(y.w);
-      if (g.out_p16) *reinterpret_cast<ushort4*>(g.out_p16 + fmt_pack_off(row, c, D / 32)) = o;
-      if (g.out_stack) *reinterpret_cast<ushort4*>(g.out_stack + fmt_pack_off(row, g.stack_col + c, g.stack_kb)) = o;
-    }
+    typedef typename T::elem E;
+    if (g.out_p16) T::store4(reinterpret_cast<E*>(g.out_p16) + fmt_pack_off(row, c, D / 32), y.x, y.y, y.z, y.w);
+    if (g.out_stack) T::store4(reinterpret_cast<E*>(g.out_stack) + fmt_pack_off(row, g.stack_col + c, g.stack_kb), y.x, y.y, y.z, y.w);
   }
 }
 
@@ -328,8 +319,9 @@ __global__ __launch_bounds__(256) void aud_ln_kernel(AudLnArgs g) {
 //   workgroup = (16 output frames, group pair); its 4 waves split the taps, partial sums meet in LDS.
 //   A fragments are converted from the fp32 residual stream on the fly; W is [pair][tap][96 out][96 in] 16-bit.
 template <class T, int GP /* channels per merged group */>
-__global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restrict__ x, int Tn, int D, const u16* __restrict__ W,
+__global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restrict__ x, int Tn, int D, const typename T::elem* __restrict__ W,
                                                           const float* __restrict__ bias, int ktaps, int pad, float* __restrict__ out) {
+  typedef typename T::pack8 P8;
   constexpr int NT = GP / 16, KBN = GP / 32;
   __shared__ float red[4][16][GP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -343,21 +335,20 @@ __global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restric
     const int t = t0 + r16 + kk - pad;
     const bool ok = t >= 0 && t < Tn;
     const float* xr = x + (size_t)(ok ? t : 0) * D + gp * GP + q * 8;
-    const u16* wr = W + (((size_t)gp * ktaps + kk) * GP + r16) * GP + q * 8;
+    const typename T::elem* wr = W + (((size_t)gp * ktaps + kk) * GP + r16) * GP + q * 8;
 #pragma unroll
     for (int kb = 0; kb < KBN; ++kb) {
-      u32x4 a = u32x4{0u, 0u, 0u, 0u};
+      P8 a = T::zero8();
       if (ok) {
         const float4 f0 = *reinterpret_cast<const float4*>(xr + kb * 32);
         const float4 f1 = *reinterpret_cast<const float4*>(xr + kb * 32 + 4);
-        a[0] = (unsigned)T::from_float(f0.x) | ((unsigned)T::from_float(f0.y) << 16);
-        a[1] = (unsigned)T::from_float(f0.z) | ((unsigned)T::from_float(f0.w) << 16);
-        a[2] = (unsigned)T::from_float(f1.x) | ((unsigned)T::from_float(f1.y) << 16);
-        a[3] = (unsigned)T::from_float(f1.z) | ((unsigned)T::from_float(f1.w) << 16);
+        const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) T::set(a, e, fv[e]);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const u32x4 b = *reinterpret_cast<const u32x4*>(wr + (size_t)j * 16 * GP + kb * 32);
+        const P8 b = T::load8(wr + (size_t)j * 16 * GP + kb * 32);
         acc[j] = T::mfma(a, b, acc[j]);  // D[row = frame q*4+reg][col = channel r16]
       }
     }
@@ -386,7 +377,9 @@ __global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restric
 // stopped at 3900 / 10 000 frames).  A clip of at most one tile takes the same arithmetic path as before.
 constexpr int kAudKeyTile = 2048;
 template <class T>
-__global__ __launch_bounds__(256) void aud_attn_kernel(const u16* __restrict__ qkv, int Tn, int D, int heads, u16* __restrict__ out) {
+__global__ __launch_bounds__(256) void aud_attn_kernel(const typename T::elem* __restrict__ qkv, int Tn, int D, int heads,
+                                                       typename T::elem* __restrict__ out) {
+  typedef typename T::elem E;
   constexpr int HD = 64;
   __shared__ float sm[4 * (HD + kAudKeyTile)];  // per wave: q[64] + p[tile]
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -399,19 +392,18 @@ __global__ __launch_bounds__(256) void aud_attn_kernel(const u16* __restrict__ q
   __syncthreads();
   if (!live) return;
   float m = -INFINITY, l = 0.f, acc = 0.f;
-  const u16* vbase = qkv + 2 * D + h * HD + lane;
+  const E* vbase = qkv + 2 * D + h * HD + lane;
   for (int j0 = 0; j0 < Tn; j0 += kAudKeyTile) {
     const int nt = min(kAudKeyTile, Tn - j0);
     float mx = -INFINITY;
     for (int j = lane; j < nt; j += 64) {
-      const u16* kp = qkv + (size_t)(j0 + j) * ld + D + h * HD;
+      const E* kp = qkv + (size_t)(j0 + j) * ld + D + h * HD;
       float dot = 0.f;
 #pragma unroll
       for (int c = 0; c < HD; c += 8) {
-        const uint4 u = *reinterpret_cast<const uint4*>(kp + c);
-        const u16* e = reinterpret_cast<const u16*>(&u);
+        const typename T::pack8 u = T::load8(kp + c);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dot += sq[c + i] * T::to_float(e[i]);
+        for (int i = 0; i < 8; ++i) dot += sq[c + i] * T::get(u, i);
       }
       sp[j] = dot;
       mx = fmaxf(mx, dot);
@@ -430,7 +422,7 @@ __global__ __launch_bounds__(256) void aud_attn_kernel(const u16* __restrict__ q
     m = mn;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    const u16* vp = vbase + (size_t)j0 * ld;
+    const E* vp = vbase + (size_t)j0 * ld;
     float a = 0.f;
     int j = 0;
     for (; j + 4 <= nt; j += 4) {
@@ -453,7 +445,7 @@ __global__ __launch_bounds__(256) void aud_attn_kernel(const u16* __restrict__ q
 template <class T, int KW>
 __global__ __launch_bounds__(256) void aud_conv0_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                            int stride, int L, int C, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, u16* __restrict__ out) {
+                                                           const float* __restrict__ beta, float eps, typename T::elem* __restrict__ out) {
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= L) return;
@@ -492,7 +484,7 @@ __global__ __launch_bounds__(256) void aud_conv0_ln_kernel(const float* __restri
 // Layers 1..n-1: the conv GEMM stores conv + bias (16-bit, row-major); this pass normalises each row over its C channels
 // (affine) and applies GELU in place.  One wave per row.
 template <class T, int NV>
-__global__ __launch_bounds__(256) void aud_rowln_gelu_kernel(u16* __restrict__ x, int M, const float* __restrict__ gamma,
+__global__ __launch_bounds__(256) void aud_rowln_gelu_kernel(typename T::elem* __restrict__ x, int M, const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float eps) {
   constexpr int C = NV * 256;
   const int lane = threadIdx.x & 63;
@@ -502,11 +494,9 @@ __global__ __launch_bounds__(256) void aud_rowln_gelu_kernel(u16* __restrict__ x
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const ushort4 a = *reinterpret_cast<const ushort4*>(x + (size_t)row * C + i * 256 + lane * 4);
-    v[i][0] = T::to_float(a.x);
-    v[i][1] = T::to_float(a.y);
-    v[i][2] = T::to_float(a.z);
-    v[i][3] = T::to_float(a.w);
+    const typename T::elem* a = x + (size_t)row * C + i * 256 + lane * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[i][e] = T::to_float(a[e]);
     s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
   }
   const float mu = wave_sum(s) * (1.f / C);
@@ -521,12 +511,8 @@ __global__ __launch_bounds__(256) void aud_rowln_gelu_kernel(u16* __restrict__ x
     const int c = i * 256 + lane * 4;
     const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
     const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-    ushort4 o;
-    o.x = T::from_float(fh_gelu_erf((v[i][0] - mu) * rstd * gm.x + bt.x));
-    o.y = T::from_float(fh_gelu_erf((v[i][1] - mu) * rstd * gm.y + bt.y));
-    o.z = T::from_float(fh_gelu_erf((v[i][2] - mu) * rstd * gm.z + bt.z));
-    o.w = T::from_float(fh_gelu_erf((v[i][3] - mu) * rstd * gm.w + bt.w));
-    *reinterpret_cast<ushort4*>(x + (size_t)row * C + c) = o;
+    T::store4(x + (size_t)row * C + c, fh_gelu_erf((v[i][0] - mu) * rstd * gm.x + bt.x), fh_gelu_erf((v[i][1] - mu) * rstd * gm.y + bt.y),
+              fh_gelu_erf((v[i][2] - mu) * rstd * gm.z + bt.z), fh_gelu_erf((v[i][3] - mu) * rstd * gm.w + bt.w));
   }
 }
 

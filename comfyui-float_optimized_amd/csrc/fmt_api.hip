@@ -1033,7 +1033,8 @@ int create_impl(float_fmt* h, const TensorTable& tt) {
 // ---------------------------------------------------------------- GEMM service (fmt_gemm.hpp)
 int fmt_pack_linear(DevicePool* pool, int dtype, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
                     FmtLin* out) {
-  FH_REQUIRE(dtype == FLOAT_DT_BF16 || dtype == FLOAT_DT_FP16, "the GEMM service runs 16-bit operands (dtype %d)", dtype);
+  FH_REQUIRE(dtype == FLOAT_DT_BF16 || dtype == FLOAT_DT_FP16 || dtype == FLOAT_DT_FP32, "the GEMM service: unknown dtype %d", dtype);
+  if (dtype == FLOAT_DT_FP32) return pack_linear_pool<FP32>(pool, tt, names, N_each, K, out);
   return dtype == FLOAT_DT_BF16 ? pack_linear_pool<BF16>(pool, tt, names, N_each, K, out)
                                 : pack_linear_pool<FP16>(pool, tt, names, N_each, K, out);
 }
@@ -1063,6 +1064,7 @@ GemmArgs fmt_gemm_args(const u16* A, const FmtLin& L, int M) { return base_args(
 
 void fmt_gemm_prime(int dtype) {
   if (dtype == FLOAT_DT_BF16) prime_kernels<BF16>();
+  else if (dtype == FLOAT_DT_FP32) prime_kernels<FP32>();
   else prime_kernels<FP16>();
 }
 
@@ -1079,6 +1081,7 @@ static int gemm_run_t(int epi, const GemmArgs& g, hipStream_t s) {
 }
 
 int fmt_gemm_run(int dtype, int epi, GemmArgs g, hipStream_t s) {
+  if (dtype == FLOAT_DT_FP32) return gemm_run_t<FP32>(epi, g, s);
   return dtype == FLOAT_DT_BF16 ? gemm_run_t<BF16>(epi, g, s) : gemm_run_t<FP16>(epi, g, s);
 }
 

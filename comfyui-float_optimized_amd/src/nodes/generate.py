@@ -36,7 +36,7 @@ def split_unified(state):
 
 
 class InferenceAgent:
-    def __init__(self, opt, parts=None, device=None, max_frames=32, use_graph=2, fmt_dtype=None, dec_dtype=None):
+    def __init__(self, opt, parts=None, device=None, max_frames=32, use_graph=2, fmt_dtype=None, dec_dtype=None, aud_dtype=None):
         self.opt = opt
         self.rank = torch.device(device if device is not None else getattr(opt, "rank", "cuda:0"))
         self.cfg = FmtConfig.from_options(opt)
@@ -57,12 +57,11 @@ class InferenceAgent:
                               dtype=self.G.dec.dtype, direction_weight=parts["dec"]["direction.weight"])
         # wav2vec2 + audio projection as one HIP operator (float_aud_*)
         aud_sd, aud_cfg = parts["audio_encoder"]
-        self.audio_encoder = AudioEncoderHIP(aud_sd, aud_cfg, self.rank, dtype=os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16"),
-                                             sampling_rate=opt.sampling_rate, fps=opt.fps)
+        aud_dtype = aud_dtype or os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16")
+        self.audio_encoder = AudioEncoderHIP(aud_sd, aud_cfg, self.rank, dtype=aud_dtype, sampling_rate=opt.sampling_rate, fps=opt.fps)
         # speech-to-emotion (emotion="none"): the wav2vec2-large variant of the same operator with its classification head
         ser = parts.get("emotion_encoder")
-        self.emotion_encoder = Audio2EmotionHIP(ser[0], ser[1], self.rank, dtype=os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16")) \
-            if ser is not None else None
+        self.emotion_encoder = Audio2EmotionHIP(ser[0], ser[1], self.rank, dtype=aud_dtype) if ser is not None else None
         # callable(a) -> (1,7) softmax scores; None disables emotion="none"
         self.emotion_predictor = self.emotion_encoder.predict_emotion if ser is not None else parts.get("emotion_predictor")
 

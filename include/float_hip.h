@@ -47,7 +47,7 @@ enum {
 };
 
 /* MFMA operand type; accumulation, statistics, softmax, residual stream and ODE state are fp32 in every mode.
- * FLOAT_DT_FP32 (FMT, decoder, appearance encoder): the verification mode - fp32 operands on v_mfma_f32_16x16x4_f32, the same launch chain and
+ * FLOAT_DT_FP32 (every operator): the verification mode - fp32 operands on v_mfma_f32_16x16x4_f32, the same launch chain and
  * the same kernels with 4-byte elements, held to the reference goldens at 1e-4 (tests/test_fmt_fp32_gpu.py,
  * tests/test_dec_fp32_gpu.py); 1/16 of the 16-bit MFMA rate, no tuned tilings. */
 enum { FLOAT_DT_BF16 = 0, FLOAT_DT_FP16 = 1, FLOAT_DT_FP32 = 2 };
@@ -303,7 +303,8 @@ typedef struct {
   int32_t pos_k, pos_groups;   /* num_conv_pos_embeddings 128, groups 16 */
   int32_t dim_w;               /* 512 */
   int32_t only_last;           /* opt.only_last_features */
-  int32_t dtype;               /* FLOAT_DT_* of activations / weights; statistics and the residual stream are fp32 */
+  int32_t dtype;               /* FLOAT_DT_* of activations / weights (FLOAT_DT_FP32 = verification mode); statistics and the
+                                  residual stream are fp32 */
   float ln_eps;                /* layer_norm_eps 1e-5 */
   /* Architecture switches of the wav2vec2-large family used by the speech-emotion model
    * (src/nodes/model_configs/emotion_ser/config.json): all 0 for wav2vec2-base. */

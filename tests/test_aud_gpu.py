@@ -12,10 +12,10 @@ pkg = load_pkg()
 W, C = pkg.weights, pkg.config
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp16": 3e-3, "bf16": 2.5e-2}
+TOL = {"fp16": 3e-3, "bf16": 2.5e-2, "fp32": 2e-5}  # fp32 = the verification mode (the same kernels, 4-byte operands)
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("tag", ["small", "base"])
 def test_audio_golden(tag, dtype):
     g = golden("aud_" + tag)
@@ -72,7 +72,7 @@ def test_audio_weight_norm_key_variants_and_errors():
         pkg.audio.AudioEncoderHIP(sd, bad, "cuda:0")
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp16", "bf16", "fp32"])
 @pytest.mark.parametrize("tag", ["small", "xlsr"])
 def test_speech_emotion_golden(tag, dtype):
     """float_aud_classify (wav2vec2-large variant + classification head) vs the golden assembled from transformers'
@@ -85,7 +85,7 @@ def test_speech_emotion_golden(tag, dtype):
     scores = ser.predict_emotion(a).cpu()
     d = float((scores - g["scores"]).abs().max())
     print(tag, dtype, "scores max|d| %.3e" % d, [round(float(v), 4) for v in scores[0]])
-    assert scores.shape == g["scores"].shape and d < (1e-3 if dtype == "fp16" else 1e-2)
+    assert scores.shape == g["scores"].shape and d < {"fp16": 1e-3, "bf16": 1e-2, "fp32": 2e-6}[dtype]
     assert abs(float(scores.sum()) - 1.0) < 1e-5 and int(scores.argmax()) == int(g["scores"].argmax())
     assert torch.equal(ser.predict_emotion(a).cpu(), scores)
     with pytest.raises(TypeError):
