@@ -210,8 +210,22 @@ int raise_lds_limits() {
 template <class T>
 int create_impl(float_dec* h, const TensorTable& tt) {
   const int size = h->cfg.size, sdim = h->cfg.style_dim;
-  static const int chan[] = {0, 0, 512, 512, 512, 512, 256, 128, 64, 32, 16};  // by log2(res), styledecoder.py:457-467
   const int log_size = ilog2(size);
+  // channels by log2(resolution): the reference's table (styledecoder.py:457-467: 512 up to 32 px, then 256 / 128 / 64 / 32 / 16
+  // times channel_multiplier) is read off the checkpoint itself - the output channels of every level's convs - so any
+  // channel_multiplier loads (the kernels take channel counts in multiples of 32, the flow kernel up to 512)
+  int chan[12] = {0, 0, 512, 512, 512, 512, 256, 128, 64, 32, 16, 0};
+  {
+    const float_tensor_t* c1 = tt.find("conv1.conv.weight");
+    if (c1 && c1->ndim == 5) chan[2] = (int)c1->shape[1];
+    for (int li = 0; li < log_size - 2; ++li) {
+      const float_tensor_t* w = tt.find("convs." + std::to_string(2 * li) + ".conv.weight");
+      if (w && w->ndim == 5) chan[li + 3] = (int)w->shape[1];
+    }
+    for (int l = 2; l <= log_size; ++l)
+      FH_REQUIRE(chan[l] >= 32 && chan[l] <= 512 && chan[l] % 32 == 0 && (chan[l] & (chan[l] - 1)) == 0,
+                 "decoder level %d px has %d channels: the HIP decoder takes powers of two in [32, 512]", 1 << l, chan[l]);
+  }
   h->n_levels = log_size - 2;
   std::vector<float> wm_rows, bm_host;  // rows = modulation outputs, [Stot][sdim]
   int rc;

@@ -168,9 +168,15 @@ class LoadFloatSynthesisModel:
             blur_kernel = safe_parse_list_str(blur_kernel_str, int)
         except ValueError as e:
             raise ValueError("Invalid blur_kernel_str format: %s. Must be Python list syntax e.g. '[1,3,3,1]'" % e)
-        if channel_multiplier != 1 or blur_kernel != [1, 3, 3, 1]:
-            raise ValueError("the HIP decoder implements channel_multiplier=1 and blur_kernel=[1,3,3,1] (the released checkpoints)")
+        if blur_kernel != [1, 3, 3, 1]:
+            raise ValueError("the HIP decoder implements blur_kernel=[1,3,3,1] (the FIR of the released checkpoints) only")
         sd = _load_sd(path)
+        # channel_multiplier: the operator reads every level's channel count off the weights (like the reference's
+        # load_state_dict would fail on a mismatch, nodes_vadv_loader.py:567-611, a widget that contradicts the file is refused)
+        w512 = sd.get("convs.%d.conv.weight" % (2 * 3))  # 64-px level: 256 * channel_multiplier output channels
+        if w512 is not None and w512.shape[1] != 256 * channel_multiplier:
+            raise ValueError("channel_multiplier=%d does not match the checkpoint (64-px level has %d channels = multiplier %g)"
+                             % (channel_multiplier, w512.shape[1], w512.shape[1] / 256.0))
         for key in ("conv1.conv.modulation.weight", "direction.weight"):  # nodes_vadv_loader.py:574-589
             if key not in sd:
                 raise KeyError("Key '%s' for synthesis architecture inference not found." % key)

@@ -80,7 +80,7 @@ def synth_fmt_state(cfg, seed=0):
 DEC_CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
 
 
-def synth_decoder_state(size=512, style_dim=512, motion_dim=20, seed=0, flow_gain=0.1, rgb_gain=0.4):
+def synth_decoder_state(size=512, style_dim=512, motion_dim=20, seed=0, flow_gain=0.1, rgb_gain=0.4, channel_multiplier=1):
     """Synthesis (motion-AE decoder) weights, prefix `motion_autoencoder.dec.` stripped.
     StyleGAN2-style layers carry their 1/sqrt(fan_in) equalised-lr scale in the forward
     pass, so N(0,1) weights are the natural scale.  `flow_gain` shrinks the ToFlow conv so
@@ -89,6 +89,7 @@ def synth_decoder_state(size=512, style_dim=512, motion_dim=20, seed=0, flow_gai
     pixel); `rgb_gain` keeps most pixels inside the clamp range so errors are not hidden."""
     sd = {}
     log_size = int(math.log2(size))
+    DEC_CHANNELS = {r: (c if r <= 32 else c * channel_multiplier) for r, c in globals()["DEC_CHANNELS"].items()}  # styledecoder.py:457-467
     blur = torch.tensor([1.0, 3.0, 3.0, 1.0])
     k2 = blur[None, :] * blur[:, None]
     k2 = k2 / k2.sum()
@@ -131,14 +132,14 @@ def synth_decoder_state(size=512, style_dim=512, motion_dim=20, seed=0, flow_gai
     return sd
 
 
-def synth_feats(size=512, seed=0, smooth=8, hi=0.02):
+def synth_feats(size=512, seed=0, smooth=8, hi=0.02, channel_multiplier=1):
     """Appearance skip features in the reference order (encoder.py:220-231): spatial
     8,16,...,size with the decoder's channel map.  Smooth random fields (low-res noise,
     bilinearly enlarged) plus a little per-pixel noise, O(1) amplitude."""
     feats = []
     r = 8
     while r <= size:
-        c = DEC_CHANNELS[r]
+        c = DEC_CHANNELS[r] * (channel_multiplier if r > 32 else 1)
         lo = max(2, r // smooth)
         base = _randn(seed, "feat%d.lo" % r, (1, c, lo, lo))
         f = torch.nn.functional.interpolate(base, size=(r, r), mode="bilinear", align_corners=False)

@@ -164,3 +164,22 @@ def test_set_feats_validates_every_map():
         dec.set_feats(bad)
     with pytest.raises(ValueError):
         dec.set_feats(good[:3])
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_dec_channel_multiplier_2(dtype):
+    """Synthesis(channel_multiplier=2) of the reference (styledecoder.py:447-467; the widget of Load FLOAT Synthesis,
+    nodes_vadv_loader.py:567-611): the operator reads every level's channel count off the checkpoint (512 / 256 channels at
+    64 / 128 px here).  Un-clamped output vs the reference: fp32 mode max-abs <= 1e-4, fp16 rel-L2 <= 5e-3."""
+    g = golden("dec_cm2_128")
+    sd = W.synth_decoder_state(128, seed=g["seed"], channel_multiplier=2)
+    feats = W.synth_feats(128, seed=g["seed"], channel_multiplier=2)
+    dec = pkg.decoder.SynthesisHIP(sd, 128, 512, "cuda:0", dtype=dtype, max_frames=2)
+    assert dec.feat_shapes()[-2:] == [(512, 64), (256, 128)]
+    dec.set_feats(feats)
+    raw = dec.synthesis_raw(g["s_r"], g["r_d"]).cpu()
+    m = float((raw - g["raw"]).abs().max())
+    r = float((raw - g["raw"]).norm() / g["raw"].norm())
+    print("channel_multiplier 2, %s: max|d| %.2e rel-L2 %.2e" % (dtype, m, r))
+    assert (m <= 1e-4) if dtype == "fp32" else (r <= 5e-3)
+    assert dec.saturation() == 0

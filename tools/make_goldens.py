@@ -376,6 +376,23 @@ def gen_dec_stress(ns, size, seed, kind, sparse):
     save("dec_stress_%s_%d" % (kind, size), **arrs)
 
 
+def gen_dec_cm2(ns, seed=1800, size=128):
+    """Synthesis with channel_multiplier=2 (styledecoder.py:447-467: 512 / 256 channels at 64 / 128 px), two frames."""
+    print("[decoder channel_multiplier 2, size %d]" % size)
+    d = ns.styledecoder.Synthesis(size, 512, 20, channel_multiplier=2)
+    sd = weights.synth_decoder_state(size, seed=seed, channel_multiplier=2)
+    d.load_state_dict(sd, strict=True)
+    d.eval()
+    feats = weights.synth_feats(size, seed=seed, channel_multiplier=2)
+    s_r = rnd(seed + 21, 1, 512)
+    r_d = rnd(seed + 22, 1, 2, 512, std=0.5)
+    with torch.no_grad():
+        raw = torch.cat([d(s_r + r_d[:, t], None, feats)[0] for t in range(2)])
+    orc = torch.cat([O.synthesis(sd, s_r + r_d[:, t], feats) for t in range(2)])
+    print("  raw std %.3f ; oracle-ref max|d| %.3e" % (float(raw.std()), maxdiff(orc, raw)[0]))
+    save("dec_cm2_%d" % size, seed=seed, size=size, s_r=s_r, r_d=r_d, raw=raw)
+
+
 def gen_e2e_config1(ns, seed=900):
     """BASELINE.json configs[0]: 1 s audio -> 25 frames, 512x512, nfe=10 (9 Euler evaluations), fp32, the
     reference's own sampler (nodes_adv.py:545-694) and decode loop (FLOAT.py:113-169) chained on CPU."""
@@ -602,6 +619,7 @@ def main():
         gen_dec_stress(ns, 64, 1710, "range", sparse=False)
         gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
         gen_dec_stress(ns, 512, 1730, "range", sparse=True)
+        gen_dec_cm2(ns)
         return
     if os.environ.get("GOLDENS_ONLY") == "enc":
         gen_encoder(ns, 64, seed=1000, sparse=False)
@@ -634,6 +652,7 @@ def main():
     gen_dec_stress(ns, 64, 1710, "range", sparse=False)
     gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
     gen_dec_stress(ns, 512, 1730, "range", sparse=True)
+    gen_dec_cm2(ns)
     gen_encoder(ns, 64, seed=1000, sparse=False)
     gen_encoder(ns, 512, seed=1100, sparse=True)
     gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
