@@ -292,52 +292,96 @@ __device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, 
   const int my = Y >> 1, mx = X >> 1;
   const int y0 = (Y & 1) ? my : my - 1, x0 = (X & 1) ? mx : mx - 1;
   const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
+  // every tap is loaded from a clamped (valid) address and an outside tap gets weight 0: no branch per tap (a divergent
+  // branch around each load cost an exec save / restore and kept the loads from being issued back to back)
   float4 t[4];
+  float tw[4];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int yy = y0 + a, xx = x0 + b;
       const bool in = yy >= 0 && yy < Rp && xx >= 0 && xx < Rp;
-      t[a * 2 + b] = in ? *reinterpret_cast<const float4*>(prev + ((size_t)(f * Rp + yy) * Rp + xx) * 4) : float4{0.f, 0.f, 0.f, 0.f};
+      const int yc = min(max(yy, 0), Rp - 1), xc = min(max(xx, 0), Rp - 1);
+      t[a * 2 + b] = *reinterpret_cast<const float4*>(prev + ((size_t)(f * Rp + yc) * Rp + xc) * 4);
+      tw[a * 2 + b] = in ? 1.f : 0.f;
     }
   out[0] = out[1] = out[2] = 0.f;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const float wgt = (a ? 1.f - wy0 : wy0) * (b ? 1.f - wx0 : wx0);
+      const float wgt = (a ? 1.f - wy0 : wy0) * (b ? 1.f - wx0 : wx0) * tw[a * 2 + b];
       out[0] += wgt * t[a * 2 + b].x;
       out[1] += wgt * t[a * 2 + b].y;
       out[2] += wgt * t[a * 2 + b].z;
     }
 }
 
-__device__ __forceinline__ float fh_tanh_fast(float x) {  // 1 - 2/(1 + e^{2x}); saturates cleanly at +-1
-  return 1.f - 2.f / (1.f + __expf(2.f * x));
+// 1 - 2/(1 + e^{2x}); saturates cleanly at +-1.  EXACT: IEEE division (the fp32 verification mode); else v_rcp_f32 (1 ulp:
+// 1e-7 on a value that positions a sample to 1/R of a pixel at best) - a division is ~10 instructions, the flow kernel had 12.
+template <bool EXACT>
+__device__ __forceinline__ float fh_tanh_fast(float x) {
+  const float d = 1.f + __expf(2.f * x);
+  return EXACT ? 1.f - 2.f / d : 1.f - 2.f * __builtin_amdgcn_rcpf(d);
+}
+template <bool EXACT>
+__device__ __forceinline__ float fh_sigmoid_t(float x) {
+  const float d = 1.f + __expf(-x);
+  return EXACT ? 1.f / d : __builtin_amdgcn_rcpf(d);
 }
 
 // One run of PIX consecutive pixels of a row (first pixel p0 = Y * R + X0 of frame f) for one lane group: ToFlow (1x1
 // modulated conv + up-sampled previous flow -> tanh / sigmoid), grid_sample of the skip features, blend, ToRGB, the pyramids,
 // the next level's input, the final frame.  xu[k] = this lane's 8 channels (c0 ..) of conv2's output at pixel k.
+// What dec_flow_pixels needs per frame, formed once per workgroup: the nine bias values (they were re-loaded from global memory
+// for every run of pixels) and the frame's base pointers, so that every access inside the pixel loop is a uniform base plus a
+// 32-bit lane offset (the 64-bit index arithmetic per access was 90 of the kernel's 1180 vector instructions per iteration).
+template <class T>
+struct FlowFrame {
+  float bf[3], b1[3], b2[3];
+  const float *pflow, *prgb;      // this frame's previous pyramids or nullptr
+  float *flow_out, *rgb_out;      // this frame's pyramids
+  float* final_hwc;               // this frame's output image (final_mode 1)
+  float* final_chw;               // this frame's raw output (final_mode 2)
+  typename T::elem* xnext;        // this frame's next-level input or nullptr
+};
+template <class T>
+__device__ __forceinline__ FlowFrame<T> dec_flow_frame(const FlowArgs& g, int f) {
+  FlowFrame<T> ff;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    ff.bf[j] = g.bflow[j];
+    ff.b1[j] = g.b1[j];
+    ff.b2[j] = g.b2[j];
+  }
+  const size_t npix = (size_t)g.R * g.R, npp = (size_t)(g.R >> 1) * (g.R >> 1);
+  ff.pflow = g.pflow ? g.pflow + (size_t)f * npp * 4 : nullptr;
+  ff.prgb = g.prgb ? g.prgb + (size_t)f * npp * 4 : nullptr;
+  ff.flow_out = g.flow_out ? g.flow_out + (size_t)f * npix * 4 : nullptr;
+  ff.rgb_out = g.rgb_out ? g.rgb_out + (size_t)f * npix * 4 : nullptr;
+  ff.final_hwc = g.final_out ? g.final_out + (size_t)f * npix * 3 : nullptr;
+  ff.final_chw = ff.final_hwc;
+  ff.xnext = g.xnext ? reinterpret_cast<typename T::elem*>(g.xnext) + (size_t)f * npix * g.C : nullptr;
+  return ff;
+}
+
 template <class T, int PIX>
-__device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* __restrict__ sw, int f, int p0, int sub, int lpp,
-                                                const typename T::pack8 (&xu)[PIX], unsigned& sm) {
+__device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFrame<T>& ff, const float* __restrict__ sw, int p0, int sub,
+                                                int lpp, const typename T::pack8 (&xu)[PIX], unsigned& sm) {
   typedef typename T::elem E;
   typedef typename T::pack8 P8;
   const E* const featp = reinterpret_cast<const E*>(g.feat);
-  E* const xnextp = reinterpret_cast<E*>(g.xnext);
   const int C = g.C, c0 = sub * 8;
   const bool owner = sub < PIX;
-  const float bf0 = g.bflow[0], bf1 = g.bflow[1], bf2 = g.bflow[2];
-  const float b10 = g.b1[0], b11 = g.b1[1], b12 = g.b1[2], b20 = g.b2[0], b21 = g.b2[1], b22 = g.b2[2];
+  const float bf0 = ff.bf[0], bf1 = ff.bf[1], bf2 = ff.bf[2];
+  const float b10 = ff.b1[0], b11 = ff.b1[1], b12 = ff.b1[2], b20 = ff.b2[0], b21 = ff.b2[1], b22 = ff.b2[2];
   const int R = g.R, npix = R * R, Rp = R >> 1;
   const float fR = (float)R;
   {
     const int Y = p0 / R, X0 = p0 - Y * R;  // R % PIX == 0: the PIX pixels share a row
-    const size_t po0 = (size_t)f * npix + p0;
     float upf[3] = {0.f, 0.f, 0.f};  // up-sampled previous flow of THIS lane's pixel
-    if (g.pflow && owner) up2_tap3(g.pflow, f, Rp, Y, X0 + sub, upf);
+    if (ff.pflow && owner) up2_tap3(ff.pflow, 0, Rp, Y, X0 + sub, upf);
     const float gy = g.lin[Y];
     float o[PIX][3];
 #pragma unroll
@@ -371,12 +415,12 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
         o[k][2] += __shfl_xor(o[k][2], d, 64);
       }
     }
-    float mask[PIX], ax[PIX], ay[PIX];
+    float mask[PIX], ax[PIX], ay[PIX], inw[PIX][4];
     P8 fu[PIX][4];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
-      const float sx = fh_tanh_fast(o[k][0]) + g.lin[X0 + k], sy = fh_tanh_fast(o[k][1]) + gy;
-      mask[k] = fh_sigmoid(o[k][2]);
+      const float sx = fh_tanh_fast<T::is32>(o[k][0]) + g.lin[X0 + k], sy = fh_tanh_fast<T::is32>(o[k][1]) + gy;
+      mask[k] = fh_sigmoid_t<T::is32>(o[k][2]);
       // grid_sample, align_corners=False: pixel = ((coord + 1) * size - 1) / 2
       const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;
       const float fx0 = floorf(ix), fy0 = floorf(iy);
@@ -387,13 +431,16 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+          // zero padding of grid_sample: the tap is read from the clamped position and weighted 0 when it lies outside
           const int yy = y0 + a, xx = x0 + b;
           const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
-          fu[k][a * 2 + b] = in ? T::load8(featp + ((size_t)yy * R + xx) * C + c0) : T::zero8();
+          const int yc = min(max(yy, 0), R - 1), xc = min(max(xx, 0), R - 1);
+          fu[k][a * 2 + b] = T::load8(featp + (unsigned)((yc * R + xc) * C + c0));
+          inw[k][a * 2 + b] = in ? 1.f : 0.f;
         }
     }
     float upr[3] = {0.f, 0.f, 0.f};
-    if (g.prgb && owner) up2_tap3(g.prgb, f, Rp, Y, X0 + sub, upr);
+    if (ff.prgb && owner) up2_tap3(ff.prgb, 0, Rp, Y, X0 + sub, upr);
     float rgb[PIX][3];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
@@ -404,7 +451,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]) * mask[k];
+          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]) * mask[k] * inw[k][a * 2 + b];
 #pragma unroll
           for (int i = 0; i < 8; ++i) fw[i] += wgt * T::get(fu[k][a * 2 + b], i);
         }
@@ -414,7 +461,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
         const float4 w1 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0 + 4);
         rgb[k][j] = w0.x * fw[0] + w0.y * fw[1] + w0.z * fw[2] + w0.w * fw[3] + w1.x * fw[4] + w1.y * fw[5] + w1.z * fw[6] + w1.w * fw[7];
       }
-      if (g.xnext) {
+      if (ff.xnext) {
         const float4 n0 = *reinterpret_cast<const float4*>(sw + 6 * C + c0);
         const float4 n1 = *reinterpret_cast<const float4*>(sw + 6 * C + c0 + 4);
         const float sn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
@@ -422,7 +469,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
         float ov[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ov[i] = (fw[i] + T::get(xu[k], i) * om) * sn[i];
-        T::store8(xnextp + (po0 + k) * C + c0, dec_pack8<T>(ov, sm));
+        T::store8(ff.xnext + (unsigned)((p0 + k) * C + c0), dec_pack8<T>(ov, sm));
       }
     }
     for (int d = 1; d < lpp; d <<= 1) {
@@ -448,18 +495,20 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const float* 
         }
       const float v0 = fh_lrelu_s2(r0 + b10) + b20 + upr[0], v1 = fh_lrelu_s2(r1 + b11) + b21 + upr[1],
                   v2 = fh_lrelu_s2(r2 + b12) + b22 + upr[2];
-      const size_t po = po0 + sub;
+      const unsigned po = (unsigned)(p0 + sub);
       if (g.write_pyr) {  // the pyramids are only read by the next level
-        *reinterpret_cast<float4*>(g.flow_out + po * 4) = float4{f0, f1, f2, 0.f};
-        *reinterpret_cast<float4*>(g.rgb_out + po * 4) = float4{v0, v1, v2, 0.f};
+        *reinterpret_cast<float4*>(ff.flow_out + po * 4u) = float4{f0, f1, f2, 0.f};
+        *reinterpret_cast<float4*>(ff.rgb_out + po * 4u) = float4{v0, v1, v2, 0.f};
       }
       if (g.final_mode == 1) {
-        float* fo = g.final_out + po * 3;
-        fo[0] = fminf(fmaxf(v0, -1.f), 1.f) * 0.5f + 0.5f;
-        fo[1] = fminf(fmaxf(v1, -1.f), 1.f) * 0.5f + 0.5f;
-        fo[2] = fminf(fmaxf(v2, -1.f), 1.f) * 0.5f + 0.5f;
+        // one 12-byte store per pixel (global_store_dwordx3): consecutive lanes own consecutive pixels, a wave writes 768
+        // contiguous bytes with one instruction instead of three strided ones
+        typedef float f3v __attribute__((ext_vector_type(3)));
+        f3v o3 = {fminf(fmaxf(v0, -1.f), 1.f) * 0.5f + 0.5f, fminf(fmaxf(v1, -1.f), 1.f) * 0.5f + 0.5f,
+                  fminf(fmaxf(v2, -1.f), 1.f) * 0.5f + 0.5f};
+        __builtin_memcpy(ff.final_hwc + po * 3u, &o3, 12);
       } else if (g.final_mode == 2) {
-        float* fo = g.final_out + (size_t)f * 3 * npix + p0 + sub;
+        float* fo = ff.final_chw + po;
         fo[0] = v0;
         fo[npix] = v1;
         fo[2 * (size_t)npix] = v2;
@@ -1312,12 +1361,13 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   const int npix = g.R * g.R;
   const int pend = min(npix, (band + 1) * g.band_pix);
   unsigned sm = 0u;
+  const FlowFrame<T> ff = dec_flow_frame<T>(g, f);
+  const typename T::elem* const xf = reinterpret_cast<const typename T::elem*>(g.x) + (size_t)f * npix * C;
   for (int p0 = band * g.band_pix + grp * PIX; p0 < pend; p0 += gpb * PIX) {
-    const size_t po0 = (size_t)f * npix + p0;
     typename T::pack8 xu[PIX];
 #pragma unroll
-    for (int k = 0; k < PIX; ++k) xu[k] = T::load8_nt(reinterpret_cast<const typename T::elem*>(g.x) + (po0 + k) * C + c0);  // read once: leave L2 to the features
-    dec_flow_pixels<T, PIX>(g, sw, f, p0, sub, lpp, xu, sm);
+    for (int k = 0; k < PIX; ++k) xu[k] = T::load8_nt(xf + (unsigned)((p0 + k) * C + c0));  // read once: leave L2 to the features
+    dec_flow_pixels<T, PIX>(g, ff, sw, p0, sub, lpp, xu, sm);
   }
   dec_sat_flush<T>(g.sat, sm);
   DEC_STAMP_MAX(3);
