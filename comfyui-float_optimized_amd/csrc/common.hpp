@@ -110,6 +110,7 @@ __device__ __forceinline__ void fh_store_f4_wt(float* p, const float4& v) {
 
 struct BF16 {
   typedef bf16x8_t vec8;
+  static constexpr bool is_fp16 = false;
   static __device__ __forceinline__ u16 from_float(float x) {
     __bf16 b = (__bf16)x;  // RNE; hipcc emits v_cvt_pk_bf16_f32 on gfx950 (keeps NaN a NaN)
     return __builtin_bit_cast(u16, b);
@@ -132,6 +133,7 @@ struct BF16 {
 
 struct FP16 {
   typedef f16x8_t vec8;
+  static constexpr bool is_fp16 = true;  // the range-tracked 16-bit stores of the decoder kernels (dec_store4) apply
   static __device__ __forceinline__ u16 from_float(float x) {
     // saturate instead of overflowing to inf: activations beyond 65504 would poison a frame
     x = fminf(fmaxf(x, -65504.f), 65504.f);
@@ -182,6 +184,7 @@ struct F32x8 {
 };
 struct FP32 {
   typedef float elem;
+  static constexpr bool is_fp16 = false;
   typedef F32x8 pack8;
   static constexpr bool is32 = true;
   static constexpr int EB = 4;

@@ -340,7 +340,8 @@ int create_impl(float_dec* h, const TensorTable& tt) {
 // Copy workgroups per carrying launch (a multiple of 8), the lowest resolution whose launches carry a share, and the pause
 // between a wave's 1-KiB stores in units of 512 clocks.  Unpaced, the copy saturates PCIe (55 GB/s) and its posted writes
 // queue in front of the compute workgroups' memory traffic: the 512-px flow launch took 665 us instead of 508 with a 217 us
-// copy inside; at ~45 GB/s (16 workgroups, pace 4) it takes 548 (in-kernel stamps, -DDEC_STAMPS).
+// copy inside; at ~45 GB/s (16 workgroups, pace 4) it takes 548 (in-kernel stamps, -DDEC_STAMPS).  Round 3: the launches got
+// shorter (flow kernel -35 %), pace 3 (~52 GB/s) leaves less of the last share exposed: 27.66 vs 28.03 ms per 250 frames.
 static int env_int(const char* name, int dflt, int lo, int hi) {  // tuning knobs: anything outside [lo, hi] falls back to the default
   const char* v = getenv(name);
   if (!v || !*v) return dflt;
@@ -350,7 +351,7 @@ static int env_int(const char* name, int dflt, int lo, int hi) {  // tuning knob
 }
 static const unsigned kRideWgs = (unsigned)env_int("FLOAT_DEC_RIDE_WGS", 16, 0, 64) / 8 * 8;
 static const int kRideMinRes = env_int("FLOAT_DEC_RIDE_MIN_RES", 64, 64, 512);
-static const unsigned kRidePace = (unsigned)env_int("FLOAT_DEC_RIDE_PACE", 4, 0, 64);
+static const unsigned kRidePace = (unsigned)env_int("FLOAT_DEC_RIDE_PACE", 3, 0, 64);
 
 // Relative duration of a carrying launch (kind 0 = up-conv + blur, 1 = conv2, 2 = flow / warp / ToRGB) at resolution R: the
 // share of the pending copy it takes is proportional to it, so that every share ends inside its launch (measured per 32-frame
@@ -358,7 +359,7 @@ static const unsigned kRidePace = (unsigned)env_int("FLOAT_DEC_RIDE_PACE", 4, 0,
 static double ride_weight(int R, int kind) {
   static const bool equal = getenv("FLOAT_DEC_RIDE_EQUAL") != nullptr;
   if (equal) return 1.0;
-  static const double w[4][3] = {{211, 210, 99}, {184, 224, 99}, {268, 295, 354}, {393, 328, 508}};
+  static const double w[4][3] = {{191, 210, 89}, {178, 224, 89}, {242, 295, 235}, {341, 328, 325}};  // re-measured in round 3 (flow kernel -35 %)
   const int li = R == 64 ? 0 : R == 128 ? 1 : R == 256 ? 2 : R == 512 ? 3 : -1;
   return li < 0 ? 250.0 : w[li][kind];
 }

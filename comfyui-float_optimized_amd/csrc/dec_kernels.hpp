@@ -26,7 +26,7 @@ typedef unsigned short dec_us2 __attribute__((ext_vector_type(2)));
 typedef _Float16 dec_h2 __attribute__((ext_vector_type(2)));
 template <class T>
 __device__ __forceinline__ unsigned dec_cvt2(float a, float b, unsigned& m) {  // two floats -> packed fp16, range-tracked
-  static_assert(!T::is32, "16-bit path");
+  static_assert(T::is_fp16, "fp16 path");
   const unsigned u = __builtin_bit_cast(unsigned, dec_h2{(_Float16)a, (_Float16)b});
 #ifndef DEC_NO_SAT  // A/B build only (make EXTRA=-DDEC_NO_SAT): what the tracking costs
   m = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(dec_us2, m), __builtin_bit_cast(dec_us2, u & 0x7fff7fffu)));
@@ -35,17 +35,16 @@ __device__ __forceinline__ unsigned dec_cvt2(float a, float b, unsigned& m) {  /
 }
 template <class T>
 __device__ __forceinline__ void dec_sat_flush(unsigned long long* ctr, unsigned& m) {
-  if constexpr (!T::is32) {
+  if constexpr (T::is_fp16) {
     if ((m & 0xffffu) >= 0x7c00u || (m >> 16) >= 0x7c00u) atomicAdd(ctr, 1ull);
     m = 0u;
   }
 }
 template <class T>
 __device__ __forceinline__ void dec_store4(typename T::elem* p, float a, float b, float c, float d, unsigned& m) {
-  if constexpr (T::is32) {
+  if constexpr (!T::is_fp16) {  // fp32 (verification mode), bf16 (the encoder borrows dec_conv16_kernel): plain stores
     T::store4(p, a, b, c, d);
   } else {
-    static_assert(sizeof(typename T::elem) == 2 && !T::is32);
     uint2 o;
     o.x = dec_cvt2<T>(a, b, m);
     o.y = dec_cvt2<T>(c, d, m);
@@ -54,7 +53,7 @@ __device__ __forceinline__ void dec_store4(typename T::elem* p, float a, float b
 }
 template <class T>
 __device__ __forceinline__ typename T::pack8 dec_pack8(const float (&v)[8], unsigned& m) {
-  if constexpr (T::is32) {
+  if constexpr (!T::is_fp16) {
     typename T::pack8 o;
 #pragma unroll
     for (int i = 0; i < 8; ++i) T::set(o, i, v[i]);
@@ -131,7 +130,7 @@ struct DemodArgs {
   int normalise;      // 0: a = 1 (A/B switch, FLOAT_DEC_STYLE_NORM=0)
   unsigned long long* sat;  // counters base (site 34: non-finite styles) or nullptr
 };
-__global__ __launch_bounds__(256) void dec_style_norm_kernel(DemodArgs g) {  // grid (layers, frames)
+static __global__ __launch_bounds__(256) void dec_style_norm_kernel(DemodArgs g) {  // grid (layers, frames)
   const DemodLayer L = g.L[blockIdx.x];
   const int f = blockIdx.y;
   float* s = g.styles + (size_t)f * g.ld_s + L.style_off;
@@ -1417,7 +1416,7 @@ __global__ void dec_dbg_unpack_kernel(float* __restrict__ out, const typename T:
   out[((size_t)f * C + c) * HW + p] = T::to_float(in[idx]);
 }
 // dir 0: (F,3,HW) -> [F][HW][4];  dir 1: back
-__global__ void dec_dbg_pyr_kernel(float* __restrict__ out, const float* __restrict__ in, int F, int HW, int dir) {
+static __global__ void dec_dbg_pyr_kernel(float* __restrict__ out, const float* __restrict__ in, int F, int HW, int dir) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)F * HW) return;
   const int p = (int)(idx % HW), f = (int)(idx / HW);

@@ -3,6 +3,7 @@
 // called from FLOAT.py:283-291 once per clip).
 #include <math.h>
 
+#include "dec_kernels.hpp"  // dec_conv16_kernel: the LDS-staged 3x3 conv of the decoder, used for the ResBlocks' conv1
 #include "enc_kernels.hpp"
 
 namespace {
@@ -41,6 +42,7 @@ struct float_enc {
   std::vector<int> resR, resC;
   void *t1 = nullptr, *tb = nullptr, *tsk = nullptr;
   float *s_r = nullptr, *fcA = nullptr, *fcB = nullptr;
+  unsigned long long* sat = nullptr;  // range counter of the 16-bit conv1 outputs (dec_kernels.hpp; float_enc_saturation)
 };
 
 namespace {
@@ -210,6 +212,10 @@ int create_impl(float_enc* h, const TensorTable& tt) {
   if ((rc = alloc_e(&h->t1, max_t1))) return rc;
   if ((rc = alloc_e(&h->tb, max_tb))) return rc;
   if ((rc = alloc_e(&h->tsk, max_sk))) return rc;
+  if ((rc = h->pool.alloc(&h->sat, 1, true))) return rc;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, 2, 3, 3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            32 * 1024 * T::EB);
+  (void)hipGetLastError();
   if ((rc = h->pool.alloc(&h->s_r, (size_t)c.dim, true))) return rc;
   if ((rc = h->pool.alloc(&h->fcA, (size_t)std::max(c.dim, 64), true))) return rc;
   if ((rc = h->pool.alloc(&h->fcB, (size_t)std::max(c.dim, 64), true))) return rc;
@@ -244,6 +250,48 @@ int launch_conv(const EConv& L, const void* X, int Hi, int Wi, int stride, int p
   return FLOAT_OK;
 }
 
+// conv1 of a ResBlock - EqualConv2d(C, C, 3, padding 1) + FusedLeakyReLU on R x R (encoder.py:184-186), 34 of the encoder's
+// 39 GFLOP - on the decoder's 16 x 16-tile kernel (halo tile and weight slab staged in swizzled LDS, 32 output channels per
+// workgroup) from 16 px up: the direct-from-global kernel below ran the encoder at 39 TFLOP/s.  Same weight layout
+// ([tap][Cout][Cin], taps row-major), no demodulation, no next-layer style.
+template <class T>
+int launch_conv3x3_tiles(float_enc* h, const EConv& L, const void* X, int R, void* Y, hipStream_t st) {
+  static const int kDy[9] = {-1, -1, -1, 0, 0, 0, 1, 1, 1}, kDx[9] = {-1, 0, 1, -1, 0, 1, -1, 0, 1};
+  constexpr size_t RB = 32 * T::EB;
+  ConvArgs g;
+  memset(&g, 0, sizeof(g));
+  g.X = X;
+  g.Wt = L.W;
+  g.Y = Y;
+  g.bias = L.bias;
+  g.act = 1;
+  g.sat = h->sat;
+  g.F = 1;
+  g.Hi = g.Wi = g.Ho = g.Wo = g.OH = g.OW = R;
+  g.Cin = L.cin;
+  g.Cout = L.cout;
+  g.sy = g.sx = 1;
+  g.ntaps = 9;
+  for (int t = 0; t < 9; ++t) {
+    g.dy[t] = (signed char)kDy[t];
+    g.dx[t] = (signed char)kDx[t];
+  }
+  g.dymin = g.dxmin = -1;
+  g.tiles_x = g.tiles_y = (R + 15) / 16;
+  g.tpw = 1;
+  const unsigned ngroups = (unsigned)(g.tiles_x * g.tiles_y), ncb = (unsigned)(L.cout / 32);
+  dim3 grid(ngroups, ncb);
+  if (ncb > 1) {  // the channel blocks of a tile side by side on one XCD (dec_group_cb)
+    g.ngroups = ngroups;
+    g.ncb = ncb;
+    grid = dim3(ngroups * ncb, 1);
+  }
+  const size_t smem = (size_t)18 * 18 * RB + (size_t)9 * 32 * RB;
+  hipLaunchKernelGGL((dec_conv16_kernel<T, 2, 3, 3>), grid, dim3(256), smem, st, g);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
 template <class T>
 int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* r_s, float* const* feats, int n_feats,
                  hipStream_t st) {
@@ -273,7 +321,10 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
     }
     if ((rc = launch_conv<T>(B.skip, h->tb, R - 1, R - 1, 2, 0, h->tsk, nullptr, nullptr, st))) return rc;
     // conv1 3x3 + act; conv2: Blur pad (2,2) -> 3x3 stride 2 + act; (out + skip) / sqrt(2)
-    if ((rc = launch_conv<T>(B.conv1, x, R, R, 1, 1, h->t1, nullptr, nullptr, st))) return rc;
+    static const bool tiles_on = !getenv("FLOAT_ENC_NO_TILES");
+    if (tiles_on && R >= 16 && B.conv1.cin % 32 == 0 && B.conv1.cout % 32 == 0) rc = launch_conv3x3_tiles<T>(h, B.conv1, x, R, h->t1, st);
+    else rc = launch_conv<T>(B.conv1, x, R, R, 1, 1, h->t1, nullptr, nullptr, st);
+    if (rc) return rc;
     {
       const size_t tot = (size_t)(R + 1) * (R + 1) * (C / 8);
       hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const E*>(h->t1),
