@@ -9,7 +9,6 @@ from ... import host_models, weights
 from ...audio import Audio2EmotionHIP, AudioEncoderHIP
 from ...config import AudioConfig, FmtConfig, emotion_audio_config, small_audio_config, small_emotion_config
 from ...encoder import EncoderHIP
-from ...fmt import draw_noise
 from ...pipeline import FloatHotPath
 from . import SYNTHETIC_MODEL, main_logger
 
@@ -94,24 +93,47 @@ class InferenceAgent:
                     emotion_encoder=(weights.synth_audio_state(small_emotion_config(), seed=seed), small_emotion_config()))
 
     # ------------------------------------------------------------------ inference
+    def _one_hot(self, emo):
+        """(1,1,7) one-hot of a label on the device, made once per label (a fresh one costs a blocking scalar upload per clip)."""
+        cache = self.__dict__.setdefault("_we_cache", {})
+        idx = host_models.emotion_index(emo)
+        if idx not in cache:
+            cache[idx] = host_models.emotion_one_hot(emo, "cpu").to(self.rank)
+        return cache[idx]
+
+    def _noise_to_device(self, n_chunks, seed):
+        """The reference's sequential CPU draws (fmt.draw_noise; FLOAT.py:203-215) written straight into a pinned buffer and sent
+        by a non-blocking copy: the host neither waits for the encoder kernels queued in front of the copy nor leaves the GPU
+        idle behind them.  The buffer is kept until the next clip (which starts after this one was synchronised)."""
+        c = self.cfg
+        shape = (n_chunks, 1, c.num_frames_for_clip, c.dim_w)
+        buf = self.__dict__.get("_noise_pin")
+        if buf is None or tuple(buf.shape) != shape:
+            buf = self._noise_pin = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        g = torch.Generator("cpu")
+        g.manual_seed(int(seed))
+        for k in range(n_chunks):
+            torch.randn(1, c.num_frames_for_clip, c.dim_w, generator=g, out=buf[k])
+        return buf.to(self.rank, non_blocking=True)
+
     @torch.no_grad()
     def conditions_device(self, s, a, emo=None):
         """Once-per-clip stage on HIP operators, inputs already in HBM: s (1,3,H,W) in [-1,1] -> (s_r, feats handed to the
         decoder, r_s); a (N,) the normalised 16 kHz waveform -> (wa, T); and for any `emo` that is not one of the seven labels
         (None, 'none', 'S2E', ...) the speech-emotion scores (FLOAT.py:196-198)."""
         o = self.opt
+        if host_models.emotion_index(emo) is None and self.emotion_predictor is None:
+            raise NotImplementedError(
+                "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198) but the checkpoint has "
+                "no `emotion_encoder.wav2vec2_for_emotion.` weights - pick an emotion or attach agent.emotion_predictor")
         s_r, _, _, r_s = self.enc.encode_image_into_latent(s, want_feats=False)  # FLOAT.py:283-291
         self.enc.hand_feats_to(self.G.dec)
         T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
         wa = self.audio_encoder.inference(a, seq_len=T)
         if host_models.emotion_index(emo) is None:
-            if self.emotion_predictor is None:
-                raise NotImplementedError(
-                    "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198) but the checkpoint has "
-                    "no `emotion_encoder.wav2vec2_for_emotion.` weights - pick an emotion or attach agent.emotion_predictor")
             we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
         else:
-            we = host_models.emotion_one_hot(emo, self.rank)
+            we = self._one_hot(emo)
         return dict(s_r=s_r, feats=None, r_s=r_s, wa=wa, we=we, T=T)  # feats: already in the decoder (NHWC 16-bit)
 
     def host_inputs(self, ref_img, ref_audio, no_crop=True):
@@ -135,9 +157,9 @@ class InferenceAgent:
         """Portrait and waveform in HBM -> (T,H,W,3) fp32 frames in [0,1] in pinned host memory: every operator of the path and
         the hand-over (frames of decode batch i leave inside the launches of batch i+1, float_dec_frames_host).  bench.py
         times exactly this call.  Like the reference, the grid size comes from opt.nfe (FLOAT.py:188)."""
-        c = self.conditions_device(s, a, emo)
+        c = self.conditions_device(s, a, emo)  # encoder kernels enqueued; nothing below waits for them on the host
         n_chunks = int(math.ceil(c["T"] / self.cfg.num_frames_for_clip))
-        noise = draw_noise(n_chunks, 1, self.cfg, seed if seed is not None else self.opt.seed)
+        noise = self._noise_to_device(n_chunks, seed if seed is not None else self.opt.seed)
         host = self.G.generate_to_host(c["r_s"], c["wa"], c["we"], c["s_r"], None, self.opt.nfe, a_cfg_scale, r_cfg_scale,
                                        e_cfg_scale, noise=noise, out=out)
         torch.cuda.current_stream(self.rank).synchronize()  # the frames are in host memory
