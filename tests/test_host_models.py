@@ -56,3 +56,19 @@ def test_emotion_labels_follow_label2id_get():
     assert hm.emotion_one_hot("sad").tolist() == [[[0, 0, 0, 0, 0, 1, 0]]]
     with pytest.raises(ValueError):
         hm.emotion_one_hot("S2E")
+
+
+def test_resampler_near_coprime_rate_is_bounded():
+    """a near-coprime source rate (44099 Hz: up 16000 x 44k taps = 5.6 GB of kernel) must not blow up; it snaps to
+    the nearest multiple of 50 Hz first and stays a clean resampler."""
+    import math
+    import time
+    import torch
+    H = pkg.host_models
+    t = torch.arange(44099) / 44099.0
+    w = torch.sin(2 * math.pi * 440 * t)
+    t0 = time.time()
+    y = H.resample_sinc(w, 44099, 16000)
+    assert time.time() - t0 < 5.0 and y.shape == (16000,)
+    ref = torch.sin(2 * math.pi * 440 * torch.arange(16000) / 16000.0)
+    assert float((y[200:-200] - ref[200:-200]).abs().max()) < 2e-3

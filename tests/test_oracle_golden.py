@@ -177,3 +177,51 @@ def test_speech_emotion(tag):
     scores = O.audio2emotion_predict(sd, cfg, W.synth_waveform(g["seconds"], seed=g["seed"] + 1))
     assert scores.shape == g["scores"].shape and max_abs(scores, g["scores"]) < 1e-5
     assert abs(float(scores.sum()) - 1.0) < 1e-5
+
+
+def test_dec_units_kernel_shapes():
+    """The unit-op fixture the HIP kernels are held to (dec_units_hip.npz: StyledConv / ToFlow / ToRGB of the reference at
+    kernel shapes) must also be what the oracle computes from the regenerated inputs - the fixture carries outputs only."""
+    from tests.util import seeded_normal as rnd
+    g = golden("dec_units_hip")
+    seed = g["seed"]
+    style = rnd(seed + 1, 2, 512)
+    names = ["plain8", "plain32", "up4", "up8", "up32"]
+    for i, (name, (cin, cout, R, up)) in enumerate(zip(names, g["sc_cases"].tolist())):
+        k = seed + 100 * (i + 1)
+        sd = {"c.conv.weight": rnd(k + 2, 1, cout, cin, 3, 3), "c.conv.modulation.weight": rnd(k + 3, cin, 512),
+              "c.conv.modulation.bias": 1 + rnd(k + 4, cin, std=0.1), "c.activate.bias": rnd(k + 5, 1, cout, 1, 1, std=0.1)}
+        out = O.styled_conv(rnd(k + 6, 2, cin, R, R), style, sd, "c", bool(up))
+        assert rel_l2(out, g["sc_%s_out" % name]) < 2e-6, name
+    for j, (name, (Cc, R, prev)) in enumerate(zip(["c32", "c128"], g["fl_cases"].tolist())):
+        k = seed + 1000 * (j + 1)
+        fsd = {"f.bias": rnd(k + 6, 1, 3, 1, 1, std=0.1), "f.conv.weight": rnd(k + 7, 1, 3, Cc, 1, 1, std=0.3),
+               "f.conv.modulation.weight": rnd(k + 8, Cc, 512), "f.conv.modulation.bias": 1 + rnd(k + 9, Cc, std=0.1)}
+        rsd = {"r.bias": rnd(k + 13, 1, 3, 1, 1, std=0.1), "r.conv.0.weight": rnd(k + 14, 3, Cc, 1, 1),
+               "r.conv.1.bias": rnd(k + 15, 1, 3, 1, 1, std=0.1)}
+        x, feat = rnd(k + 10, 2, Cc, R, R), rnd(k + 11, 1, Cc, R, R)
+        pflow = rnd(k + 12, 2, 3, R // 2, R // 2, std=0.5) if prev else None
+        prgb = rnd(k + 16, 2, 3, R // 2, R // 2) if prev else None
+        fw, bl, o3, _ = O.to_flow(x, style, feat.repeat(2, 1, 1, 1), fsd, "f", pflow)
+        rgb = O.to_rgb(fw, rsd, "r", prgb)
+        assert max_abs(o3, g["fl_%s_out" % name]) < 1e-5 and max_abs(bl, g["fl_%s_blend" % name]) < 1e-5
+        assert max_abs(rgb, g["fl_%s_rgb" % name]) < 1e-5
+
+
+@pytest.mark.parametrize("kind", ["warp", "range"])
+def test_dec_stress_64(kind):
+    """Stress fixtures of the reference Synthesis (full-range warp on white-noise features; styles of +-300 on activations of
+    1e2..1e4) against the oracle: bit-identical op order, so the tolerance is the fp32 one."""
+    g = golden("dec_stress_%s_64" % kind)
+    sd, feats = W.stress_decoder(64, seed=g["seed"], kind=kind)
+    raw = torch.cat([O.synthesis(sd, g["s_r"] + g["r_d"][:, t], feats) for t in range(g["r_d"].shape[1])])
+    assert rel_l2(raw, g["raw"]) < TOL_REL
+    assert g["ref_vs_f64_rel"] < (1e-3 if kind == "warp" else 1e-5)  # the recorded sensitivity the GPU limits scale with
+
+
+def test_dec_channel_multiplier_2():
+    g = golden("dec_cm2_128")
+    sd = W.synth_decoder_state(128, seed=g["seed"], channel_multiplier=2)
+    feats = W.synth_feats(128, seed=g["seed"], channel_multiplier=2)
+    raw = torch.cat([O.synthesis(sd, g["s_r"] + g["r_d"][:, t], feats) for t in range(2)])
+    assert rel_l2(raw, g["raw"]) < TOL_REL
