@@ -449,10 +449,11 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
   const int fblocks = (F + nf - 1) / nf;
   const int npix = nf * g.hh * g.hw;
   FH_REQUIRE(npix * 4 <= 9 * 256, "conv halo tile too large (%d pixels)", npix);
-  // Output channels per workgroup.  32 (NT = 2) everywhere: twice the workgroups and 39 KB instead of 58 KB of LDS each beat the
-  // 64-channel tiles' better operand reuse (decode 35.2 -> 33.9 ms); FLOAT_DEC_CONV_BN=64 / FLOAT_DEC_CONV_BN_LO=64 restore them
-  // for the 16x16-tile kernel / the generic low-resolution kernel.
-  static const int bn_hi = env_int("FLOAT_DEC_CONV_BN", 32, 32, 64);
+  // Output channels per workgroup: 64 (NT = 4) in the 16x16-tile kernel where the layer has them - each A fragment feeds twice
+  // the MFMAs (22.75 vs 23.10 ms per 250 frames since the kernel's address arithmetic went; before that the 32-channel tiles'
+  // doubled workgroup count won, 33.9 vs 35.2) - and 32 in the generic low-resolution kernel; FLOAT_DEC_CONV_BN /
+  // FLOAT_DEC_CONV_BN_LO = 32 | 64 are the A/B switches.
+  static const int bn_hi = env_int("FLOAT_DEC_CONV_BN", 64, 32, 64);
   static const int bn_lo = env_int("FLOAT_DEC_CONV_BN_LO", 32, 32, 64);
   const bool tile16 = tdim == 16;
   const int bn = (s.cout >= 64 && (tile16 ? bn_hi : bn_lo) == 64) ? 64 : 32;
@@ -460,7 +461,7 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
   const int ty_taps = dymax - dymin + 1, tx_taps = dxmax - dxmin + 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool prof = fh_prof_pair(1, &e0, &e1);
-  if (tdim == 16 && ty_taps * tx_taps == ntaps) {
+  if (tdim == 16 && ty_taps * tx_taps == ntaps && Ho % 16 == 0 && Wo % 16 == 0 && Ho == Hi && Wo == Wi) {
     // dense TY x TX window on 16x16 tiles: compile-time geometry, swizzled LDS, register prefetch
     const int total = g.tiles_x * g.tiles_y * F;
     static const int tpw_env = env_int("FLOAT_DEC_TPW", 0, 0, 4096);  // tuning aid

@@ -692,117 +692,150 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv_kernel(ConvArgs
   dec_sat_flush<T>(g.sat, sm);
 }
 
-// Specialisation of the conv for 16x16-pixel tiles of one frame and a dense TY x TX tap window (3x3
-// plain convs; 2x2 / 2x1 / 1x2 / 1x1 parity classes of the transposed conv) - every layer from 16x16
-// upward.  What the counters asked for (r01 PMC: 12.6 VALU instructions per MFMA, 42 % of LDS cycles
-// bank conflicts, waves parked 69 % of their life):
-//   * geometry is compile-time: halo decode, tap shifts and unrolling cost no run-time index math, and
-//     every lane keeps its TY*TX swizzled LDS read offsets in registers;
-//   * LDS rows are 64 B (32 channels) and the 16-byte chunk index is XOR-ed with (row>>1)&3, which makes
-//     the ds_read_b128 fragment reads conflict-free for any tile alignment (brute-forced over the gfx950
-//     lane groups, tools/probes/lds_swizzle.py);
-//   * a workgroup walks `tpw` consecutive tiles and all K chunks as one item stream, and the global
-//     loads of item i+1 are issued into registers before the MFMAs of item i (single LDS buffer).
+// Specialisation of the conv for 16x16-pixel tiles of one frame and a dense TY x TX tap window (the 3x3 convs of every level
+// from 16x16 upward; image sizes are multiples of 16 here).  What the counters and the listing asked for:
+//   * r01 PMC: 42 % of LDS cycles bank conflicts -> LDS rows are 64 B (32 channels) and the 16-byte chunk index is XOR-ed with
+//     (halo column >> 1) & 3, conflict-free for the ds_read_b128 fragment reads at any tile alignment (brute-forced over the
+//     gfx950 lane groups, tools/probes/lds_swizzle.py);
+//   * a wave's 4 m-tiles are image rows w*4 .. w*4+3 of the tile (x = r16), so tap (ty, tx) of m-tile mt reads halo row
+//     w*4 + mt + ty at column shift tx: only (3 + TY) * TX distinct A fragments per chunk (3x3: 18 ds_read_b128, not 36);
+//   * a workgroup walks `tpw` consecutive tiles and all K chunks as one item stream, and the global loads of item i+1 are
+//     issued into registers before the MFMAs of item i (single LDS buffer);
+//   * r03 listing: 700-800 vector instructions per item against 72 MFMAs (staging addresses with a division and 64-bit
+//     multiplies per 16-byte load, swizzled LDS addresses re-derived per item, 30 instructions per epilogue fragment): the
+//     wave spent two to three times the MFMA time issuing them.  Now every per-lane address is formed ONCE per workgroup - a
+//     32-bit byte offset from a per-item scalar base for the loads, a register + immediate for the LDS accesses (the swizzle
+//     depends on the halo column only, so fragment rows differ by a constant), one offset for the stores - tiles are decoded
+//     by carrying (f, ty, tx) along instead of dividing, interior tiles load without any bounds logic, border tiles take one
+//     4-bit mask per chunk (top / bottom / left / right halo membership, formed once) against the tile's border bits.
 template <class T, int NT, int TY, int TX>
 __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
   typedef typename T::elem E;
   typedef typename T::pack8 P8;
-  constexpr int RB = 32 * T::EB, CB = 8 * T::EB;
-  const E* const X = reinterpret_cast<const E*>(g.X);
-  const E* const Wt = reinterpret_cast<const E*>(g.Wt);
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int EB = T::EB, RB = 32 * EB, CB = 8 * EB;
   constexpr int BN = NT * 16, HH = 15 + TY, HW = 15 + TX, NPIX = HH * HW, NTAPS = TY * TX;
-  constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
+  constexpr int NA = (NPIX * 4 + 255) / 256, NBROWS = NTAPS * BN, NB = (NBROWS * 4 + 255) / 256;
+  static_assert(64 % BN == 0, "weight rows of one staging round are whole taps apart");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;              // [NPIX][RB], pack-swizzled
-  unsigned char* sB = smem + NPIX * RB;  // [NTAPS][BN][RB], pack-swizzled
+  unsigned char* const sA = smem;              // [NPIX][RB], chunk ^ ((halo column >> 1) & 3)
+  unsigned char* const sB = smem + NPIX * RB;  // [NTAPS][BN][RB], chunk ^ ((row >> 1) & 3)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r16 = lane & 15, q = lane >> 4;
+  const int Wi = g.Wi, Cin = g.Cin;
 
-  // A wave's 4 m-tiles are image rows w*4 .. w*4+3 of the tile (x = r16), so tap (ty, tx) of m-tile mt reads halo row
-  // w*4 + mt + ty at column shift tx: only (3 + TY) * TX distinct fragments, each feeding every (mt, ty) with mt + ty = its
-  // row (3x3: 18 ds_read_b128 per chunk instead of 36; the kernel was LDS-read bound: 54 reads per 72 MFMAs).
-  // Per-lane swizzled LDS byte offsets of those fragments, two 16-bit offsets per register.
-  constexpr int HR = 3 + TY, NFR = HR * TX, NTP = (NFR + 1) / 2;
-  static_assert(NPIX * RB <= 65536, "packed 16-bit LDS offsets");
-  unsigned aaddr[NTP];
+  // ---- per-lane constants of the staging pass.  Chunk e = tid + 256 i of the halo tile: pixel p = e >> 2, pack ch = e & 3;
+  // lanes past the last pixel repeat the last pixel's chunk (same bytes to the same place: no mask anywhere).
+  unsigned a_off[NA];  // byte offset of the chunk from the halo origin of the tile in X
+  unsigned a_lds[NA];  // its LDS byte offset
+  unsigned a_edge = 0u;  // 4 bits per chunk: halo row above / below, halo column left / right of the 16x16 tile
+  const int ch = tid & 3;
 #pragma unroll
-  for (int tp = 0; tp < NTP; ++tp) {
-    unsigned packed = 0;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int idx = tp * 2 + h;
-      if (idx < NFR) {
-        const int P = (w * 4 + idx / TX) * HW + r16 + idx % TX;
-        packed |= (unsigned)(P * RB + (q ^ ((P >> 1) & 3)) * CB) << (16 * h);
-      }
-    }
-    aaddr[tp] = packed;
+  for (int i = 0; i < NA; ++i) {
+    const int p = min((tid >> 2) + 64 * i, NPIX - 1);
+    const int hy = p / HW, hx = p - hy * HW;
+    a_off[i] = (unsigned)(((hy * Wi + hx) * Cin + ch * 8) * EB);
+    a_lds[i] = (unsigned)(p * RB + (ch ^ ((hx >> 1) & 3)) * CB);
+    const unsigned m = (hy < -g.dymin ? 1u : 0u) | (hy >= 16 - g.dymin ? 2u : 0u) | (hx < -g.dxmin ? 4u : 0u) | (hx >= 16 - g.dxmin ? 8u : 0u);
+    a_edge |= m << (4 * i);
   }
-  const int baddr = r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB;  // rows t*BN + j*16 + r16: same swizzle term
+  const unsigned a_safe = (unsigned)(((-g.dymin * Wi - g.dxmin) * Cin + ch * 8) * EB);  // pixel (0, 0) of the tile: always inside
+  // weight rows: row = (tid >> 2) + 64 i = tap * BN + n; 64 / BN taps per round, the last round repeats the last row
+  const int brow = tid >> 2;
+  const unsigned b_off = (unsigned)((((brow / BN) * g.Cout + brow % BN) * Cin + ch * 8) * EB);
+  const int brow_l = min(brow + 64 * (NB - 1), NBROWS - 1);
+  const unsigned b_off_l = (unsigned)((((brow_l / BN) * g.Cout + brow_l % BN) * Cin + ch * 8) * EB);
+  const unsigned b_lds = (unsigned)(brow * RB + (ch ^ ((brow >> 1) & 3)) * CB);
+  const unsigned b_lds_l = (unsigned)(brow_l * RB + (ch ^ ((brow_l >> 1) & 3)) * CB);
+  const size_t b_round = (size_t)(64 / BN) * g.Cout * Cin * EB;  // bytes between staging rounds
+
+  // ---- per-lane constants of the MFMA pass: A fragment (hr, tx) = halo row w*4 + hr, columns r16 + tx; B fragment rows t*BN + j*16 + r16
+  unsigned fa[TX];
+#pragma unroll
+  for (int tx = 0; tx < TX; ++tx) fa[tx] = (unsigned)(((w * 4) * HW + r16 + tx) * RB + (q ^ (((r16 + tx) >> 1) & 3)) * CB);
+  const unsigned fb = (unsigned)(r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB);
+  // ---- epilogue: output pixel (ty*16 + w*4 + mt, tx*16 + r16), channels n0 + j*16 + q*4 .. +3
+  const unsigned y_off = (unsigned)((((w * 4) * g.sy * g.OW + r16 * g.sx) * g.Cout + q * 4) * EB);
+  const size_t y_row = (size_t)g.sy * g.OW * g.Cout * EB;  // bytes between the wave's m-tiles
 
   const int tiles_pf = g.tiles_x * g.tiles_y;
   const int total = tiles_pf * g.F;
-  const int nchunks = g.Cin >> 5;
+  const int nchunks = Cin >> 5;
   unsigned grp = bid, cb = blockIdx.y;
   if (g.ncb) dec_group_cb(bid, g.ngroups, g.ncb, grp, cb);
   const int tile0 = grp * g.tpw;
   const int ntile = min(g.tpw, total - tile0);
   const int nitems = ntile * nchunks;
   const int n0 = cb * BN;
+  const unsigned char* const Wn = reinterpret_cast<const unsigned char*>(g.Wt) + (size_t)n0 * Cin * EB;
+
+  // the tile being staged (runs one item ahead of the tile being computed) and the tile being computed: (frame, ty, tx)
+  int sf, sty, stx, schunk = 0;
+  {
+    sf = tile0 / tiles_pf;
+    const int rem = tile0 - sf * tiles_pf;
+    sty = rem / g.tiles_x;
+    stx = rem - sty * g.tiles_x;
+  }
+  int cf = sf, cty = sty, ctx = stx;
+  unsigned s_edge = 0u;  // border bits of the staged tile (uniform): top, bottom, left, right
+  unsigned s_hit = 0u;   // per chunk: 4-bit field != 0 <=> the chunk lies outside the image (zero padding)
 
   P8 ra[NA], rb[NB];
-  auto issue = [&](int item) {
-    const int tile = tile0 + item / nchunks, c0 = (item % nchunks) << 5;
-    const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
-    const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
-    const int iy0 = ty * 16 + g.dymin, ix0 = tx * 16 + g.dxmin;
+  auto issue = [&]() {
+    const unsigned edge = (sty == 0 ? 1u : 0u) | (sty == g.tiles_y - 1 ? 2u : 0u) | (stx == 0 ? 4u : 0u) | (stx == g.tiles_x - 1 ? 8u : 0u);
+    s_edge = edge;
+    const long long org = ((long long)(sf * g.Hi + sty * 16 + g.dymin) * Wi + stx * 16 + g.dxmin) * Cin + (schunk << 5);
+    const unsigned char* const Xo = reinterpret_cast<const unsigned char*>(g.X) + org * EB;
+    if (edge == 0u) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      ra[i] = T::zero8();
-      if (p < NPIX) {
-        const int hy = p / HW, hx = p - hy * HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
-          ra[i] = T::load8(X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
-      }
+      for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const P8*>(Xo + a_off[i]);
+    } else {
+      s_hit = a_edge & (edge * 0x11111111u);
+#pragma unroll
+      for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const P8*>(Xo + (((s_hit >> (4 * i)) & 15u) ? a_safe : a_off[i]));
     }
-    if (nchunks > 1 || item == 0) {
+    if (nchunks > 1 || schunk == 0) {
+      const unsigned char* const Wc = Wn + (size_t)(schunk << 5) * EB;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int e = tid + i * 256;
-        if (e < NBC) {
-          const int row = e >> 2, ch = e & 3;
-          const int tap = row / BN, n = row - tap * BN;
-          rb[i] = T::load8(Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
+      for (int i = 0; i < NB - 1; ++i) rb[i] = *reinterpret_cast<const P8*>(Wc + i * b_round + b_off);
+      rb[NB - 1] = *reinterpret_cast<const P8*>(Wc + b_off_l);
+    }
+    // advance the staging cursor
+    if (++schunk == nchunks) {
+      schunk = 0;
+      if (++stx == g.tiles_x) {
+        stx = 0;
+        if (++sty == g.tiles_y) {
+          sty = 0;
+          ++sf;
         }
       }
     }
   };
 
   f32x4 acc[4][NT];
-  issue(0);
+  int chunk = 0;
+  bool first = true;
+  issue();
   for (int item = 0; item < nitems; ++item) {
     __syncthreads();  // every wave is done reading the previous item's tiles
+    if (s_edge == 0u) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      if (p < NPIX) *reinterpret_cast<P8*>(sA + p * RB + (ch ^ ((p >> 1) & 3)) * CB) = ra[i];
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ra[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ((s_hit >> (4 * i)) & 15u) ? T::zero8() : ra[i];
     }
-    if (nchunks > 1 || item == 0) {
+    if (nchunks > 1 || first) {
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int e = tid + i * 256;
-        if (e < NBC) {
-          const int row = e >> 2, ch = e & 3;
-          *reinterpret_cast<P8*>(sB + row * RB + (ch ^ ((row >> 1) & 3)) * CB) = rb[i];
-        }
-      }
+      for (int i = 0; i < NB - 1; ++i) *reinterpret_cast<P8*>(sB + b_lds + i * 64 * RB) = rb[i];
+      *reinterpret_cast<P8*>(sB + b_lds_l) = rb[NB - 1];
+      first = false;
     }
     __syncthreads();
-    if (item + 1 < nitems) issue(item + 1);  // in flight while this item computes
-    const int chunk = item % nchunks;
+    if (item + 1 < nitems) issue();  // in flight while this item computes
     if (chunk == 0) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
@@ -815,11 +848,10 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
 #pragma unroll
       for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + baddr + ((ty * TX + tx) * BN + j * 16) * RB);
+        for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + fb + ((ty * TX + tx) * BN + j * 16) * RB);
 #pragma unroll
-      for (int hr = 0; hr < HR; ++hr) {
-        const int idx = hr * TX + tx;
-        const P8 a = *reinterpret_cast<const P8*>(sA + ((idx & 1) ? (aaddr[idx >> 1] >> 16) : (aaddr[idx >> 1] & 0xffffu)));
+      for (int hr = 0; hr < 3 + TY; ++hr) {
+        const P8 a = *reinterpret_cast<const P8*>(sA + fa[tx] + hr * HW * RB);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
           const int ty = hr - mt;
@@ -830,47 +862,55 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
         }
       }
     }
-    if (chunk == nchunks - 1) {
-      const int tile = tile0 + item / nchunks;
-      const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
-      const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
-      // per-(frame, channel) epilogue operands once per tile, not once per pixel row (the stores to Y may alias them as
-      // far as the compiler knows, so it re-loaded all three for each of the 4 x NT fragments): v = lrelu(acc*d + b) * (sqrt2*s)
-      float4 ed[NT], eb[NT], es[NT];
+    if (++chunk == nchunks) {
+      chunk = 0;
+      // v = lrelu(acc * d + b) * (sqrt2 * s): leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf) (one instruction; fmaxf
+      // costs a canonicalising v_max first), slope = 1 when the layer has no activation; the sqrt(2) rides in the style
+      v2f ed[NT][2], eb[NT][2], es[NT][2];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const int co = n0 + j * 16 + q * 4;
-        ed[j] = g.demod ? *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + co) : float4{1.f, 1.f, 1.f, 1.f};
-        eb[j] = g.act ? *reinterpret_cast<const float4*>(g.bias + co) : float4{0.f, 0.f, 0.f, 0.f};
-        es[j] = g.snext ? *reinterpret_cast<const float4*>(g.snext + (size_t)f * g.lds + co) : float4{1.f, 1.f, 1.f, 1.f};
+        const float4 d = g.demod ? *reinterpret_cast<const float4*>(g.demod + (size_t)cf * g.ldd + co) : float4{1.f, 1.f, 1.f, 1.f};
+        const float4 bb = g.act ? *reinterpret_cast<const float4*>(g.bias + co) : float4{0.f, 0.f, 0.f, 0.f};
+        float4 sn = g.snext ? *reinterpret_cast<const float4*>(g.snext + (size_t)cf * g.lds + co) : float4{1.f, 1.f, 1.f, 1.f};
         if (g.act) {
-          es[j].x *= 1.4142135623730951f;
-          es[j].y *= 1.4142135623730951f;
-          es[j].z *= 1.4142135623730951f;
-          es[j].w *= 1.4142135623730951f;
+          sn.x *= 1.4142135623730951f;
+          sn.y *= 1.4142135623730951f;
+          sn.z *= 1.4142135623730951f;
+          sn.w *= 1.4142135623730951f;
         }
+        ed[j][0] = v2f{d.x, d.y};
+        ed[j][1] = v2f{d.z, d.w};
+        eb[j][0] = v2f{bb.x, bb.y};
+        eb[j][1] = v2f{bb.z, bb.w};
+        es[j][0] = v2f{sn.x, sn.y};
+        es[j][1] = v2f{sn.z, sn.w};
       }
-      // leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf): one instruction (fmaxf costs a canonicalising v_max first),
-      // and slope = 1 when the layer has no activation, so the epilogue has no branch per fragment; the sqrt(2) rides in es
       const float slope = g.act ? 0.2f : 1.0f;
+      unsigned char* yt = reinterpret_cast<unsigned char*>(g.Y) +
+                          ((((size_t)cf * g.OH + (size_t)cty * 16 * g.sy + g.py) * g.OW + (size_t)ctx * 16 * g.sx + g.px) * g.Cout + n0) * EB;
       unsigned sm = 0u;
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) {
-        const int m = (w * 4 + mt) * 16 + r16;
-        const int oy = ty * 16 + (m >> 4), ox = tx * 16 + (m & 15);
-        if (oy >= g.Ho || ox >= g.Wo) continue;
-        E* yp = reinterpret_cast<E*>(g.Y) + ((size_t)(f * g.OH + oy * g.sy + g.py) * g.OW + ox * g.sx + g.px) * g.Cout;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const int co = n0 + j * 16 + q * 4;
-          float v[4] = {acc[mt][j][0] * ed[j].x + eb[j].x, acc[mt][j][1] * ed[j].y + eb[j].y, acc[mt][j][2] * ed[j].z + eb[j].z,
-                        acc[mt][j][3] * ed[j].w + eb[j].w};
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(v[r], slope * v[r], __builtin_inff());
-          dec_store4<T>(yp + co, v[0] * es[j].x, v[1] * es[j].y, v[2] * es[j].z, v[3] * es[j].w, sm);
+          v2f v0 = v2f{acc[mt][j][0], acc[mt][j][1]} * ed[j][0] + eb[j][0];
+          v2f v1 = v2f{acc[mt][j][2], acc[mt][j][3]} * ed[j][1] + eb[j][1];
+          const v2f l0 = slope * v0, l1 = slope * v1;
+          v0 = v2f{__builtin_amdgcn_fmed3f(v0.x, l0.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v0.y, l0.y, __builtin_inff())} * es[j][0];
+          v1 = v2f{__builtin_amdgcn_fmed3f(v1.x, l1.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v1.y, l1.y, __builtin_inff())} * es[j][1];
+          dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + j * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
         }
       }
       dec_sat_flush<T>(g.sat, sm);
+      // the next tile to compute
+      if (++ctx == g.tiles_x) {
+        ctx = 0;
+        if (++cty == g.tiles_y) {
+          cty = 0;
+          ++cf;
+        }
+      }
     }
   }
 }
