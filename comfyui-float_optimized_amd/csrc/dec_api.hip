@@ -196,8 +196,7 @@ int raise_lds_limits() {
   const int lim = 32 * 1024 * T::EB;
 #define CONV16_ATTR(NTv, TYv, TXv) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, NTv, TYv, TXv>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3) CONV16_ATTR(4, 2, 2) CONV16_ATTR(2, 2, 2) CONV16_ATTR(4, 2, 1) CONV16_ATTR(2, 2, 1)
-  CONV16_ATTR(4, 1, 2) CONV16_ATTR(2, 1, 2) CONV16_ATTR(4, 1, 1) CONV16_ATTR(2, 1, 1)
+  CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3)
 #undef CONV16_ATTR
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -461,12 +460,12 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
   const int ty_taps = dymax - dymin + 1, tx_taps = dxmax - dxmin + 1;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   const bool prof = fh_prof_pair(1, &e0, &e1);
-  if (tdim == 16 && ty_taps * tx_taps == ntaps && Ho % 16 == 0 && Wo % 16 == 0 && Ho == Hi && Wo == Wi) {
+  if (tdim == 16 && ty_taps == 3 && tx_taps == 3 && ntaps == 9 && Ho % 16 == 0 && Wo % 16 == 0 && Ho == Hi && Wo == Wi) {
     // dense TY x TX window on 16x16 tiles: compile-time geometry, swizzled LDS, register prefetch
     const int total = g.tiles_x * g.tiles_y * F;
     static const int tpw_env = env_int("FLOAT_DEC_TPW", 0, 0, 4096);  // tuning aid
     g.tpw = tpw_env ? tpw_env : (total >= 16384 ? 4 : (total >= 4096 ? 2 : 1));
-    const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * RB + (size_t)ntaps * bn * RB;
+    const size_t smem = (size_t)(15 + ty_taps) * (15 + tx_taps) * RB + (size_t)ntaps * bn * RB + 3 * bn * sizeof(float);  // halo, weights, epilogue operands
     if (h) g.ct = take_ride(h, Ho, 1);
     dim3 grid((total + g.tpw - 1) / g.tpw + g.ct.nwg, s.cout / bn);
     if (g_dec_cb_order && s.cout / bn > 1) {  // channel blocks of a tile group side by side on one XCD (dec_group_cb)
@@ -479,8 +478,7 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
     if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
     else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);                  \
   }
-    CONV16(4, 3, 3) CONV16(2, 3, 3) CONV16(4, 2, 2) CONV16(2, 2, 2) CONV16(4, 2, 1) CONV16(2, 2, 1) CONV16(4, 1, 2)
-    CONV16(2, 1, 2) CONV16(4, 1, 1) CONV16(2, 1, 1)
+    CONV16(4, 3, 3) CONV16(2, 3, 3)
 #undef CONV16
   } else {
     const size_t smem = (size_t)npix * RB + (size_t)ntaps * bn * RB;
@@ -1171,6 +1169,23 @@ int float_dec_debug_flow_level(const float_dec_unit_t* u, const float_tensor_t* 
   TensorTable tt(tensors, n_tensors);
   return DEC_DISPATCH(u->dtype, unit_flow_level<T>(u, tt, x, feat, style, prev_flow, prev_rgb, out_flow, out_blend, out_rgb, (hipStream_t)stream));
 }
+
+#ifdef DEC_PHASES
+int float_dec_debug_phases(unsigned long long* out16, int reset) {
+  static unsigned long long all[64 * 16];
+  FH_CHECK_HIP(hipDeviceSynchronize());
+  FH_CHECK_HIP(hipMemcpyFromSymbol(all, HIP_SYMBOL(g_dec_phase), sizeof(all)));
+  for (int i = 0; i < 16; ++i) {
+    out16[i] = 0;
+    for (int r = 0; r < 64; ++r) out16[i] += all[r * 16 + i];
+  }
+  if (reset) {
+    memset(all, 0, sizeof(all));
+    FH_CHECK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dec_phase), all, sizeof(all)));
+  }
+  return FLOAT_OK;
+}
+#endif
 
 #ifdef DEC_STAMPS
 int float_dec_debug_stamps(unsigned long long* out4) {

@@ -10,6 +10,7 @@
 // batch and the conv becomes an implicit GEMM with M = frames*pixels.
 #pragma once
 #include "common.hpp"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------
 // Range check of the fp16 mode (float_dec_saturation).  fp16 ends at 65504; a checkpoint whose activations leave that range
@@ -242,6 +243,40 @@ __device__ unsigned long long g_dec_stamps[4];
 #else
 #define DEC_STAMP_MIN(i)
 #define DEC_STAMP_MAX(i)
+#endif
+// Where the lanes of a partial tile store instead of branching around the store (dec_zblur_kernel: the filter loop stays one
+// basic block, so the compiler can run the LDS reads of the following rows ahead of the current row's arithmetic): 16 bytes per
+// lane, never read.
+static __device__ unsigned long long g_dec_sink[64 * 2];
+
+// diagnostic build only (make EXTRA=-DDEC_PHASES): 10-ns wall clock spent by wave 0 of every workgroup between phase marks,
+// summed per phase: [0..7] dec_zblur_kernel, [8..15] dec_conv16_kernel (float_dec_debug_phases)
+#ifdef DEC_PHASES
+__device__ unsigned long long g_dec_phase[64 * 16];  // 64 replicas (workgroup id mod 64) x 16 slots
+#define DEC_PH_BEGIN                                              \
+  unsigned long long ph_t = __builtin_amdgcn_s_memrealtime();    \
+  unsigned ph_acc[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#define DEC_PH(i)                                                      \
+  do {                                                                 \
+    if (threadIdx.x == 0) {                                            \
+      const unsigned long long ph_n = __builtin_amdgcn_s_memrealtime(); \
+      ph_acc[(i) & 7] += (unsigned)(ph_n - ph_t);                      \
+      ph_t = ph_n;                                                     \
+    }                                                                  \
+  } while (0)
+#define DEC_PH_COUNT(i) do { if (threadIdx.x == 0) ph_acc[(i) & 7] += 1u; } while (0)
+#define DEC_PH_END(base)                                                                                   \
+  do {                                                                                                     \
+    if (threadIdx.x == 0) {                                                                                \
+      for (int ph_i = 0; ph_i < 8; ++ph_i)                                                                 \
+        if (ph_acc[ph_i]) atomicAdd(&g_dec_phase[(blockIdx.x & 63) * 16 + (base) + ph_i], (unsigned long long)ph_acc[ph_i]); \
+    }                                                                                                      \
+  } while (0)
+#else
+#define DEC_PH_BEGIN
+#define DEC_PH(i)
+#define DEC_PH_COUNT(i)
+#define DEC_PH_END(base)
 #endif
 // at the top of a kernel that may carry a copy: the copy workgroups do their share and leave; BID = the compute block id
 #define DEC_COPY_PROLOGUE(g, BID)                                   \
@@ -711,6 +746,7 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv_kernel(ConvArgs
 template <class T, int NT, int TY, int TX>
 __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
+  DEC_PH_BEGIN
   typedef typename T::elem E;
   typedef typename T::pack8 P8;
   typedef float v2f __attribute__((ext_vector_type(2)));
@@ -721,7 +757,8 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* const sA = smem;              // [NPIX][RB], chunk ^ ((halo column >> 1) & 3)
   unsigned char* const sB = smem + NPIX * RB;  // [NTAPS][BN][RB], chunk ^ ((row >> 1) & 3)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  float* const sE = reinterpret_cast<float*>(sB + NBROWS * RB);  // [3][BN]: demod, bias, next style of the tile's (frame, channels)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave index is uniform: scalar arithmetic
   const int r16 = lane & 15, q = lane >> 4;
   const int Wi = g.Wi, Cin = g.Cin;
 
@@ -783,6 +820,7 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
   unsigned s_hit = 0u;   // per chunk: 4-bit field != 0 <=> the chunk lies outside the image (zero padding)
 
   P8 ra[NA], rb[NB];
+  float4 re = float4{0.f, 0.f, 0.f, 0.f};
   auto issue = [&]() {
     const unsigned edge = (sty == 0 ? 1u : 0u) | (sty == g.tiles_y - 1 ? 2u : 0u) | (stx == 0 ? 4u : 0u) | (stx == g.tiles_x - 1 ? 8u : 0u);
     s_edge = edge;
@@ -802,6 +840,15 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
       for (int i = 0; i < NB - 1; ++i) rb[i] = *reinterpret_cast<const P8*>(Wc + i * b_round + b_off);
       rb[NB - 1] = *reinterpret_cast<const P8*>(Wc + b_off_l);
     }
+    // the tile's per-(frame, channel) epilogue operands travel with its last chunk: thread t < 3 BN / 4 stages 4 floats of
+    // (demod | bias | next style); read in the epilogue they cost ~1 us of exposed latency per tile (r03 in-kernel stamps)
+    if (schunk == nchunks - 1 && tid < 3 * BN / 4) {
+      const int which = tid / (BN / 4), co = n0 + (tid % (BN / 4)) * 4;
+      re = float4{which == 1 ? 0.f : 1.f, which == 1 ? 0.f : 1.f, which == 1 ? 0.f : 1.f, which == 1 ? 0.f : 1.f};
+      if (which == 0 && g.demod) re = *reinterpret_cast<const float4*>(g.demod + (size_t)sf * g.ldd + co);
+      if (which == 1 && g.act) re = *reinterpret_cast<const float4*>(g.bias + co);
+      if (which == 2 && g.snext) re = *reinterpret_cast<const float4*>(g.snext + (size_t)sf * g.lds + co);
+    }
     // advance the staging cursor
     if (++schunk == nchunks) {
       schunk = 0;
@@ -819,6 +866,7 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
   int chunk = 0;
   bool first = true;
   issue();
+  DEC_PH(8);
   for (int item = 0; item < nitems; ++item) {
     __syncthreads();  // every wave is done reading the previous item's tiles
     if (s_edge == 0u) {
@@ -834,7 +882,9 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
       *reinterpret_cast<P8*>(sB + b_lds_l) = rb[NB - 1];
       first = false;
     }
+    if (chunk == nchunks - 1 && tid < 3 * BN / 4) *reinterpret_cast<float4*>(sE + tid * 4) = re;
     __syncthreads();
+    DEC_PH(9);
     if (item + 1 < nitems) issue();  // in flight while this item computes
     if (chunk == 0) {
 #pragma unroll
@@ -862,17 +912,18 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
         }
       }
     }
+    DEC_PH(10);
     if (++chunk == nchunks) {
       chunk = 0;
+      DEC_PH_COUNT(15);
       // v = lrelu(acc * d + b) * (sqrt2 * s): leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf) (one instruction; fmaxf
       // costs a canonicalising v_max first), slope = 1 when the layer has no activation; the sqrt(2) rides in the style
       v2f ed[NT][2], eb[NT][2], es[NT][2];
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const int co = n0 + j * 16 + q * 4;
-        const float4 d = g.demod ? *reinterpret_cast<const float4*>(g.demod + (size_t)cf * g.ldd + co) : float4{1.f, 1.f, 1.f, 1.f};
-        const float4 bb = g.act ? *reinterpret_cast<const float4*>(g.bias + co) : float4{0.f, 0.f, 0.f, 0.f};
-        float4 sn = g.snext ? *reinterpret_cast<const float4*>(g.snext + (size_t)cf * g.lds + co) : float4{1.f, 1.f, 1.f, 1.f};
+        const float4 d = *reinterpret_cast<const float4*>(sE + j * 16 + q * 4);
+        const float4 bb = *reinterpret_cast<const float4*>(sE + BN + j * 16 + q * 4);
+        float4 sn = *reinterpret_cast<const float4*>(sE + 2 * BN + j * 16 + q * 4);
         if (g.act) {
           sn.x *= 1.4142135623730951f;
           sn.y *= 1.4142135623730951f;
@@ -903,6 +954,7 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
         }
       }
       dec_sat_flush<T>(g.sat, sm);
+      DEC_PH(11);
       // the next tile to compute
       if (++ctx == g.tiles_x) {
         ctx = 0;
@@ -913,6 +965,7 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
       }
     }
   }
+  DEC_PH_END(8);
 }
 
 // All four parity classes of the stride-2 transposed conv in ONE launch (styledecoder.py:250-257): output
@@ -1061,50 +1114,78 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zconv4_kernel(ConvAr
 // Transposed conv AND its FIR blur in one launch, for the levels whose z tensor is HBM traffic (r01: at 512x512 the separate
 // kernels ran at 3.4 TB/s - z is written once and read once, 2 x 16.8 MB per frame, for nothing).  A workgroup computes the
 // z values of a 16x16 block of (m, n) positions like dec_zconv4_kernel - 32x32 z pixels x 32 channels - parks them in LDS
-// (fp16, the rounding the z tensor had), and filters the 28x28 output pixels whose 4x4 support lies inside: block origin
-// (14 ty - 1, 14 tx - 1), output tile origin (28 ty, 28 tx), out[Y][X] = sum_ab k[a] k[b] z[Y - 1 + a][X - 1 + b].  Positions
-// outside the image read zero inputs, so their z (the blur's zero padding) comes out as exact zeros by itself.  (16/14)^2 =
-// 1.31x the MFMA work of the unfused kernel buys 59 -> 25 MB of traffic per frame at 512x512.
+// (in the operand type, the rounding the z tensor had), and filters the 28x28 output pixels whose 4x4 support lies inside:
+// block origin (14 ty - 1, 14 tx - 1), output tile origin (28 ty, 28 tx), out[Y][X] = sum_ab k[a] k[b] z[Y - 1 + a][X - 1 + b].
+// Positions outside the image read zero inputs, so their z (the blur's zero padding) comes out as exact zeros by itself.
+// (16/14)^2 = 1.31x the MFMA work of the unfused kernel buys 59 -> 25 MB of traffic per frame at 512x512.
+//
+// The filter runs on the matrix pipe (round 3; the listing of the VALU filter: 2 600 vector instructions per tile against 144
+// MFMAs, 2 x 17 x 4 z packs converted to fp32 by every thread - the kernel was issue-bound at 211 TFLOP/s):
+//   * the conv accumulates D[position n][channel] (pixel operand first), so a lane holds 4 consecutive n of one channel for
+//     both column parities = 8 CONSECUTIVE z columns: one pack, written to the z tile as [z row][channel][32 z columns];
+//   * the horizontal pass of z row zr is ONE MFMA per (16 channels, 16 output columns): A = the z row (a lane's pack = 8
+//     consecutive columns of its channel, K = the 32 columns of the tile), B = the banded filter matrix Bx[zc][X] =
+//     k[zc - X - 1] (constants in 2 x 4 registers), fp32 accumulation of exact products - the sums the VALU filter formed;
+//   * its result D[channel][X] leaves 4 consecutive channels of one output column in a lane, row after row, so the vertical
+//     pass is 4 packed fp32 operations on a 3-row register history and the epilogue stores 8 bytes per lane like the convs.
+// Wave (j, half) filters channels 16 j .. + 15 of output rows 14 half .. + 13: 17 fragment reads, 34 MFMAs.
 template <class T>
 __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
+  DEC_PH_BEGIN
   typedef typename T::elem E;
   typedef typename T::pack8 P8;
-  constexpr int RB = 32 * T::EB, CB = 8 * T::EB;
-  const E* const X = reinterpret_cast<const E*>(g.X);
-  const E* const Wt = reinterpret_cast<const E*>(g.Wt);
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  constexpr int EB = T::EB, RB = 32 * EB, CB = 8 * EB;
   constexpr int NT = 2, BN = 32, HW = 17, NPIX = HW * HW, NTAPS = 9;
-  constexpr int NA = (NPIX * 4 + 255) / 256, NBC = NTAPS * BN * 4, NB = (NBC + 255) / 256;
+  constexpr int NA = (NPIX * 4 + 255) / 256, NBROWS = NTAPS * BN, NB = (NBROWS * 4 + 255) / 256;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* sA = smem;              // [17*17][RB], pack-swizzled
-  unsigned char* sB = smem + NPIX * RB;  // [9][BN][RB], pack-swizzled
-  unsigned char* sZ = smem;              // after the K loop: [32][32][RB] z tile, pack c of pixel (zr, zc) at c ^ ((zc >> 2) & 3)
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned char* const sA = smem;              // [17*17][RB], chunk ^ ((halo column >> 1) & 3)
+  unsigned char* const sB = smem + NPIX * RB;  // [9][BN][RB], chunk ^ ((row >> 1) & 3)
+  unsigned char* const sZ = smem;              // after the K loop: [32 z rows][32 channels][RB = 32 z columns], chunk ^ ((channel >> 1) & 3)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // uniform: scalar arithmetic
   const int r16 = lane & 15, q = lane >> 4;
-  unsigned aaddr[4][2];
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int mrow = (w * 4 + mt), x = r16;
-#pragma unroll
-    for (int sh = 0; sh < 4; ++sh) {
-      const int P = (mrow + (sh >> 1)) * HW + x + (sh & 1);  // halo origin is (m-1, n-1)
-      const unsigned off = (unsigned)(P * RB + (q ^ ((P >> 1) & 3)) * CB);
-      if (sh & 1) aaddr[mt][sh >> 1] |= off << 16;
-      else aaddr[mt][sh >> 1] = off;
-    }
-  }
-  const int baddr = r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB;
+  const int Wi = g.Wi, Cin = g.Cin;
   const int tiles_pf = g.tiles_x * g.tiles_y;
   unsigned grp = bid, cb = blockIdx.y;
   if (g.ncb) dec_group_cb(bid, g.ngroups, g.ncb, grp, cb);
-  const int tile = grp;
-  const int f = tile / tiles_pf, rem = tile - f * tiles_pf;
+  const int f = (int)grp / tiles_pf, rem = (int)grp - f * tiles_pf;
   const int ty = rem / g.tiles_x, tx = rem - ty * g.tiles_x;
   const int n0 = cb * BN;
-  const int nchunks = g.Cin >> 5;
-  const int iy0 = ty * 14 - 2, ix0 = tx * 14 - 2;
+  const int nchunks = Cin >> 5;
+  const int iy0 = ty * 14 - 2, ix0 = tx * 14 - 2;  // halo origin: position (m - 1, n - 1) of the block's first (m, n)
 
-  f32x4 acc[4][4][NT];  // [class][m-tile][n-tile]
+  // ---- staging constants (one tile per workgroup: the border logic runs once).  Chunk e = tid + 256 i: pixel p = e >> 2, pack
+  // ch = e & 3; lanes past the last pixel repeat the last pixel's chunk.  A chunk outside the image loads a valid address and
+  // is stored as zeros.
+  const int ch = tid & 3;
+  const bool interior = iy0 >= 0 && iy0 + HW <= g.Hi && ix0 >= 0 && ix0 + HW <= Wi;
+  unsigned a_off[NA], a_lds[NA], a_bad = 0u;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int p = min((tid >> 2) + 64 * i, NPIX - 1);
+    const int hy = p / HW, hx = p - hy * HW;
+    const bool in = (unsigned)(iy0 + hy) < (unsigned)g.Hi && (unsigned)(ix0 + hx) < (unsigned)Wi;
+    a_off[i] = (unsigned)((((in ? hy : 2) * Wi + (in ? hx : 2)) * Cin + ch * 8) * EB);  // (2, 2) = position (14 ty, 14 tx): inside
+    a_lds[i] = (unsigned)(p * RB + (ch ^ ((hx >> 1) & 3)) * CB);
+    a_bad |= (in ? 0u : 1u) << i;
+  }
+  const unsigned char* const Xo = reinterpret_cast<const unsigned char*>(g.X) + ((long long)(f * g.Hi + iy0) * Wi + ix0) * Cin * EB;
+  const int brow = tid >> 2;
+  const unsigned b_off = (unsigned)((((brow / BN) * g.Cout + brow % BN) * Cin + ch * 8) * EB);
+  const int brow_l = min(brow + 64 * (NB - 1), NBROWS - 1);
+  const unsigned b_off_l = (unsigned)((((brow_l / BN) * g.Cout + brow_l % BN) * Cin + ch * 8) * EB);
+  const unsigned b_lds = (unsigned)(brow * RB + (ch ^ ((brow >> 1) & 3)) * CB);
+  const unsigned b_lds_l = (unsigned)(brow_l * RB + (ch ^ ((brow_l >> 1) & 3)) * CB);
+  const size_t b_round = (size_t)(64 / BN) * g.Cout * Cin * EB;
+  const unsigned char* const Wn = reinterpret_cast<const unsigned char*>(g.Wt) + (size_t)n0 * Cin * EB;
+  // A fragment of input shift (dy, dx) in {-1, 0}^2 and m-tile mt: halo row w*4 + mt + dy + 1, columns r16 + dx + 1
+  unsigned fa[2];
+#pragma unroll
+  for (int dx = 0; dx < 2; ++dx) fa[dx] = (unsigned)(((w * 4) * HW + r16 + dx) * RB + (q ^ (((r16 + dx) >> 1) & 3)) * CB);
+  const unsigned fb = (unsigned)(r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB);
+
+  f32x4 acc[4][4][NT];  // [class pu*2 + pv][m-tile][n-tile]: D[position n = 4q + reg][channel j*16 + r16]
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -1113,153 +1194,177 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArg
       for (int j = 0; j < NT; ++j) acc[c][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   P8 ra[NA], rb[NB];
+  float dm[NT];
+  float4 b4, s4;
   auto issue = [&](int chunk) {
-    const int c0 = chunk << 5;
+    const unsigned char* const Xc = Xo + (size_t)(chunk << 5) * EB;
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      ra[i] = T::zero8();
-      if (p < NPIX) {
-        const int hy = p / HW, hx = p - hy * HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        if (iy >= 0 && iy < g.Hi && ix >= 0 && ix < g.Wi)
-          ra[i] = T::load8(X + ((size_t)(f * g.Hi + iy) * g.Wi + ix) * g.Cin + c0 + ch * 8);
-      }
-    }
+    for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const P8*>(Xc + a_off[i]);
+    const unsigned char* const Wc = Wn + (size_t)(chunk << 5) * EB;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int e = tid + i * 256;
-      if (e < NBC) {
-        const int row = e >> 2, ch = e & 3;
-        const int tap = row / BN, n = row - tap * BN;
-        rb[i] = T::load8(Wt + ((size_t)tap * g.Cout + n0 + n) * g.Cin + c0 + ch * 8);
-      }
-    }
+    for (int i = 0; i < NB - 1; ++i) rb[i] = *reinterpret_cast<const P8*>(Wc + i * b_round + b_off);
+    rb[NB - 1] = *reinterpret_cast<const P8*>(Wc + b_off_l);
   };
   issue(0);
+  DEC_PH(0);
   for (int chunk = 0; chunk < nchunks; ++chunk) {
     __syncthreads();
+    if (interior) {
 #pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int e = tid + i * 256, p = e >> 2, ch = e & 3;
-      if (p < NPIX) *reinterpret_cast<P8*>(sA + p * RB + (ch ^ ((p >> 1) & 3)) * CB) = ra[i];
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ra[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ((a_bad >> i) & 1u) ? T::zero8() : ra[i];
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const int e = tid + i * 256;
-      if (e < NBC) {
-        const int row = e >> 2, ch = e & 3;
-        *reinterpret_cast<P8*>(sB + row * RB + (ch ^ ((row >> 1) & 3)) * CB) = rb[i];
-      }
-    }
+    for (int i = 0; i < NB - 1; ++i) *reinterpret_cast<P8*>(sB + b_lds + i * 64 * RB) = rb[i];
+    *reinterpret_cast<P8*>(sB + b_lds_l) = rb[NB - 1];
     __syncthreads();
-    if (chunk + 1 < nchunks) issue(chunk + 1);
-    constexpr int kNum[4] = {1, 2, 2, 4};  // see dec_zconv4_kernel
+    DEC_PH(1);
+    if (chunk + 1 < nchunks) {
+      issue(chunk + 1);
+    } else {
+      // what the phases after the K loop need from memory, requested before the MFMAs that hide the latency
+#pragma unroll
+      for (int j = 0; j < NT; ++j) dm[j] = g.demod[(size_t)f * g.ldd + n0 + j * 16 + r16];
+      const int co = n0 + (w & 1) * 16 + q * 4;
+      b4 = *reinterpret_cast<const float4*>(g.bias + co);
+      s4 = *reinterpret_cast<const float4*>(g.snext + (size_t)f * g.lds + co);
+    }
+    // input shift sh = 2*(dy+1) + (dx+1): 0 (-1,-1)  1 (-1,0)  2 (0,-1)  3 (0,0); the A fragments of one shift serve every
+    // (class, tap) that reads it: class 0 taps 0..3 = sh 0..3; class 1 (pv=1) taps 4,5 = sh 1,3; class 2 (pu=1) taps 6,7 =
+    // sh 2,3; class 3 tap 8 = sh 3
+    constexpr int kNum[4] = {1, 2, 2, 4};
     constexpr int kTap[4][4] = {{0, 0, 0, 0}, {1, 4, 0, 0}, {2, 6, 0, 0}, {3, 5, 7, 8}};
     constexpr int kCls[4][4] = {{0, 0, 0, 0}, {0, 1, 0, 0}, {0, 2, 0, 0}, {0, 1, 2, 3}};
 #pragma unroll
     for (int sh = 0; sh < 4; ++sh) {
       P8 a[4];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt)
-        a[mt] = *reinterpret_cast<const P8*>(sA + ((sh & 1) ? (aaddr[mt][sh >> 1] >> 16) : (aaddr[mt][sh >> 1] & 0xffffu)));
+      for (int mt = 0; mt < 4; ++mt) a[mt] = *reinterpret_cast<const P8*>(sA + fa[sh & 1] + (mt + (sh >> 1)) * HW * RB);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (u < kNum[sh]) {
           const int t = kTap[sh][u], c = kCls[sh][u];
           P8 b[NT];
 #pragma unroll
-          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const P8*>(sB + baddr + (t * BN + j * 16) * RB);
+          for (int j = 0; j < NT; ++j) b[j] = *reinterpret_cast<const P8*>(sB + fb + (t * BN + j * 16) * RB);
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[c][mt][j] = T::mfma(b[j], a[mt], acc[c][mt][j]);
+            for (int j = 0; j < NT; ++j) acc[c][mt][j] = T::mfma(a[mt], b[j], acc[c][mt][j]);
         }
       }
     }
+    DEC_PH(2);
   }
-  // z tile -> LDS: lane (r16, q) holds channels j*16 + q*4 .. +3 of z pixel (2*(w*4+mt) + pu, 2*r16 + pv)
+  // ---- z tile -> LDS.  Lane (r16, q) holds channel j*16 + r16 of z pixels (zr = 2 (w*4 + mt) + pu, zc = 2 (4q + reg) + pv):
+  // pv = 0 / 1 interleave to z columns 8q .. 8q + 7, one pack.
   __syncthreads();  // every wave is done with the operand tiles
   unsigned sm = 0u;
   {
-    float4 ed[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) ed[j] = *reinterpret_cast<const float4*>(g.demod + (size_t)f * g.ldd + n0 + j * 16 + q * 4);
+    const unsigned zw = (unsigned)(((8 * w) * 32 + r16) * RB + (q ^ ((r16 >> 1) & 3)) * CB);
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const int zr = 2 * (w * 4 + mt) + (c >> 1), zc = 2 * r16 + (c & 1);
-        unsigned char* zp = sZ + (zr * 32 + zc) * RB;
+      for (int pu = 0; pu < 2; ++pu)
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          const float4 d = ed[j];
-          const int chunk = (j * 2 + (q >> 1)) ^ ((zc >> 2) & 3);
-          dec_store4<T>(reinterpret_cast<E*>(zp + chunk * CB + (q & 1) * (CB / 2)), acc[c][mt][j][0] * d.x, acc[c][mt][j][1] * d.y,
-                        acc[c][mt][j][2] * d.z, acc[c][mt][j][3] * d.w, sm);
+          const f32x4 ev = acc[pu * 2][mt][j], od = acc[pu * 2 + 1][mt][j];
+          const float d = dm[j];
+          const float v[8] = {ev[0] * d, od[0] * d, ev[1] * d, od[1] * d, ev[2] * d, od[2] * d, ev[3] * d, od[3] * d};
+          *reinterpret_cast<P8*>(sZ + zw + ((2 * mt + pu) * 32 + j * 16) * RB) = dec_pack8<T>(v, sm);
         }
-      }
   }
   __syncthreads();
-  // FIR + bias + lrelu*sqrt2 + next style: thread = (8-channel group cg, output column X, half of the 28 rows); the 64 lanes
-  // of a wave read 16 consecutive pixels x 64 B per LDS row (conflict-free), each z row is filtered horizontally once and
-  // feeds the four output rows it belongs to through a 3-row history
+  DEC_PH(3);
+  // ---- FIR + bias + lrelu*sqrt2 + next style.  Output row Yl (tile-local) takes z rows Yl + 1 .. Yl + 4, output column X
+  // takes z columns X + 1 .. X + 4, weights (1, 3, 3, 1) / 4 per axis (the up-sampling gain 4 included).
   {
-    const int cg = tid & 3, X = (tid & 127) >> 2, half = tid >> 7;
-    const int gx = tx * 28 + X;
-    if (X < 28 && gx < g.OW) {
-      // two channels per packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32): the filter is VALU-bound
-      typedef float v2f __attribute__((ext_vector_type(2)));
-      const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-      v2f bs[4], sn[4];
+    const int j2 = w & 1, half = w >> 1;
+    P8 bx[2];  // Bx[zc = 8q + k][X = 16 xt + r16]
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float2 b2 = *reinterpret_cast<const float2*>(g.bias + n0 + cg * 8 + i * 2);
-        const float2 s2 = *reinterpret_cast<const float2*>(g.snext + (size_t)f * g.lds + n0 + cg * 8 + i * 2);
-        bs[i] = v2f{b2.x, b2.y};
-        sn[i] = v2f{s2.x * 1.4142135623730951f, s2.y * 1.4142135623730951f};  // leaky_relu's sqrt(2) rides in the style
+    for (int xt = 0; xt < 2; ++xt) {
+      bx[xt] = T::zero8();
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int t = 8 * q + k - (16 * xt + r16) - 1;
+        const float kv = (16 * xt + r16 < 28) ? ((t == 0 || t == 3) ? 0.25f : ((t == 1 || t == 2) ? 0.75f : 0.f)) : 0.f;
+        T::set(bx[xt], k, kv);
       }
-      v2f h0[4], h1[4], h2[4];
+    }
+    // b4, s4: this wave's bias / next style (channels n0 + j2*16 + q*4 .. +3), loaded under the last chunk's MFMAs.  The asm
+    // makes the compiler wait for them HERE: left to the first use inside the row loop it put an `s_waitcnt vmcnt(0)` in front
+    // of every row's arithmetic, which on gfx9 also waits for the previous row's STORES - 28 store round trips in series, 8.9
+    // of the 15 us a 512-px tile took (r03 in-kernel stamps).
+    asm volatile("" : "+v"(b4.x), "+v"(b4.y), "+v"(b4.z), "+v"(b4.w), "+v"(s4.x), "+v"(s4.y), "+v"(s4.z), "+v"(s4.w));
+    const v2f bs[2] = {v2f{b4.x, b4.y}, v2f{b4.z, b4.w}};
+    const v2f sn[2] = {v2f{s4.x * 1.4142135623730951f, s4.y * 1.4142135623730951f},
+                       v2f{s4.z * 1.4142135623730951f, s4.w * 1.4142135623730951f}};  // leaky_relu's sqrt(2) rides in the style
+    const unsigned zrd = (unsigned)((((half * 14 + 1) * 32) + j2 * 16 + r16) * RB + (q ^ ((r16 >> 1) & 3)) * CB);
+    // stores: lane (r16, q) writes 4 channels of output pixel (28 ty + yl, 28 tx + 16 xt + r16); lanes / rows outside the tile's
+    // 28 x 28 block or outside the image store into g_dec_sink instead (no branch: the row loop is one basic block)
+    unsigned char* const yt = reinterpret_cast<unsigned char*>(g.Y) + ((((size_t)f * g.OH + ty * 28) * g.OW + tx * 28) * g.Cout + n0) * EB;
+    unsigned char* const sink = reinterpret_cast<unsigned char*>(g_dec_sink) + lane * 16;
+    unsigned char* yp[2];
+    unsigned ystep[2];  // bytes between output rows; 0 for a lane that stores into the sink
 #pragma unroll
-      for (int i = 0; i < 4; ++i) h0[i] = h1[i] = h2[i] = v2f{0.f, 0.f};
+    for (int xt = 0; xt < 2; ++xt) {
+      const bool ok = 16 * xt + r16 < 28 && tx * 28 + 16 * xt + r16 < g.OW;
+      yp[xt] = ok ? yt + (size_t)((16 * xt + r16) * g.Cout + j2 * 16 + q * 4) * EB : sink;
+      ystep[xt] = ok ? (unsigned)(g.OW * g.Cout * EB) : 0u;
+    }
+    // FULL: all 28 output rows of the tile exist (every tile but the last row of tiles): no per-row test
+    auto filter = [&](auto full_rows) {
+      constexpr bool FULL = decltype(full_rows)::value;
+      v2f h0[2][2], h1[2][2], h2[2][2];
+#pragma unroll
+      for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) h0[xt][i] = h1[xt][i] = h2[xt][i] = v2f{0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 17; ++r) {
-        const int zr = half * 14 + 1 + r;  // z rows Yl + 1 .. Yl + 4 of output row Yl
-        v2f h[4];
+        const P8 a = *reinterpret_cast<const P8*>(sZ + zrd + r * 32 * RB);
+        v2f h[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) h[i] = v2f{0.f, 0.f};
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int zc = X + 1 + b;
-          const P8 u = *reinterpret_cast<const P8*>(sZ + (zr * 32 + zc) * RB + (cg ^ ((zc >> 2) & 3)) * CB);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) h[i] += k1[b] * v2f{T::get(u, 2 * i), T::get(u, 2 * i + 1)};
+        for (int xt = 0; xt < 2; ++xt) {
+          const f32x4 d = T::mfma(a, bx[xt], f32x4{0.f, 0.f, 0.f, 0.f});  // D[channel 4q + reg][X = 16 xt + r16]
+          h[xt][0] = v2f{d[0], d[1]};
+          h[xt][1] = v2f{d[2], d[3]};
         }
         if (r >= 3) {
-          const int gy = ty * 28 + half * 14 + (r - 3);
-          if (gy < g.OH) {
-            float ov[8];
+          const int yl = half * 14 + r - 3;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              v2f v = k1[0] * h0[i] + k1[1] * h1[i] + k1[2] * h2[i] + k1[3] * h[i] + bs[i];
-              const v2f lo = 0.2f * v;
-              v = v2f{__builtin_amdgcn_fmed3f(v.x, lo.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v.y, lo.y, __builtin_inff())} * sn[i];  // leaky_relu(0.2)
-              ov[2 * i] = v.x;
-              ov[2 * i + 1] = v.y;
+          for (int xt = 0; xt < 2; ++xt) {
+            v2f v[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              v2f t = 0.25f * (h0[xt][i] + h[xt][i]) + bs[i];
+              t = 0.75f * (h1[xt][i] + h2[xt][i]) + t;
+              const v2f lo = 0.2f * t;
+              v[i] = v2f{__builtin_amdgcn_fmed3f(t.x, lo.x, __builtin_inff()), __builtin_amdgcn_fmed3f(t.y, lo.y, __builtin_inff())} * sn[i];  // leaky_relu(0.2)
             }
-            T::store8(reinterpret_cast<E*>(g.Y) + ((size_t)(f * g.OH + gy) * g.OW + gx) * g.Cout + n0 + cg * 8, dec_pack8<T>(ov, sm));
+            unsigned char* const dst = (FULL || ty * 28 + yl < g.OH) ? yp[xt] + (unsigned)yl * ystep[xt] : sink;
+            dec_store4<T>(reinterpret_cast<E*>(dst), v[0].x, v[0].y, v[1].x, v[1].y, sm);
           }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          h0[i] = h1[i];
-          h1[i] = h2[i];
-          h2[i] = h[i];
-        }
+        for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            h0[xt][i] = h1[xt][i];
+            h1[xt][i] = h2[xt][i];
+            h2[xt][i] = h[xt][i];
+          }
       }
-    }
+      };
+    if (ty * 28 + 28 <= g.OH) filter(std::true_type{});
+    else filter(std::false_type{});
   }
   dec_sat_flush<T>(g.sat, sm);
+  DEC_PH(4);
+  DEC_PH_COUNT(7);
+  DEC_PH_END(0);
 }
 
 // Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4) over the

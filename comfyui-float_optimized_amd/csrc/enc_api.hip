@@ -286,7 +286,7 @@ int launch_conv3x3_tiles(float_enc* h, const EConv& L, const void* X, int R, voi
     g.ncb = ncb;
     grid = dim3(ngroups * ncb, 1);
   }
-  const size_t smem = (size_t)18 * 18 * RB + (size_t)9 * 32 * RB;
+  const size_t smem = (size_t)18 * 18 * RB + (size_t)9 * 32 * RB + 3 * 32 * sizeof(float);  // halo, weights, epilogue operands
   hipLaunchKernelGGL((dec_conv16_kernel<T, 2, 3, 3>), grid, dim3(256), smem, st, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
