@@ -449,18 +449,32 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
         o[k][2] += __shfl_xor(o[k][2], d, 64);
       }
     }
-    float mask[PIX], ax[PIX], ay[PIX], inw[PIX][4];
+    // Sample position, tap addresses and blend weights of a pixel are the same in all its lanes: lane `sub` forms them for
+    // pixel sub & (PIX - 1) ONLY and the group reads them by lane index (ds_bpermute: LDS pipe) - 9 values per pixel instead of
+    // ~100 vector instructions per pixel in every lane (r03 listing: a third of the kernel's 1 200 instructions per iteration,
+    // and the kernel is VALU-bound).
+    float mask[PIX], wg[PIX][4];
+    unsigned fo[PIX][4];
     P8 fu[PIX][4];
+    {
+      const int ks = sub & (PIX - 1);
+      float f0 = o[0][0], f1 = o[0][1], f2 = o[0][2];
 #pragma unroll
-    for (int k = 0; k < PIX; ++k) {
-      const float sx = fh_tanh_fast<T::is32>(o[k][0]) + g.lin[X0 + k], sy = fh_tanh_fast<T::is32>(o[k][1]) + gy;
-      mask[k] = fh_sigmoid_t<T::is32>(o[k][2]);
+      for (int k = 1; k < PIX; ++k)
+        if (ks == k) {
+          f0 = o[k][0];
+          f1 = o[k][1];
+          f2 = o[k][2];
+        }
+      const float sx = fh_tanh_fast<T::is32>(f0) + g.lin[X0 + ks], sy = fh_tanh_fast<T::is32>(f1) + gy;
+      const float mk = fh_sigmoid_t<T::is32>(f2);
       // grid_sample, align_corners=False: pixel = ((coord + 1) * size - 1) / 2
       const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;
       const float fx0 = floorf(ix), fy0 = floorf(iy);
       const int x0 = (int)fx0, y0 = (int)fy0;  // |ix| <= R + 1: tanh bounds the sample position
-      ax[k] = ix - fx0;
-      ay[k] = iy - fy0;
+      const float axk = ix - fx0, ayk = iy - fy0;
+      float own_w[4];
+      unsigned own_o[4];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -469,9 +483,23 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
           const int yy = y0 + a, xx = x0 + b;
           const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
           const int yc = min(max(yy, 0), R - 1), xc = min(max(xx, 0), R - 1);
-          fu[k][a * 2 + b] = T::load8(featp + (unsigned)((yc * R + xc) * C + c0));
-          inw[k][a * 2 + b] = in ? 1.f : 0.f;
+          own_o[a * 2 + b] = (unsigned)((yc * R + xc) * C);
+          own_w[a * 2 + b] = (a ? ayk : 1.f - ayk) * (b ? axk : 1.f - axk) * mk * (in ? 1.f : 0.f);
         }
+      const int gb = (int)(threadIdx.x & 63) - sub;  // first lane of this pixel group
+#pragma unroll
+      for (int k = 0; k < PIX; ++k) {
+        mask[k] = __shfl(mk, gb + k, 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          wg[k][t] = __shfl(own_w[t], gb + k, 64);
+          fo[k][t] = (unsigned)__shfl((int)own_o[t], gb + k, 64);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < PIX; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) fu[k][t] = T::load8(featp + fo[k][t] + (unsigned)c0);
     }
     float upr[3] = {0.f, 0.f, 0.f};
     if (ff.prgb && owner) up2_tap3(ff.prgb, 0, Rp, Y, X0 + sub, upr);
@@ -485,7 +513,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          const float wgt = (a ? ay[k] : 1.f - ay[k]) * (b ? ax[k] : 1.f - ax[k]) * mask[k] * inw[k][a * 2 + b];
+          const float wgt = wg[k][a * 2 + b];
 #pragma unroll
           for (int i = 0; i < 8; ++i) fw[i] += wgt * T::get(fu[k][a * 2 + b], i);
         }
@@ -1271,8 +1299,9 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArg
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
           const f32x4 ev = acc[pu * 2][mt][j], od = acc[pu * 2 + 1][mt][j];
-          const float d = dm[j];
-          const float v[8] = {ev[0] * d, od[0] * d, ev[1] * d, od[1] * d, ev[2] * d, od[2] * d, ev[3] * d, od[3] * d};
+          const v2f d = v2f{dm[j], dm[j]};
+          const v2f z0 = v2f{ev[0], od[0]} * d, z1 = v2f{ev[1], od[1]} * d, z2 = v2f{ev[2], od[2]} * d, z3 = v2f{ev[3], od[3]} * d;
+          const float v[8] = {z0.x, z0.y, z1.x, z1.y, z2.x, z2.y, z3.x, z3.y};
           *reinterpret_cast<P8*>(sZ + zw + ((2 * mt + pu) * 32 + j * 16) * RB) = dec_pack8<T>(v, sm);
         }
   }
