@@ -64,6 +64,51 @@ __device__ __forceinline__ typename T::pack8 dec_pack8(const float (&v)[8], unsi
   }
 }
 
+// Packs addressed as a uniform base plus a 32-bit BYTE offset: the global_load / global_store take the base in scalar registers
+// and the offset as it is (an element offset costs a 64-bit shift-and-add per access: 38 of the flow kernel's 800 vector
+// instructions per iteration).
+template <class T>
+__device__ __forceinline__ typename T::pack8 dec_load8_b(const void* base, unsigned byte_off) {
+  return T::load8(reinterpret_cast<const typename T::elem*>(reinterpret_cast<const unsigned char*>(base) + byte_off));
+}
+template <class T>
+__device__ __forceinline__ typename T::pack8 dec_load8_b_nt(const void* base, unsigned byte_off) {
+  return T::load8_nt(reinterpret_cast<const typename T::elem*>(reinterpret_cast<const unsigned char*>(base) + byte_off));
+}
+template <class T>
+__device__ __forceinline__ void dec_store8_b(void* base, unsigned byte_off, const typename T::pack8& v) {
+  T::store8(reinterpret_cast<typename T::elem*>(reinterpret_cast<unsigned char*>(base) + byte_off), v);
+}
+// acc[i] += w * v[i] for the 8 elements of a pack.  fp16: v_fma_mix_f32 converts the half inside the FMA - one instruction per
+// element where the compiler's v_cvt_f32_f16 + half a v_pk_fma_f32 is 1.5 (it prefers those; right for elements used by several
+// FMAs, wrong for a bilinear tap, which is used once).  Same single rounding as the fused form it replaces.
+template <class T>
+__device__ __forceinline__ void dec_scale8(float (&acc)[8], const typename T::pack8& v, float w) {  // acc[i] = w * v[i]
+  if constexpr (T::is_fp16) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel_hi:[1,0,0]" : "=v"(acc[2 * d]) : "v"(v[d]), "v"(w));
+      asm("v_fma_mix_f32 %0, %1, %2, 0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(acc[2 * d + 1]) : "v"(v[d]), "v"(w));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = w * T::get(v, i);
+  }
+}
+template <class T>
+__device__ __forceinline__ void dec_axpy8(float (&acc)[8], const typename T::pack8& v, float w) {
+  if constexpr (T::is_fp16) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(acc[2 * d]) : "v"(v[d]), "v"(w));
+      asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(acc[2 * d + 1]) : "v"(v[d]), "v"(w));
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += w * T::get(v, i);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // out[f][j] = epi( sum_k in[f][k]^(1|2) * Wt[k][j] ), fp32, Wt stored k-major so lanes read
 // consecutive j.  Used for the 22 EqualLinear style modulations (styledecoder.py:229,241) in one
@@ -403,10 +448,10 @@ __device__ __forceinline__ FlowFrame<T> dec_flow_frame(const FlowArgs& g, int f)
 template <class T, int PIX>
 __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFrame<T>& ff, const float* __restrict__ sw, int p0, int sub,
                                                 int lpp, const typename T::pack8 (&xu)[PIX], unsigned& sm) {
-  typedef typename T::elem E;
   typedef typename T::pack8 P8;
-  const E* const featp = reinterpret_cast<const E*>(g.feat);
+  constexpr unsigned EB = T::EB;
   const int C = g.C, c0 = sub * 8;
+  const unsigned cb0 = (unsigned)c0 * EB;  // byte offset of this lane's 8 channels inside a pixel
   const bool owner = sub < PIX;
   const float bf0 = ff.bf[0], bf1 = ff.bf[1], bf2 = ff.bf[2];
   const float b10 = ff.b1[0], b11 = ff.b1[1], b12 = ff.b1[2], b20 = ff.b2[0], b21 = ff.b2[1], b22 = ff.b2[2];
@@ -483,7 +528,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
           const int yy = y0 + a, xx = x0 + b;
           const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
           const int yc = min(max(yy, 0), R - 1), xc = min(max(xx, 0), R - 1);
-          own_o[a * 2 + b] = (unsigned)((yc * R + xc) * C);
+          own_o[a * 2 + b] = (unsigned)((yc * R + xc) * C) * EB;  // bytes
           own_w[a * 2 + b] = (a ? ayk : 1.f - ayk) * (b ? axk : 1.f - axk) * mk * (in ? 1.f : 0.f);
         }
       const int gb = (int)(threadIdx.x & 63) - sub;  // first lane of this pixel group
@@ -499,24 +544,17 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
 #pragma unroll
       for (int k = 0; k < PIX; ++k)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fu[k][t] = T::load8(featp + fo[k][t] + (unsigned)c0);
+        for (int t = 0; t < 4; ++t) fu[k][t] = dec_load8_b<T>(g.feat, fo[k][t] + cb0);
     }
     float upr[3] = {0.f, 0.f, 0.f};
     if (ff.prgb && owner) up2_tap3(ff.prgb, 0, Rp, Y, X0 + sub, upr);
     float rgb[PIX][3];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
-      float fw[8];
+      float fw[8];  // the warped, masked features: sum over the 4 taps of weight * feature
+      dec_scale8<T>(fw, fu[k][0], wg[k][0]);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fw[i] = 0.f;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          const float wgt = wg[k][a * 2 + b];
-#pragma unroll
-          for (int i = 0; i < 8; ++i) fw[i] += wgt * T::get(fu[k][a * 2 + b], i);
-        }
+      for (int t = 1; t < 4; ++t) dec_axpy8<T>(fw, fu[k][t], wg[k][t]);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
         const float4 w0 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0);
@@ -531,7 +569,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
         float ov[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) ov[i] = (fw[i] + T::get(xu[k], i) * om) * sn[i];
-        T::store8(ff.xnext + (unsigned)((p0 + k) * C + c0), dec_pack8<T>(ov, sm));
+        dec_store8_b<T>(ff.xnext, (unsigned)((p0 + k) * C) * EB + cb0, dec_pack8<T>(ov, sm));
       }
     }
     for (int d = 1; d < lpp; d <<= 1) {
@@ -1539,7 +1577,7 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   for (int p0 = band * g.band_pix + grp * PIX; p0 < pend; p0 += gpb * PIX) {
     typename T::pack8 xu[PIX];
 #pragma unroll
-    for (int k = 0; k < PIX; ++k) xu[k] = T::load8_nt(xf + (unsigned)((p0 + k) * C + c0));  // read once: leave L2 to the features
+    for (int k = 0; k < PIX; ++k) xu[k] = dec_load8_b_nt<T>(xf, (unsigned)(((p0 + k) * C + c0) * T::EB));  // read once: leave L2 to the features
     dec_flow_pixels<T, PIX>(g, ff, sw, p0, sub, lpp, xu, sm);
   }
   dec_sat_flush<T>(g.sat, sm);
