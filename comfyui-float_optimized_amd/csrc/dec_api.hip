@@ -352,13 +352,25 @@ static const unsigned kRideWgs = (unsigned)env_int("FLOAT_DEC_RIDE_WGS", 16, 0, 
 static const int kRideMinRes = env_int("FLOAT_DEC_RIDE_MIN_RES", 64, 64, 512);
 static const unsigned kRidePace = (unsigned)env_int("FLOAT_DEC_RIDE_PACE", 3, 0, 64);
 
-// Relative duration of a carrying launch (kind 0 = up-conv + blur, 1 = conv2, 2 = flow / warp / ToRGB) at resolution R: the
-// share of the pending copy it takes is proportional to it, so that every share ends inside its launch (measured per 32-frame
-// batch, us; other resolutions: equal shares).
+// Weight of a carrying launch (kind 0 = up-conv + blur, 1 = conv2, 2 = flow / warp / ToRGB) at resolution R: the share of the
+// pending copy it takes is proportional to it, so that every share ends inside its launch (per 32-frame batch, ~us; other
+// resolutions: equal shares).
 static double ride_weight(int R, int kind) {
   static const bool equal = getenv("FLOAT_DEC_RIDE_EQUAL") != nullptr;
   if (equal) return 1.0;
-  static const double w[4][3] = {{191, 210, 89}, {178, 224, 89}, {242, 295, 235}, {341, 328, 325}};  // re-measured in round 3 (flow kernel -35 %)
+  // launch durations (tools/probes/trace_sequence.py on the round-3 kernels: {203,155,61},{178,175,118},{242,226,215},{318,256,336})
+  // shifted toward the flow launches, which absorb a share without getting longer while the 512-px convs are stretched by theirs
+  // (a trace of the carrying batch: +49 / +56 us there, +6 on the flow launch): 26.35 vs 26.80 ms per 250 frames decode + hand-over
+  static double w[4][3] = {{170, 150, 70}, {178, 175, 125}, {242, 205, 230}, {290, 225, 370}};
+  static const bool tuned = [] {  // tuning aid: FLOAT_DEC_RIDE_W="12 numbers", rows 64 / 128 / 256 / 512 px x (up-conv, conv2, flow)
+    const char* e = getenv("FLOAT_DEC_RIDE_W");
+    double t[12];
+    if (e && sscanf(e, "%lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf %lf", t, t + 1, t + 2, t + 3, t + 4, t + 5, t + 6, t + 7, t + 8, t + 9, t + 10, t + 11) == 12)
+      for (int i = 0; i < 12; ++i)
+        if (t[i] > 0.0 && t[i] < 1e6) w[i / 3][i % 3] = t[i];
+    return true;
+  }();
+  (void)tuned;
   const int li = R == 64 ? 0 : R == 128 ? 1 : R == 256 ? 2 : R == 512 ? 3 : -1;
   return li < 0 ? 250.0 : w[li][kind];
 }
