@@ -221,6 +221,71 @@ struct FP32 {
   }
 };
 
+// ---------------------------------------------------------------- range tracking of 16-bit stores (float_{fmt,enc,aud}_saturation)
+// FP16::from_float clamps at +-65504 (a NaN becomes -65504): outside the decoder an out-of-range activation degrades the
+// result instead of poisoning it, but it must not do so silently.  Every 16-bit activation store of the FMT, encoder and
+// audio kernels goes through fh_cvt / fh_set / fh_store4 (or packs first and calls fh_track_pack): the thread keeps the
+// running maximum of the stored half-precision magnitudes, two u16 lanes in one register (v_and_b32 + v_pk_max_u16 per two
+// values, as dec_cvt2 does in the decoder), and fh_range_flush adds 1 to the handle's 64-bit device counter once per thread
+// if a magnitude reached 0x7bff = 65504, the clamp value.  The counter counts threads with at least one clamped store -
+// zero or not is what matters.  BF16 (fp32's exponent range) and FP32 instantiations compile to the plain conversions.
+typedef unsigned short fh_us2 __attribute__((ext_vector_type(2)));
+template <class T>
+__device__ __forceinline__ void fh_track_u32(unsigned& m, unsigned packed2) {  // two packed halves
+  if constexpr (T::is_fp16)
+    m = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(fh_us2, m), __builtin_bit_cast(fh_us2, packed2 & 0x7fff7fffu)));
+}
+template <class T>
+__device__ __forceinline__ void fh_track_pack(unsigned& m, const typename T::pack8& u) {
+  if constexpr (T::is_fp16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fh_track_u32<T>(m, u[i]);
+  }
+}
+template <class T>
+__device__ __forceinline__ typename T::elem fh_cvt(float x, unsigned& m) {
+  const typename T::elem h = T::from_float(x);
+  if constexpr (T::is_fp16) fh_track_u32<T>(m, (unsigned)h);
+  return h;
+}
+template <class T>
+__device__ __forceinline__ void fh_set(typename T::pack8& v, int j, float x, unsigned& m) {
+  if constexpr (T::is_fp16) reinterpret_cast<u16*>(&v)[j] = fh_cvt<T>(x, m);
+  else T::set(v, j, x);
+}
+template <class T>
+__device__ __forceinline__ void fh_store4(typename T::elem* p, float a, float b, float c, float d, unsigned& m) {
+  if constexpr (T::is_fp16) {
+    uint2 o;
+    o.x = (unsigned)T::from_float(a) | ((unsigned)T::from_float(b) << 16);
+    o.y = (unsigned)T::from_float(c) | ((unsigned)T::from_float(d) << 16);
+    fh_track_u32<T>(m, o.x);
+    fh_track_u32<T>(m, o.y);
+    *reinterpret_cast<uint2*>(p) = o;
+  } else {
+    T::store4(p, a, b, c, d);
+  }
+}
+template <class T, int SITE, bool ON>
+__device__ __forceinline__ void fh_store4_wt(typename T::elem* p, float a, float b, float c, float d, unsigned& m) {
+  if constexpr (T::is_fp16) {
+    const unsigned lo = (unsigned)T::from_float(a) | ((unsigned)T::from_float(b) << 16);
+    const unsigned hi = (unsigned)T::from_float(c) | ((unsigned)T::from_float(d) << 16);
+    fh_track_u32<T>(m, lo);
+    fh_track_u32<T>(m, hi);
+    if constexpr (ON && (FMT_WT & SITE) != 0) fh_store8_wt<SITE, true>(p, (unsigned long long)lo | ((unsigned long long)hi << 32));
+    else *reinterpret_cast<uint2*>(p) = uint2{lo, hi};
+  } else {
+    T::template store4_wt<SITE, ON>(p, a, b, c, d);
+  }
+}
+template <class T>
+__device__ __forceinline__ void fh_range_flush(unsigned long long* ctr, unsigned m) {
+  if constexpr (T::is_fp16) {
+    if (ctr && ((m & 0xffffu) >= 0x7bffu || (m >> 16) >= 0x7bffu)) atomicAdd(ctr, 1ull);
+  }
+}
+
 // ---------------------------------------------------------------- small device math
 __device__ __forceinline__ float fh_silu(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float fh_sigmoid(float x) { return 1.f / (1.f + __expf(-x)); }

@@ -30,9 +30,10 @@ struct float_fmt {
   // workspace
   u16 *cond16, *sc16, *h16, *hfin16, *qkv16, *att16, *hid16, *xin16, *tsin16, *th16;
   float *ccond, *xres, *xcur, *temb, *vout;
-  float* slab = nullptr;  // [4][Mpad][D] split-K partial sums (EPI_PARTIAL)
+  float* slab = nullptr;  // [8][Mpad][D] split-K partial sums (EPI_PARTIAL; the fused attention + proj launch writes one slab per head)
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
   int method = 0;          // FLOAT_ODE_*
+  int attnproj = 0;        // heads per workgroup of the fused attention + proj launch (FLOAT_FMT_ATTNPROJ), 0 = two launches
   float* kbuf = nullptr;   // [4][kMaxTok][dim_w] stage velocities of the Runge-Kutta solvers
   // Modulations of up to kScSteps evaluations of a window, [step][Mmod][Ntot] fp32: c = t_emb + c_embedder(wr, wa, we) does not
   // depend on x (FMT.py:333-335, 163-166), so every adaLN projection of those evaluations is ONE GEMM per window.
@@ -507,7 +508,8 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
     if (ks == 0) LN_LAUNCH(NV, 0);      \
     else if (ks == 1) LN_LAUNCH(NV, 1); \
     else if (ks == 2) LN_LAUNCH(NV, 2); \
-    else LN_LAUNCH(NV, 4);              \
+    else if (ks == 4) LN_LAUNCH(NV, 4); \
+    else LN_LAUNCH(NV, 8);              \
     break;
   switch (nv) {
     LN_CASE(1) LN_CASE(2) LN_CASE(4) LN_CASE(8)
@@ -553,6 +555,41 @@ void launch_attn(float_fmt* h, int M, const Lin* pull, hipStream_t s) {
     else ATTN_LAUNCH(8, false);
   }
 #undef ATTN_LAUNCH
+}
+
+// Banded attention + attn.proj as one launch (fmt_attnproj_kernel): slab[head] = attention_head(qkv16) @ W_proj[:, head]^T for
+// the M rows; the caller hands the fold (bias, gate, residual) to the next LayerNorm launch through PendingRed with ks = heads.
+// FLOAT_FMT_ATTNPROJ=1|2 (heads per workgroup; read at float_fmt_create) selects it; the default is the two-launch form
+// (fmt_attn_kernel, then the proj GEMM), which measured the same or faster - see the kernel's header.
+int attnproj_hpw(const float_fmt* h) {
+  const int hd = h->cfg.heads, hpw = h->attnproj;
+  if (hpw <= 0 || h->D != hd * 128 || hd % hpw) return 0;
+  const int ks = hd / hpw;
+  return (ks == 1 || ks == 2 || ks == 4 || ks == 8) && (hpw == 1 || hpw == 2) ? hpw : 0;
+}
+template <class T>
+int launch_attnproj(float_fmt* h, int M, const Lin& proj, hipStream_t s) {
+  const float_fmt_cfg_t& c = h->cfg;
+  const int hpw = attnproj_hpw(h);
+  GemmArgs g = base_args(nullptr, proj, M);
+  g.out_f32 = h->slab;
+  g.ldo = g.N;
+  g.slab_stride = (size_t)h->Mpad * g.N;
+  g.ksplit = c.heads / hpw;
+  g.mblk = ((M + 15) / 16 + 2) / 3;
+  const dim3 grid((unsigned)(g.ksplit * (g.N / (128 / hpw)) * g.mblk));
+  hipEvent_t e0, e1;
+  const bool prof = fh_prof_pair(0, &e0, &e1);
+#define AP_LAUNCH(HPW)                                                                                                                              \
+  do {                                                                                                                                              \
+    if (prof) hipExtLaunchKernelGGL((fmt_attnproj_kernel<T, 3, HPW>), grid, dim3(512), 0, s, e0, e1, 0, h->qkv16, 3 * h->D, g, h->ntok, h->D, c.attn_window); \
+    else hipLaunchKernelGGL((fmt_attnproj_kernel<T, 3, HPW>), grid, dim3(512), 0, s, h->qkv16, 3 * h->D, g, h->ntok, h->D, c.attn_window);         \
+  } while (0)
+  if (hpw == 2) AP_LAUNCH(2);
+  else AP_LAUNCH(1);
+#undef AP_LAUNCH
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
 }
 
 // Modulation half of the evaluations [e0, e0 + n) of a window: depends only on t and the window's conditions, NOT on x
@@ -624,16 +661,22 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       GemmArgs g = base_args(h->h16, B.qkv, M);
       g.out16 = h->qkv16;
       g.ldo16 = 3 * D;
-      if ((g_fmt_touch & 8) && !split_ok(g_fmt_proj_split, B.proj)) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
+      if ((g_fmt_touch & 8) && attnproj_hpw(h)) g.touch = make_touch(B.proj, M, c.heads / attnproj_hpw(h), gemm_lanes_per_xcd(M, g.N, g.K), 2, 8 / attnproj_hpw(h));  // k-slices <-> XCDs as the fused launch decodes them
+      else if ((g_fmt_touch & 8) && !split_ok(g_fmt_proj_split, B.proj)) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       static const LayerPlan plan("FLOAT_FMT_PLAN_QKV");
       if ((rc = run_gemm<T, EPI_T16>(g, s, false, &plan))) return rc;
     }
-    launch_attn<T>(h, M, (g_fmt_touch & 2) && !split_ok(g_fmt_proj_split, B.proj) ? &B.proj : nullptr, s);
-    if (split_ok(g_fmt_proj_split, B.proj)) {
+    if (attnproj_hpw(h)) {
+      if ((rc = launch_attnproj<T>(h, M, B.proj, s))) return rc;
+      pend.ks = c.heads / attnproj_hpw(h);
+      pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
+    } else if (split_ok(g_fmt_proj_split, B.proj)) {
+      launch_attn<T>(h, M, nullptr, s);
       if ((rc = run_gemm_partial<T>(h, base_args(h->att16, B.proj, M), g_fmt_proj_split, s))) return rc;
       pend.ks = g_fmt_proj_split;
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
     } else {
+      launch_attn<T>(h, M, (g_fmt_touch & 2) ? &B.proj : nullptr, s);
       GemmArgs g = base_args(h->att16, B.proj, M);
       g.out_f32 = h->xres;
       g.ldo = D;
@@ -1128,6 +1171,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (const char* v = getenv("FLOAT_FMT_FULL_NW")) g_fmt_full_nw = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
+  h->attnproj = getenv("FLOAT_FMT_ATTNPROJ") ? atoi(getenv("FLOAT_FMT_ATTNPROJ")) : 0;
   if (const char* v = getenv("FLOAT_FMT_HOIST")) g_fmt_hoist = atoi(v) != 0;
   if (const char* v = getenv("FLOAT_FMT_ZGROUP")) g_fmt_zgroup = std::max(0, atoi(v));
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
@@ -1162,7 +1206,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (!rc) rc = h->pool.alloc(&h->modall, (size_t)kScSteps * h->Mmod * h->Ntot, false);
   A(&h->kbuf, (size_t)4 * h->Bmax * kMaxTok * cfg->dim_w);
   A(&h->xres, (size_t)Mp * D);
-  A(&h->slab, (size_t)4 * Mp * D);
+  A(&h->slab, (size_t)8 * Mp * D);
   A(&h->xcur, (size_t)h->Bmax * cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
   A(&h->vout, (size_t)h->Bmax * kMaxTok * cfg->dim_w);

@@ -90,5 +90,6 @@ struct GemmArgs {
   // EPI_CFG: rows are token-blocked, row = (i / 16) * (bc * 16) + b * 16 + i % 16 for token i, CFG row b, so a workgroup
   // with bc row tiles holds every CFG row of its 16 tokens (else: row = b * ntok + i and the workgroup holds all rows)
   int tokblk;
+  unsigned long long* sat;  // range counter of the launch's 16-bit stores (fh_range_flush) or nullptr
 };
 

@@ -147,3 +147,30 @@ def test_graph_cache_is_bounded():
     for i in range(12):
         assert torch.isfinite(fmt.sample(r_s, wa, we, noise, 4, 2.0 + 0.1 * i, 1.0, 1.0)).all()
     assert torch.equal(fmt.sample(r_s, wa, we, noise, 4, 1.5, 1.0, 1.0).cpu(), first)
+
+
+@pytest.mark.parametrize("hpw", [1, 2])
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_fused_attention_proj_launch(hpw, dtype, monkeypatch):
+    """FLOAT_FMT_ATTNPROJ=1|2: banded attention and attn.proj in ONE launch (split-K over the heads, folded by the next
+    LayerNorm launch; FMT.py:71-89) against the same reference goldens as the default two-launch chain, and bitwise
+    reproducible from run to run."""
+    monkeypatch.setenv("FLOAT_FMT_ATTNPROJ", str(hpw))
+    g = golden("fmt_eval_full")
+    cfg = C.FmtConfig()
+    sd, fmt = _fmt(cfg, g["seed"], dtype)
+    tol = 2e-5 if dtype == "fp32" else TOL[dtype]
+    for case in ("cfg3", "cfg4"):
+        a, r, e, rc = [float(v) for v in g[case + "_scales"]]
+        call = lambda: fmt.forward_with_cfv(g["t"], g[case + "_x"], g[case + "_wa"], g[case + "_wr"], g[case + "_we"],  # noqa: E731
+                                            g[case + "_prev_x"], g[case + "_prev_wa"], g.get(case + "_prev_we"),
+                                            a_cfg_scale=a, r_cfg_scale=r, e_cfg_scale=e, include_r_cfg=bool(rc)).cpu()
+        out = call()
+        err = rel_l2(out, g[case + "_out"])
+        print("fused hpw=%d" % hpw, dtype, case, "rel-L2 %.3e" % err)
+        assert err < tol, (case, err)
+        assert torch.equal(out, call())
+    gs = golden("fmt_sample_full_static")
+    sd, fmt = _fmt(cfg, gs["seed"], dtype)
+    r_d = fmt.sample(gs["r_s"], gs["wa"], gs["we"], gs["noise"], gs["nfe"], gs["a"], 1.0, gs["e"]).cpu()
+    assert rel_l2(r_d, gs["r_d"]) < tol
