@@ -30,6 +30,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# an fp16 operator that leaves its range during a timed clip invalidates the number: make it an error (pipeline.report_range)
+os.environ["FLOAT_AMD_RANGE"] = "raise"
 
 # SURVEY.md section 8(d) algorithmic work per unit
 FMT_WEIGHT_BYTES_PER_EVAL = 313.4e6    # every 16-bit weight of the FMT once
@@ -62,6 +64,9 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stage split / hot-path side numbers")
     ap.add_argument("--no-bf16", action="store_true", help="skip the second measurement with bf16 FMT operands")
+    ap.add_argument("--no-s2e", action="store_true", help="skip the measurement with the speech-emotion model in the step "
+                    "(emotion='none', the reference's default widget: wav2vec2-large classifier on the clip's audio)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the literal nfe=50 run and the run from host inputs")
     return ap.parse_args()
 
 
@@ -169,6 +174,7 @@ def main():
     dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
     dist = None
+    rccl_ranks, rccl_note = None, None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -178,6 +184,26 @@ def main():
             dist.init_process_group(backend)
         if dist.get_world_size() != world:
             raise RuntimeError("rendezvous gave %d ranks, expected %d" % (dist.get_world_size(), world))
+    elif backend == "nccl" and os.environ.get("FLOAT_BENCH_RCCL1", "1") != "0":
+        # N = 1: still bring RCCL up (a one-rank communicator on this GPU) so that the collective calls of the N > 1 modes have
+        # run on the box at least once; a failure here is reported on the line, it does not fail the single-GPU measurement
+        try:
+            import torch.distributed as dist
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=dev)
+        except Exception as e:  # noqa: BLE001
+            rccl_note = "RCCL one-rank communicator failed: %s" % (str(e).splitlines()[0][:200],)
+            dist = None
+    if dist is not None and backend == "nccl":
+        # ranks as RCCL itself counts them: all_reduce of ones on the device, plus the other two collectives of
+        # distributed.py (all_gather of boundary latents, broadcast of the chain) on tensors of their real sizes
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        tail = torch.zeros(2, 10, 512, device=dev)
+        gathered = [torch.empty_like(tail) for _ in range(dist.get_world_size())]
+        dist.all_gather(gathered, tail)
+        dist.broadcast(tail, src=0)
+        torch.cuda.synchronize()
+        rccl_ranks = int(ones.item())
 
     pkg = load_pkg()
     cfg = pkg.config.FmtConfig()
@@ -194,6 +220,10 @@ def main():
     acfg = pkg.config.AudioConfig()
     parts = dict(enc=pkg.weights.synth_encoder_state(args.size, seed=1), dec=dec_sd, fmt=fmt_sd,
                  audio_encoder=(pkg.weights.synth_audio_state(acfg, seed=1), acfg))
+    with_s2e = rank == 0 and world == 1 and not args.no_s2e and not args.dynamic_we
+    if with_s2e:  # the speech-emotion model at its checkpoint shape (wav2vec2-large, 24 layers: wav2vec2_ser.py:23-96)
+        ecfg = pkg.config.emotion_audio_config()
+        parts["emotion_encoder"] = (pkg.weights.synth_audio_state(ecfg, seed=2), ecfg)
     agent = gen.InferenceAgent(opt, parts, dev, max_frames=args.max_frames, use_graph=0 if args.no_graph else 2,
                                fmt_dtype=args.fmt_dtype, dec_dtype=args.dec_dtype)
     hp, enc, aud = agent.G, agent.enc, agent.audio_encoder
@@ -226,11 +256,13 @@ def main():
         wa = aud.inference(wav, seq_len=T_total)
         return s_r, r_s, wa
 
+    emo_of_step = ["neutral"]  # a label: the emotion is given.  None = the reference's default widget 'none' (speech-to-emotion)
+
     def step():
         """(image, waveform) in HBM -> this rank's frames in pinned host memory."""
         last.pop("host", None)  # the previous result is released first, as a caller that consumed it would have
         if product:
-            last["host"] = agent.infer_device(img, wav, a_cfg, 1.0, e_cfg, emo="neutral", seed=15)
+            last["host"] = agent.infer_device(img, wav, a_cfg, 1.0, e_cfg, emo=emo_of_step[0], seed=15)
             return
         s_r, r_s, wa = conditioning()
         if args.mode == "window" and world > 1:
@@ -269,7 +301,10 @@ def main():
     host = last["host"]
     assert host.shape[0] == n_local and host.is_pinned()
     assert float(host[0].min()) >= 0.0 and float(host[-1].max()) <= 1.0 and float(host.mean()) > 0.0
-    assert hp.dec.saturation() == 0, "the fp16 decoder clamped activations: frames are not the reference's"
+    # fp16 range: every timed clip went through agent.check_range in "raise" mode (product path); the operator-driven
+    # modes are checked here
+    range_hits = agent.range_counts(reset=True)
+    assert not any(range_hits.values()), "an fp16 operator left its range: frames are not the reference's: %s" % range_hits
     frames_per_step = T_total if one_clip else T * world
     fps = frames_per_step * args.steps / elapsed
     staging = hp.staging(n_local)
@@ -295,6 +330,8 @@ def main():
         st = {"appearance_encoder": ev_ms(lambda: (enc.encode_image_into_latent(img, want_feats=False), enc.hand_feats_to(hp.dec))),
               "audio_encoder": ev_ms(lambda: aud.inference(wav, seq_len=T_total)),
               "fmt_sample": ev_ms(f_sample)}
+        if with_s2e:
+            st["speech_emotion"] = ev_ms(lambda: agent.emotion_predictor(wav))
         rd_loc = keep["r_d"][0, t0f:t1f]
         st["decode"] = ev_ms(lambda: hp.decode(s_r, None, rd_loc))
         st["decode_and_d2h"] = ev_ms(lambda: hp.dec.decode_into_host(s_r, rd_loc, host, staging))
@@ -342,11 +379,11 @@ def main():
             mod_roof["frac"] = round(mod_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
         # HBM traffic per launch / MFMA pipe utilisation from the committed rocprofv3 --pmc passes (tools/profile_round.sh),
         # only when they were taken on these kernel sources
-        pmc = load_profile_json("r03_pmc_traffic.json", warnings)
+        pmc = load_profile_json("r04_pmc_traffic.json", warnings)
         if pmc:
             gemm_roof["traffic"] = pmc.get("fmt_gemm", {}).get("hbm_bytes_per_launch")
             conv_roof["traffic"] = pmc.get("dec_conv", {}).get("hbm_bytes_per_launch")
-        mf = load_profile_json("r03_pmc_mfma.json", warnings)
+        mf = load_profile_json("r04_pmc_mfma.json", warnings)
         if mf:
             gemm_roof["mfma_util_pmc"] = mf.get("fmt_gemm", {}).get("mfma_util")
             conv_roof["mfma_util_pmc"] = mf.get("dec_conv", {}).get("mfma_util")
@@ -372,6 +409,54 @@ def main():
         el = time.perf_counter() - t0
         bf16 = {"value_bf16": round(T * k / el, 3), "ms_per_step_bf16": round(el / k * 1e3, 3), "steps_bf16": k}
         hp.fmt = fmt_keep
+
+    def timed(k):
+        step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        barrier()
+        return time.perf_counter() - t0
+
+    variants = {}
+    if rank == 0 and world == 1 and product:
+        k = max(3, min(20, args.steps))
+        if with_s2e:
+            # the reference's DEFAULT workflow: emotion = 'none' -> the speech-emotion model scores the clip's audio
+            # (nodes.py:146-160, FLOAT.py:196-198); same step, one more operator inside the timed region
+            emo_of_step[0] = None
+            el = timed(k)
+            emo_of_step[0] = "neutral"
+            variants.update({"value_s2e": round(T * k / el, 3), "ms_per_step_s2e": round(el / k * 1e3, 3), "steps_s2e": k})
+        if not args.no_variants:
+            # the literal "nfe = 50" grid of the reference (49 Euler evaluations per window; SURVEY.md section 8 "N ODE steps")
+            nfe_keep = opt.nfe
+            opt.nfe = args.nfe - 1
+            el = timed(k)
+            opt.nfe = nfe_keep
+            variants.update({"value_nfe%d" % (args.nfe - 1): round(T * k / el, 3), "ms_per_step_nfe%d" % (args.nfe - 1): round(el / k * 1e3, 3)})
+            # from HOST inputs, as FloatProcess hands them over (generate.py:139-148): (H,W,3) image in [0,1] and a 16 kHz mono
+            # waveform in pageable host memory -> resize / normalise / H2D (host_inputs) -> the step above
+            ref_img = ((img[0].permute(1, 2, 0) + 1) * 0.5).cpu()[None]
+            ref_audio = {"waveform": wav.reshape(1, 1, -1).cpu(), "sample_rate": 16000}
+
+            def from_host():
+                last.pop("host", None)
+                last["host"] = agent.run_inference(None, ref_img, ref_audio, a_cfg, 1.0, e_cfg, emo="neutral", no_crop=True, seed=15)
+            from_host()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                from_host()
+            barrier()
+            el = time.perf_counter() - t0
+            t1 = time.perf_counter()
+            for _ in range(k):
+                agent.host_inputs(ref_img, ref_audio, True)
+            torch.cuda.synchronize()
+            variants.update({"value_from_host_inputs": round(T * k / el, 3), "ms_per_step_from_host_inputs": round(el / k * 1e3, 3),
+                             "host_inputs_ms": round((time.perf_counter() - t1) / k * 1e3, 3)})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -402,8 +487,13 @@ def main():
                        "decode_batch": args.max_frames, "hip_graph": not args.no_graph, "parallelism": par},
         }
         out.update(extra)
+        out["rccl_ranks"] = rccl_ranks  # ranks as counted by an RCCL all_reduce of ones (None: no RCCL communicator in this run)
+        out["fp16_range_hits"] = sum(range_hits.values())
+        if rccl_note:
+            warnings.append(rccl_note)
         if bf16:
             out.update(bf16)
+        out.update(variants)
         if roof:
             out["roofline"] = roof[0]
             out["roofline_secondary"] = roof[1]
@@ -415,7 +505,7 @@ def main():
             out["warnings"] = warnings
         print(json.dumps(out))
         sys.stdout.flush()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -47,6 +47,13 @@ class AudioEncoderHIP:
         self._h = h
         del keep
 
+    def saturation(self, reset=False):
+        """Threads with a clamped (+-65504) or non-finite 16-bit activation store since create / the last reset
+        (float_aud_saturation): 0 unless the checkpoint leaves fp16's range - then the result is not the reference's within the
+        stated tolerance; run it with dtype="fp32" (or "bf16").  Always 0 for bf16 / fp32 handles.  Synchronises the current stream."""
+        with torch.cuda.device(self.device):
+            return native.saturation("float_aud_saturation", self._h, self.device, reset)
+
     def close(self):
         if getattr(self, "_h", None) and native is not None:
             native.lib().float_aud_destroy(self._h)

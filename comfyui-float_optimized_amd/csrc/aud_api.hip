@@ -55,6 +55,7 @@ struct float_aud {
   float *part = nullptr, *scsh = nullptr;
   void *x16 = nullptr, *hp16 = nullptr, *qkv16 = nullptr, *att16 = nullptr, *hid16 = nullptr, *stack16 = nullptr;
   float *hproj = nullptr, *pos = nullptr, *h = nullptr, *h1 = nullptr, *y = nullptr, *yproj = nullptr;
+  unsigned long long* sat = nullptr;  // range counter of the 16-bit activation stores (float_aud_saturation)
 };
 
 namespace {
@@ -321,7 +322,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   FH_REQUIRE(c.conv_kernel[0] == 10, "first conv kernel must be 10 (got %d)", c.conv_kernel[0]);
   if (c.feat_norm_layer) {
     hipLaunchKernelGGL((aud_conv0_ln_kernel<T, 10>), dim3((L + 3) / 4), dim3(256), 0, st, a, h->w0, h->b0, c.conv_stride[0], L, C, h->gn.g, h->gn.b,
-                       1e-5f, reinterpret_cast<E*>(h->fa));
+                       1e-5f, reinterpret_cast<E*>(h->fa), h->sat);
   } else {
     const int tchunk = 64, nchunk = (L + tchunk - 1) / tchunk;
     hipLaunchKernelGGL((aud_conv0_stats_kernel<10>), dim3(nchunk, (C + 255) / 256), dim3(256), 0, st, a, n_samples, h->w0, c.conv_stride[0], L, C,
@@ -329,13 +330,14 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     hipLaunchKernelGGL(aud_gn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, h->part, nchunk, C, L, h->gn.g, h->gn.b, 1e-5f, h->scsh);
     const size_t tot = (size_t)L * (C / 8);
     hipLaunchKernelGGL((aud_conv0_apply_kernel<T, 10>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, h->w0, c.conv_stride[0], L, C,
-                       h->scsh, reinterpret_cast<E*>(h->fa));
+                       h->scsh, reinterpret_cast<E*>(h->fa), h->sat);
   }
   E *cur = reinterpret_cast<E*>(h->fa), *nxt = reinterpret_cast<E*>(h->fb);
   for (const ConvL& Lc : h->convs) {
     const int Lo = (L - Lc.k) / Lc.stride + 1;
     AudGemmArgs g;
     memset(&g, 0, sizeof(g));
+    g.sat = h->sat;
     g.A = cur;
     g.lda = (long long)Lc.stride * Lc.cin;
     g.W = Lc.W;
@@ -348,17 +350,13 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     g.act = c.feat_norm_layer ? 0 : 1;
     {
       constexpr int smem = 2 * (128 + 64) * 64 * T::EB;  // 48 KiB with 16-bit operands, 96 KiB in the fp32 mode
-      static const bool raised = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(aud_gemm_tile_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        return true;
-      }();
-      (void)raised;
+      // the dynamic-LDS limit is a per-device function attribute: raised at float_aud_create on the handle's device (create_impl)
       hipLaunchKernelGGL((aud_gemm_tile_kernel<T>), dim3((Lo + 127) / 128, Lc.cout / 64), dim3(256), smem, st, g);
     }
     if (c.feat_norm_layer) {  // LayerNorm over channels + GELU, in place
       dim3 grid((Lo + 3) / 4);
-      if (Lc.cout == 512) hipLaunchKernelGGL((aud_rowln_gelu_kernel<T, 2>), grid, dim3(256), 0, st, nxt, Lo, Lc.ln.g, Lc.ln.b, 1e-5f);
-      else hipLaunchKernelGGL((aud_rowln_gelu_kernel<T, 1>), grid, dim3(256), 0, st, nxt, Lo, Lc.ln.g, Lc.ln.b, 1e-5f);
+      if (Lc.cout == 512) hipLaunchKernelGGL((aud_rowln_gelu_kernel<T, 2>), grid, dim3(256), 0, st, nxt, Lo, Lc.ln.g, Lc.ln.b, 1e-5f, h->sat);
+      else hipLaunchKernelGGL((aud_rowln_gelu_kernel<T, 1>), grid, dim3(256), 0, st, nxt, Lo, Lc.ln.g, Lc.ln.b, 1e-5f, h->sat);
     }
     std::swap(cur, nxt);
     L = Lo;
@@ -368,11 +366,12 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   {
     dim3 grid((Tn + 3) / 4);
     switch (C / 256) {
-      case 1: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 1>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, reinterpret_cast<E*>(h->x16)); break;
-      case 2: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 2>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, reinterpret_cast<E*>(h->x16)); break;
+      case 1: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 1>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, reinterpret_cast<E*>(h->x16), h->sat); break;
+      case 2: hipLaunchKernelGGL((aud_interp_ln_kernel<T, 2>), grid, dim3(256), 0, st, cur, L, Tn, h->fp_ln.g, h->fp_ln.b, c.ln_eps, reinterpret_cast<E*>(h->x16), h->sat); break;
       default: fh_set_error("conv_dim %d unsupported", C); return FLOAT_E_INVALID;
     }
     GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->x16), h->fp_proj, Tn);
+    g.sat = h->sat;
     g.out_f32 = h->hproj;
     g.ldo = D;
     if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
@@ -384,6 +383,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   auto ln = [&](const float* a_in, const float* res, const LnP& p, float* o32, void* o16, int keep_sum, void* stack, int stack_col) {
     AudLnArgs g;
     memset(&g, 0, sizeof(g));
+    g.sat = h->sat;
     g.a = a_in;
     g.res = res;
     g.gamma = p.g;
@@ -401,7 +401,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   {
     dim3 grid((Tn + 15) / 16, h->pos_pairs);
 #define POS_CASE(GP) \
-  case GP: hipLaunchKernelGGL((aud_posconv_kernel<T, GP>), grid, dim3(256), 0, st, h->hproj, Tn, D, reinterpret_cast<const E*>(h->pos_w), h->pos_b, c.pos_k, c.pos_k / 2, h->pos); break;
+  case GP: hipLaunchKernelGGL((aud_posconv_kernel<T, GP>), grid, dim3(256), 0, st, h->hproj, Tn, D, reinterpret_cast<const E*>(h->pos_w), h->pos_b, c.pos_k, c.pos_k / 2, h->pos, h->sat); break;
     switch (h->pos_gp) {
       POS_CASE(32) POS_CASE(64) POS_CASE(96) POS_CASE(128)
       default: fh_set_error("merged positional group width %d unsupported", h->pos_gp); return FLOAT_E_INVALID;
@@ -415,16 +415,18 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     const TLayer& Ly = h->layers[l];
     {
       GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->hp16), Ly.qkv, Tn);
+      g.sat = h->sat;
       g.out16 = reinterpret_cast<u16*>(h->qkv16);
       g.ldo16 = 3 * D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_T16, g, st))) return rc;
     }
     {
       hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), 0, st, reinterpret_cast<const E*>(h->qkv16), Tn, D, c.heads,
-                         reinterpret_cast<E*>(h->att16));
+                         reinterpret_cast<E*>(h->att16), h->sat);
     }
     {
       GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->att16), Ly.out, Tn);
+      g.sat = h->sat;
       g.out_f32 = h->y;
       g.ldo = D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
@@ -433,12 +435,14 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     if ((rc = ln(h->y, h->h, c.stable_ln ? Ly.ln2 : Ly.ln1, h->h1, h->hp16, c.stable_ln, nullptr, 0))) return rc;
     {
       GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->hp16), Ly.ff1, Tn);
+      g.sat = h->sat;
       g.out16 = reinterpret_cast<u16*>(h->hid16);
       g.ldo16 = Ly.ff2.K / 32;
       if ((rc = fmt_gemm_run(c.dtype, EPI_GELUERF_P16, g, st))) return rc;
     }
     {
       GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->hid16), Ly.ff2, Tn);
+      g.sat = h->sat;
       g.out_f32 = h->y;
       g.ldo = D;
       if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
@@ -463,11 +467,13 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   } else {
     // ---- audio projection: Linear -> LayerNorm -> SiLU
     GemmArgs g = fmt_gemm_args(reinterpret_cast<const u16*>(h->stack16), h->aproj, Tn);
+    g.sat = h->sat;
     g.out_f32 = h->yproj;
     g.ldo = c.dim_w;
     if ((rc = fmt_gemm_run(c.dtype, EPI_F32, g, st))) return rc;
     AudLnArgs n;
     memset(&n, 0, sizeof(n));
+    n.sat = h->sat;
     n.a = h->yproj;
     n.gamma = h->aproj_ln.g;
     n.beta = h->aproj_ln.b;
@@ -506,6 +512,15 @@ int float_aud_create(const float_aud_cfg_t* cfg, const float_tensor_t* tensors, 
   TensorTable tt(tensors, n_tensors);
   int rc = (cfg->dtype == FLOAT_DT_BF16) ? create_impl<BF16>(h, tt)
            : (cfg->dtype == FLOAT_DT_FP32) ? create_impl<FP32>(h, tt) : create_impl<FP16>(h, tt);
+  if (!rc) rc = h->pool.alloc(&h->sat, 1);
+  if (!rc) {
+    // dynamic-LDS limit of the conv GEMM on THIS device (a second GPU of the process gets its own: the attribute is per device)
+    const int eb = cfg->dtype == FLOAT_DT_FP32 ? 4 : 2, smem = 2 * (128 + 64) * 64 * eb;
+    const void* k = cfg->dtype == FLOAT_DT_BF16   ? reinterpret_cast<const void*>(aud_gemm_tile_kernel<BF16>)
+                    : cfg->dtype == FLOAT_DT_FP32 ? reinterpret_cast<const void*>(aud_gemm_tile_kernel<FP32>)
+                                                  : reinterpret_cast<const void*>(aud_gemm_tile_kernel<FP16>);
+    if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) (void)hipGetLastError();
+  }
   if (rc) {
     float_aud_destroy(h);
     return rc;
@@ -529,6 +544,16 @@ int float_aud_classify(float_aud_t* h, const float* a, int32_t n_samples, float*
   if (h->cfg.dtype == FLOAT_DT_FP32) return inference_impl<FP32>(h, a, n_samples, 0, scores, st);
   return h->cfg.dtype == FLOAT_DT_BF16 ? inference_impl<BF16>(h, a, n_samples, 0, scores, st)
                                        : inference_impl<FP16>(h, a, n_samples, 0, scores, st);
+}
+
+int float_aud_saturation(float_aud_t* h, uint64_t* total, int32_t reset, void* stream) {
+  FH_REQUIRE(h && total, "null argument to float_aud_saturation");
+  FH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long v = 0;
+  FH_CHECK_HIP(hipMemcpy(&v, h->sat, sizeof(v), hipMemcpyDeviceToHost));
+  *total = v;
+  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(v)));
+  return FLOAT_OK;
 }
 
 int float_aud_reserve(float_aud_t* h, int32_t n_samples, int32_t seq_len, void* stream) {

@@ -59,7 +59,7 @@ __global__ void aud_gn_final_kernel(const float* __restrict__ part, int nchunk, 
 template <class T, int KW>
 __global__ __launch_bounds__(256) void aud_conv0_apply_kernel(const float* __restrict__ x, const float* __restrict__ w, int stride, int L,
                                                               int C, const float* __restrict__ scale_shift,
-                                                              typename T::elem* __restrict__ out) {
+                                                              typename T::elem* __restrict__ out, unsigned long long* sat) {
   const int c8 = C >> 3;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)L * c8) return;
@@ -77,6 +77,9 @@ __global__ __launch_bounds__(256) void aud_conv0_apply_kernel(const float* __res
     for (int k = 0; k < KW; ++k) y += w[c * KW + k] * xv[k];
     T::set(o, i, fh_gelu_erf(y * scale_shift[c] + scale_shift[C + c]));
   }
+  unsigned rm = 0u;
+  fh_track_pack<T>(rm, o);
+  fh_range_flush<T>(sat, rm);
   T::store8(out + t * C + cg * 8, o);
 }
 
@@ -95,11 +98,13 @@ struct AudGemmArgs {
   const float* bias;  // [N] or nullptr
   void* out;      // [M][ldc] T::elem
   int M, N, K, ldc, act;  // act 1: GELU(erf)
+  unsigned long long* sat;  // range counter of the 16-bit stores (fh_range_flush)
 };
 
 template <class T>
 __global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
   constexpr int BM = 128, BN = 64, BK = 64;
+  unsigned rm = 0u;  // range tracker (fh_range_flush)
   typedef typename T::elem E;
   typedef typename T::pack8 P8;
   constexpr int EB = T::EB, CB = 8 * EB;  // bytes per element / per pack of 8
@@ -190,9 +195,10 @@ __global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fh_gelu_erf(v[r]);
       }
-      T::store4(reinterpret_cast<E*>(g.out) + (size_t)m * g.ldc + n, v[0], v[1], v[2], v[3]);
+      fh_store4<T>(reinterpret_cast<E*>(g.out) + (size_t)m * g.ldc + n, v[0], v[1], v[2], v[3], rm);
     }
   }
+  fh_range_flush<T>(g.sat, rm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -202,8 +208,9 @@ __global__ __launch_bounds__(256) void aud_gemm_tile_kernel(AudGemmArgs g) {
 template <class T, int NV>
 __global__ __launch_bounds__(256) void aud_interp_ln_kernel(const typename T::elem* __restrict__ f, int L, int Tn,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
-                                                            typename T::elem* __restrict__ out) {
+                                                            typename T::elem* __restrict__ out, unsigned long long* sat) {
   constexpr int C = NV * 256;
+  unsigned rm = 0u;  // range tracker (fh_range_flush)
   const int lane = threadIdx.x & 63;
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= Tn) return;
@@ -234,9 +241,10 @@ __global__ __launch_bounds__(256) void aud_interp_ln_kernel(const typename T::el
     const int c = i * 256 + lane * 4;
     const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
     const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-    T::store4(out + fmt_pack_off(t, c, C / 32), (v[i][0] - mu) * rstd * gm.x + bt.x, (v[i][1] - mu) * rstd * gm.y + bt.y,
-              (v[i][2] - mu) * rstd * gm.z + bt.z, (v[i][3] - mu) * rstd * gm.w + bt.w);
+    fh_store4<T>(out + fmt_pack_off(t, c, C / 32), (v[i][0] - mu) * rstd * gm.x + bt.x, (v[i][1] - mu) * rstd * gm.y + bt.y,
+                 (v[i][2] - mu) * rstd * gm.z + bt.z, (v[i][3] - mu) * rstd * gm.w + bt.w, rm);
   }
+  fh_range_flush<T>(sat, rm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -257,11 +265,13 @@ struct AudLnArgs {
   int stack_col, stack_kb;
   int M, silu;
   int keep_sum;  // 1: out_f32 = a + res (the un-normalised residual stream of a pre-LayerNorm encoder), 0: the LayerNorm output
+  unsigned long long* sat;  // range counter of the 16-bit stores
 };
 
 template <class T, int NV>
 __global__ __launch_bounds__(256) void aud_ln_kernel(AudLnArgs g) {
   constexpr int D = NV * 256;
+  unsigned rm = 0u;  // range tracker (fh_range_flush)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= g.M) return;
@@ -306,9 +316,10 @@ __global__ __launch_bounds__(256) void aud_ln_kernel(AudLnArgs g) {
     }
     if (g.out_f32) *reinterpret_cast<float4*>(g.out_f32 + (size_t)row * D + c) = g.keep_sum ? v[i] : y;
     typedef typename T::elem E;
-    if (g.out_p16) T::store4(reinterpret_cast<E*>(g.out_p16) + fmt_pack_off(row, c, D / 32), y.x, y.y, y.z, y.w);
-    if (g.out_stack) T::store4(reinterpret_cast<E*>(g.out_stack) + fmt_pack_off(row, g.stack_col + c, g.stack_kb), y.x, y.y, y.z, y.w);
+    if (g.out_p16) fh_store4<T>(reinterpret_cast<E*>(g.out_p16) + fmt_pack_off(row, c, D / 32), y.x, y.y, y.z, y.w, rm);
+    if (g.out_stack) fh_store4<T>(reinterpret_cast<E*>(g.out_stack) + fmt_pack_off(row, g.stack_col + c, g.stack_kb), y.x, y.y, y.z, y.w, rm);
   }
+  fh_range_flush<T>(g.sat, rm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -320,9 +331,11 @@ __global__ __launch_bounds__(256) void aud_ln_kernel(AudLnArgs g) {
 //   A fragments are converted from the fp32 residual stream on the fly; W is [pair][tap][96 out][96 in] 16-bit.
 template <class T, int GP /* channels per merged group */>
 __global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restrict__ x, int Tn, int D, const typename T::elem* __restrict__ W,
-                                                          const float* __restrict__ bias, int ktaps, int pad, float* __restrict__ out) {
+                                                          const float* __restrict__ bias, int ktaps, int pad, float* __restrict__ out,
+                                                          unsigned long long* sat) {
   typedef typename T::pack8 P8;
   constexpr int NT = GP / 16, KBN = GP / 32;
+  unsigned rm = 0u;  // range tracker (fh_range_flush)
   __shared__ float red[4][16][GP];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int r16 = lane & 15, q = lane >> 4;
@@ -345,6 +358,7 @@ __global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restric
         const float fv[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) T::set(a, e, fv[e]);
+        fh_track_pack<T>(rm, a);
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -357,6 +371,7 @@ __global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restric
   for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[w][q * 4 + r][j * 16 + r16] = acc[j][r];
+  fh_range_flush<T>(sat, rm);
   __syncthreads();
   for (int idx = threadIdx.x; idx < 16 * GP; idx += 256) {
     const int r = idx / GP, c = idx % GP;
@@ -378,7 +393,7 @@ __global__ __launch_bounds__(256) void aud_posconv_kernel(const float* __restric
 constexpr int kAudKeyTile = 2048;
 template <class T>
 __global__ __launch_bounds__(256) void aud_attn_kernel(const typename T::elem* __restrict__ qkv, int Tn, int D, int heads,
-                                                       typename T::elem* __restrict__ out) {
+                                                       typename T::elem* __restrict__ out, unsigned long long* sat) {
   typedef typename T::elem E;
   constexpr int HD = 64;
   __shared__ float sm[4 * (HD + kAudKeyTile)];  // per wave: q[64] + p[tile]
@@ -435,7 +450,9 @@ __global__ __launch_bounds__(256) void aud_attn_kernel(const typename T::elem* _
     __builtin_amdgcn_wave_barrier();  // the next tile overwrites the score row
     __threadfence_block();
   }
-  out[fmt_pack_off(qi, h * HD + lane, D / 32)] = T::from_float(acc / l);
+  unsigned rm = 0u;
+  out[fmt_pack_off(qi, h * HD + lane, D / 32)] = fh_cvt<T>(acc / l, rm);
+  fh_range_flush<T>(sat, rm);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -445,8 +462,10 @@ __global__ __launch_bounds__(256) void aud_attn_kernel(const typename T::elem* _
 template <class T, int KW>
 __global__ __launch_bounds__(256) void aud_conv0_ln_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                                                            int stride, int L, int C, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, float eps, typename T::elem* __restrict__ out) {
+                                                           const float* __restrict__ beta, float eps, typename T::elem* __restrict__ out,
+                                                           unsigned long long* sat) {
   const int lane = threadIdx.x & 63;
+  unsigned rm = 0u;  // range tracker (fh_range_flush)
   const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (t >= L) return;
   float xv[KW];
@@ -477,16 +496,18 @@ __global__ __launch_bounds__(256) void aud_conv0_ln_kernel(const float* __restri
   for (int i = 0; i < 8; ++i)
     if (i < per) {
       const int c = lane * per + i;
-      out[(size_t)t * C + c] = T::from_float(fh_gelu_erf((y[i] - mu) * rstd * gamma[c] + beta[c]));
+      out[(size_t)t * C + c] = fh_cvt<T>(fh_gelu_erf((y[i] - mu) * rstd * gamma[c] + beta[c]), rm);
     }
+  fh_range_flush<T>(sat, rm);
 }
 
 // Layers 1..n-1: the conv GEMM stores conv + bias (16-bit, row-major); this pass normalises each row over its C channels
 // (affine) and applies GELU in place.  One wave per row.
 template <class T, int NV>
 __global__ __launch_bounds__(256) void aud_rowln_gelu_kernel(typename T::elem* __restrict__ x, int M, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float eps) {
+                                                             const float* __restrict__ beta, float eps, unsigned long long* sat) {
   constexpr int C = NV * 256;
+  unsigned rm = 0u;  // range tracker (fh_range_flush)
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -511,9 +532,10 @@ __global__ __launch_bounds__(256) void aud_rowln_gelu_kernel(typename T::elem* _
     const int c = i * 256 + lane * 4;
     const float4 gm = *reinterpret_cast<const float4*>(gamma + c);
     const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-    T::store4(x + (size_t)row * C + c, fh_gelu_erf((v[i][0] - mu) * rstd * gm.x + bt.x), fh_gelu_erf((v[i][1] - mu) * rstd * gm.y + bt.y),
-              fh_gelu_erf((v[i][2] - mu) * rstd * gm.z + bt.z), fh_gelu_erf((v[i][3] - mu) * rstd * gm.w + bt.w));
+    fh_store4<T>(x + (size_t)row * C + c, fh_gelu_erf((v[i][0] - mu) * rstd * gm.x + bt.x), fh_gelu_erf((v[i][1] - mu) * rstd * gm.y + bt.y),
+                 fh_gelu_erf((v[i][2] - mu) * rstd * gm.z + bt.z), fh_gelu_erf((v[i][3] - mu) * rstd * gm.w + bt.w), rm);
   }
+  fh_range_flush<T>(sat, rm);
 }
 
 // ------------------------------------------------------------------------------------------

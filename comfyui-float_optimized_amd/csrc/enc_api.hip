@@ -42,7 +42,7 @@ struct float_enc {
   std::vector<int> resR, resC;
   void *t1 = nullptr, *tb = nullptr, *tsk = nullptr;
   float *s_r = nullptr, *fcA = nullptr, *fcB = nullptr;
-  unsigned long long* sat = nullptr;  // range counter of the 16-bit conv1 outputs (dec_kernels.hpp; float_enc_saturation)
+  unsigned long long* sat = nullptr;  // range counter of every 16-bit activation store (float_enc_saturation): conv1 of the ResBlocks runs the decoder's kernel (overflow -> inf, counted), the other layers clamp at 65504 and count
 };
 
 namespace {
@@ -224,9 +224,10 @@ int create_impl(float_enc* h, const TensorTable& tt) {
 
 template <class T>
 int launch_conv(const EConv& L, const void* X, int Hi, int Wi, int stride, int pad, void* Y, float* Yf32, const void* skip,
-                hipStream_t st) {
+                hipStream_t st, unsigned long long* sat) {
   EncConvArgs g;
   memset(&g, 0, sizeof(g));
+  g.sat = sat;
   g.X = X;
   g.W = L.W;
   g.Y = Y;
@@ -308,7 +309,7 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
     const int HW = c.size * c.size;
     const size_t tot = (size_t)HW * (h->C0 / 8);
     hipLaunchKernelGGL((enc_first_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, img, h->w0, h->b0,
-                       reinterpret_cast<E*>(h->res[0]), feat_out(0), HW, h->C0);
+                       reinterpret_cast<E*>(h->res[0]), feat_out(0), HW, h->C0, h->sat);
   }
   for (int b = 0; b < nb; ++b) {
     const ResBlk& B = h->blocks[b];
@@ -317,23 +318,23 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
     // skip: Blur pad (1,1) -> 1x1 stride 2, no bias / activation (encoder.py:191)
     {
       const size_t tot = (size_t)(R - 1) * (R - 1) * (C / 8);
-      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, reinterpret_cast<E*>(h->tb), R, C, 1);
+      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, reinterpret_cast<E*>(h->tb), R, C, 1, h->sat);
     }
-    if ((rc = launch_conv<T>(B.skip, h->tb, R - 1, R - 1, 2, 0, h->tsk, nullptr, nullptr, st))) return rc;
+    if ((rc = launch_conv<T>(B.skip, h->tb, R - 1, R - 1, 2, 0, h->tsk, nullptr, nullptr, st, h->sat))) return rc;
     // conv1 3x3 + act; conv2: Blur pad (2,2) -> 3x3 stride 2 + act; (out + skip) / sqrt(2)
     static const bool tiles_on = !getenv("FLOAT_ENC_NO_TILES");
     if (tiles_on && R >= 16 && B.conv1.cin % 32 == 0 && B.conv1.cout % 32 == 0) rc = launch_conv3x3_tiles<T>(h, B.conv1, x, R, h->t1, st);
-    else rc = launch_conv<T>(B.conv1, x, R, R, 1, 1, h->t1, nullptr, nullptr, st);
+    else rc = launch_conv<T>(B.conv1, x, R, R, 1, 1, h->t1, nullptr, nullptr, st, h->sat);
     if (rc) return rc;
     {
       const size_t tot = (size_t)(R + 1) * (R + 1) * (C / 8);
       hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const E*>(h->t1),
-                         reinterpret_cast<E*>(h->tb), R, C, 2);
+                         reinterpret_cast<E*>(h->tb), R, C, 2, h->sat);
     }
-    if ((rc = launch_conv<T>(B.conv2, h->tb, R + 1, R + 1, 2, 0, h->res[b + 1], feat_out(b + 1), h->tsk, st))) return rc;
+    if ((rc = launch_conv<T>(B.conv2, h->tb, R + 1, R + 1, 2, 0, h->res[b + 1], feat_out(b + 1), h->tsk, st, h->sat))) return rc;
   }
   // EqualConv2d(C, dim, 4): 4x4 -> 1x1 = s_r (encoder.py:219, 231)
-  if ((rc = launch_conv<T>(h->last, h->res[nb], 4, 4, 1, 0, nullptr, h->s_r, nullptr, st))) return rc;
+  if ((rc = launch_conv<T>(h->last, h->res[nb], 4, 4, 1, 0, nullptr, h->s_r, nullptr, st, h->sat))) return rc;
   if (s_r && (rc = fh_copy_d2d(s_r, h->s_r, (size_t)c.dim * sizeof(float), st))) return rc;
   // Encoder.fc: EqualLinear chain without activation (encoder.py:242-247, 101-143)
   const float* cur = h->s_r;
@@ -405,6 +406,16 @@ int float_enc_forward(float_enc_t* h, const float* img, float* s_r, float* lam, 
   if (h->cfg.dtype == FLOAT_DT_FP32) return forward_impl<FP32>(h, img, s_r, lam, r_s, feats, n_feats, st);
   return h->cfg.dtype == FLOAT_DT_BF16 ? forward_impl<BF16>(h, img, s_r, lam, r_s, feats, n_feats, st)
                                        : forward_impl<FP16>(h, img, s_r, lam, r_s, feats, n_feats, st);
+}
+
+int float_enc_saturation(float_enc_t* h, uint64_t* total, int32_t reset, void* stream) {
+  FH_REQUIRE(h && total, "null argument to float_enc_saturation");
+  FH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long v = 0;
+  FH_CHECK_HIP(hipMemcpy(&v, h->sat, sizeof(v), hipMemcpyDeviceToHost));
+  *total = v;
+  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(v)));
+  return FLOAT_OK;
 }
 
 int float_enc_feats16(float_enc_t* h, const void** feats16, int32_t* channels, int32_t max_feats, int32_t* n_out) {

@@ -11,7 +11,7 @@
 template <class T>
 __global__ __launch_bounds__(256) void enc_first_kernel(const float* __restrict__ img, const float* __restrict__ w /*[C][3] scaled*/,
                                                         const float* __restrict__ bias, typename T::elem* __restrict__ out,
-                                                        float* __restrict__ out_f32, int HW, int C) {
+                                                        float* __restrict__ out_f32, int HW, int C, unsigned long long* sat) {
   const int c8 = C >> 3;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)HW * c8) return;
@@ -26,6 +26,9 @@ __global__ __launch_bounds__(256) void enc_first_kernel(const float* __restrict_
     T::set(o, i, v);
     if (out_f32) out_f32[(size_t)c * HW + p] = v;
   }
+  unsigned rm = 0u;
+  fh_track_pack<T>(rm, o);
+  fh_range_flush<T>(sat, rm);
   T::store8(out + p * C + cg * 8, o);
 }
 
@@ -34,7 +37,7 @@ __global__ __launch_bounds__(256) void enc_first_kernel(const float* __restrict_
 // correlate with the separable 4x4 FIR / 64; output (R + 2p - 3)^2.  One thread = one pixel x 8 channels.
 template <class T>
 __global__ __launch_bounds__(256) void enc_blur_kernel(const typename T::elem* __restrict__ in, typename T::elem* __restrict__ out,
-                                                       int R, int C, int pad) {
+                                                       int R, int C, int pad, unsigned long long* sat) {
   const int Ro = R + 2 * pad - 3, c8 = C >> 3;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)Ro * Ro * c8) return;
@@ -62,6 +65,9 @@ __global__ __launch_bounds__(256) void enc_blur_kernel(const typename T::elem* _
   typename T::pack8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) T::set(o, i, acc[i]);
+  unsigned rm = 0u;
+  fh_track_pack<T>(rm, o);
+  fh_range_flush<T>(sat, rm);
   T::store8(out + p * C + cg * 8, o);
 }
 
@@ -83,6 +89,7 @@ struct EncConvArgs {
   const float* bias;  // [Cout] or nullptr (with act)
   const void* skip;   // [Ho][Wo][Cout] T::elem or nullptr
   int Hi, Wi, Cin, Cout, Ho, Wo, k, stride, pad, act;
+  unsigned long long* sat;  // range counter of the 16-bit stores (fh_range_flush)
 };
 
 template <class T, int NT>
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs g) {
   }
   if (!mvalid) return;
   const float inv_s2 = 0.70710678118654752f;
+  unsigned rm = 0u;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int co = n0 + j * 16 + q * 4;
@@ -143,12 +151,13 @@ __global__ __launch_bounds__(256) void enc_conv_kernel(EncConvArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = (v[r] + T::to_float(sp[r])) * inv_s2;
     }
-    if (g.Y) T::store4(reinterpret_cast<E*>(g.Y) + (size_t)m * g.Cout + co, v[0], v[1], v[2], v[3]);
+    if (g.Y) fh_store4<T>(reinterpret_cast<E*>(g.Y) + (size_t)m * g.Cout + co, v[0], v[1], v[2], v[3], rm);
     if (g.Yf32) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) g.Yf32[(size_t)(co + r) * npix + m] = v[r];
     }
   }
+  fh_range_flush<T>(g.sat, rm);
 }
 
 // ------------------------------------------------------------------------------------------

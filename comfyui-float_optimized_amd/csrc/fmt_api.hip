@@ -30,6 +30,7 @@ struct float_fmt {
   // workspace
   u16 *cond16, *sc16, *h16, *hfin16, *qkv16, *att16, *hid16, *xin16, *tsin16, *th16;
   float *ccond, *xres, *xcur, *temb, *vout;
+  unsigned long long* sat = nullptr;  // range counter of every 16-bit activation store of the handle's launches (float_fmt_saturation)
   float* slab = nullptr;  // [8][Mpad][D] split-K partial sums (EPI_PARTIAL; the fused attention + proj launch writes one slab per head)
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
   int method = 0;          // FLOAT_ODE_*
@@ -58,6 +59,8 @@ struct float_fmt {
     const float *wr, *wa, *we, *noise;
     float* r_d;
     int T, we_len, nfe, include_r, next, n_chunks, B;
+    int first = 0, total = 0;                                  // first window of the job / windows of the whole clip
+    const float *hist_x = nullptr, *hist_wa = nullptr, *hist_we = nullptr;  // history of window `first` (nullptr: zeros)
     float a, r, e;
     std::vector<float> ts;
     bool active = false;
@@ -498,10 +501,10 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   if (next && (g_fmt_touch & (1 | touch_bit)) && rpw == 1 && !T::is32) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
 #define LN_LAUNCH(NV, KS)                                                                                                          \
   do {                                                                                                                             \
-    if (pf.W && wt) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
-    else if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
-    else if (wt) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm); \
-    else hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm);   \
+    if (pf.W && wt) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm, h->sat); \
+    else if (pf.W) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm, h->sat); \
+    else if (wt) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm, h->sat); \
+    else hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, false, false>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm, h->sat);   \
   } while (0)
 #define LN_CASE(NV)                     \
   case NV:                              \
@@ -544,8 +547,8 @@ void launch_attn(float_fmt* h, int M, const Lin* pull, hipStream_t s) {
   if (pull && !T::is32) pf = make_touch(*pull, M, 0, (grid.x * grid.y / 8) * block.x, 2);
 #define ATTN_LAUNCH(LPQ, TCH)                                                                                                  \
   do {                                                                                                                         \
-    if (M <= kWtRows) hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH, true>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf); \
-    else hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH, false>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf);             \
+    if (M <= kWtRows) hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH, true>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf, h->sat); \
+    else hipLaunchKernelGGL((fmt_attn_kernel<T, LPQ, TCH, false>), grid, block, 0, s, h->qkv16, 3 * D, h->att16, ntok, M, D, c.attn_window, pf, h->sat);             \
   } while (0)
   if (lpq == 16) {
     if (pf.W) ATTN_LAUNCH(16, true);
@@ -572,6 +575,7 @@ int launch_attnproj(float_fmt* h, int M, const Lin& proj, hipStream_t s) {
   const float_fmt_cfg_t& c = h->cfg;
   const int hpw = attnproj_hpw(h);
   GemmArgs g = base_args(nullptr, proj, M);
+  g.sat = h->sat;
   g.out_f32 = h->slab;
   g.ldo = g.N;
   g.slab_stride = (size_t)h->Mpad * g.N;
@@ -610,8 +614,9 @@ int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
   const int D = h->D;
   FH_REQUIRE(n >= 1 && n <= kScSteps, "modulation batch of %d evaluations (max %d)", n, kScSteps);
   hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256, n), dim3(256), 0, s, h->sc16, h->temb + (size_t)e0 * D,
-                     h->ccond, M, D, (size_t)h->Mpad * D);
+                     h->ccond, M, D, (size_t)h->Mpad * D, h->sat);
   GemmArgs g = base_args(h->sc16, h->adaln_all, M);
+  g.sat = h->sat;
   g.out_f32 = h->modall;
   g.ldo = h->Ntot;
   g.zcount = n;
@@ -644,6 +649,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
   // x_embedder + pos_embed; the CFG rows share x, so 60 rows are computed and broadcast
   {
     GemmArgs g = base_args(h->xin16, h->x_embed, nclip * ntok);
+    g.sat = h->sat;
     g.out_f32 = h->xres;
     g.ldo = D;
     g.pos = h->pos;
@@ -659,6 +665,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
     if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, &B.qkv, nullptr, 0, 128))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.qkv, M);
+      g.sat = h->sat;
       g.out16 = h->qkv16;
       g.ldo16 = 3 * D;
       if ((g_fmt_touch & 8) && attnproj_hpw(h)) g.touch = make_touch(B.proj, M, c.heads / attnproj_hpw(h), gemm_lanes_per_xcd(M, g.N, g.K), 2, 8 / attnproj_hpw(h));  // k-slices <-> XCDs as the fused launch decodes them
@@ -672,12 +679,14 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
     } else if (split_ok(g_fmt_proj_split, B.proj)) {
       launch_attn<T>(h, M, nullptr, s);
-      if ((rc = run_gemm_partial<T>(h, base_args(h->att16, B.proj, M), g_fmt_proj_split, s))) return rc;
+      GemmArgs gp = base_args(h->att16, B.proj, M);
+      if ((rc = run_gemm_partial<T>(h, gp, g_fmt_proj_split, s))) return rc;
       pend.ks = g_fmt_proj_split;
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
     } else {
       launch_attn<T>(h, M, (g_fmt_touch & 2) ? &B.proj : nullptr, s);
       GemmArgs g = base_args(h->att16, B.proj, M);
+      g.sat = h->sat;
       g.out_f32 = h->xres;
       g.ldo = D;
       g.gate = mod + 2 * D;
@@ -689,6 +698,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
     if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, &B.fc1, nullptr, 0, 64))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.fc1, M);
+      g.sat = h->sat;
       g.out16 = h->hid16;
       g.ldo16 = B.fc2.K / 32;  // packed for fc2
       if (g_fmt_touch & 4)
@@ -698,6 +708,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
     }
     if (split_ok(g_fmt_fc2_split, B.fc2)) {
       GemmArgs g = base_args(h->hid16, B.fc2, M);
+      g.sat = h->sat;
       if (g_fmt_touch & 32) {
         const unsigned lanes = gemm_lanes_per_xcd(M, g.N * g_fmt_fc2_split, g.K / g_fmt_fc2_split);
         if (b + 1 < c.depth) g.touch = make_touch(h->blk[b + 1].qkv, M, 0, lanes, 2);
@@ -709,6 +720,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.fc2.b, mod + 5 * D};
     } else {
       GemmArgs g = base_args(h->hid16, B.fc2, M);
+      g.sat = h->sat;
       g.out_f32 = h->xres;
       g.ldo = D;
       g.gate = mod + 5 * D;
@@ -726,6 +738,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
     const int nblk = (ntok + 15) / 16, seqs = nclip * bc;
     if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, nullptr, tokblk ? h->hfin16 : nullptr, tokblk ? seqs * 16 : 0))) return rc;
     GemmArgs g = base_args(tokblk ? h->hfin16 : h->h16, h->final_lin, tokblk ? nblk * seqs * 16 : M);
+    g.sat = h->sat;
     g.tokblk = tokblk ? 1 : 0;
     g.nclip = nclip;
     g.bc = bc;
@@ -776,10 +789,12 @@ int prepare_time(float_fmt* h, const TimeSpec& ts, int n, hipStream_t s) {
   hipLaunchKernelGGL((fmt_tsin_kernel<T>), dim3(n), dim3(256), 0, s, h->tsin16, h->freqs, n, ts.t, ts.nfe, ts.stages, ts.c[0],
                      ts.c[1], ts.c[2], ts.c[3]);
   GemmArgs g = base_args(h->tsin16, h->t0, n);
+  g.sat = h->sat;
   g.out16 = h->th16;
   g.ldo16 = h->t2.K / 32;
   if ((rc = launch_gemm<T, EPI_SILU_P16>(g, 4, 1, T::is32 ? 4 : pick_nw(g.K, 0), false, s))) return rc;
   GemmArgs g2 = base_args(h->th16, h->t2, n);
+  g2.sat = h->sat;
   g2.out_f32 = h->temb;
   g2.ldo = h->D;
   if ((rc = launch_gemm<T, EPI_F32>(g2, 4, 1, T::is32 ? 4 : pick_nw(g2.K, 0), false, s))) return rc;
@@ -805,15 +820,16 @@ int stage_window(float_fmt* h, const CfgMode& m, const float* x0, const float* w
   const float_fmt_cfg_t& c = h->cfg;
   const int M = m.nclip * m.bc * h->ntok;
   hipLaunchKernelGGL((fmt_build_cond_kernel<T>), dim3(M), dim3(256), 0, s, h->cond16, h->Kc, m.bc, h->ntok, c.n_prev,
-                     c.dim_w, c.dim_a, c.dim_e, wr, wa, prev_wa, we, we_len, prev_we, m.wr_mask, m.wa_mask, m.we_mask);
+                     c.dim_w, c.dim_a, c.dim_e, wr, wa, prev_wa, we, we_len, prev_we, m.wr_mask, m.wa_mask, m.we_mask, h->sat);
   GemmArgs g = base_args(h->cond16, h->c_embed, M);
+  g.sat = h->sat;
   g.out_f32 = h->ccond;
   g.ldo = h->D;
   int rc;
   if ((rc = run_gemm<T, EPI_F32>(g, s))) return rc;
   const int n = m.nclip * h->ntok * c.dim_w;
   hipLaunchKernelGGL((fmt_init_x_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->xin16, h->Kx / 32, x0, prev_x,
-                     c.n_prev, c.n_cur, c.dim_w, m.nclip);
+                     c.n_prev, c.n_cur, c.dim_w, m.nclip, h->sat);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -886,13 +902,13 @@ int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<
     if (j > 0) {
       hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, j,
                          dt * tb.a[j][0], dt * tb.a[j][1], dt * tb.a[j][2], 0.f, 0, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
-                         c.dim_w, m.nclip);
+                         c.dim_w, m.nclip, h->sat);
     }
     if ((rc = run_blocks<T>(h, m.nclip, m.bc, mod, false, 0.f, a, r, e, s, h->kbuf + (size_t)j * kstride))) return rc;
     if (j == tb.s - 1) {
       hipLaunchKernelGGL((fmt_rk_combine_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->xcur, h->kbuf, kstride, tb.s,
                          dt * tb.b[0], dt * tb.b[1], dt * tb.b[2], dt * tb.b[3], 1, h->xin16, h->Kx / 32, c.n_prev, c.n_cur,
-                         c.dim_w, m.nclip);
+                         c.dim_w, m.nclip, h->sat);
     }
   }
   FH_CHECK_HIP(hipGetLastError());
@@ -1005,12 +1021,19 @@ int sample_window(float_fmt* h, int k, hipStream_t s) {
   const bool dynamic = J.we_len > 1;
   int rc;
   auto blocks = [](int n) { return dim3((n + 255) / 256); };
-  if (k == 0) {
+  if (k == J.first) {
     if ((rc = prepare_time<T>(h, time_spec(h->method, J.nfe), std::max(1, n_evals(h->method, J.nfe)), s))) return rc;
-    // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593)
-    if ((rc = dev_zero(h->prev_x, (size_t)B * P * c.dim_w, s))) return rc;
-    if ((rc = dev_zero(h->prev_wa, (size_t)B * P * c.dim_a, s))) return rc;
-    if ((rc = dev_zero(h->prev_we, (size_t)B * P * c.dim_e, s))) return rc;
+    // chunk 0 starts from zero history (FLOAT.py:217-219, nodes_adv.py:591-593); a job that starts at a later window
+    // (float_fmt_sample_begin_range) from the history its caller hands over, or from zeros too
+    if (J.hist_x) rc = dev_copy(h->prev_x, J.hist_x, (size_t)B * P * c.dim_w, s);
+    else rc = dev_zero(h->prev_x, (size_t)B * P * c.dim_w, s);
+    if (rc) return rc;
+    if (J.hist_wa) rc = dev_copy(h->prev_wa, J.hist_wa, (size_t)B * P * c.dim_a, s);
+    else rc = dev_zero(h->prev_wa, (size_t)B * P * c.dim_a, s);
+    if (rc) return rc;
+    if (J.hist_we) rc = dev_copy(h->prev_we, J.hist_we, (size_t)B * P * c.dim_e, s);
+    else rc = dev_zero(h->prev_we, (size_t)B * P * c.dim_e, s);
+    if (rc) return rc;
   } else if (P > 0) {
     // AR hand-off: last P frames of the previous final sample / (padded) wa window / we window, per clip
     hipLaunchKernelGGL(fmt_tail_kernel, blocks(B * P * c.dim_w), dim3(256), 0, s, h->prev_x, h->xcur, P, L, c.dim_w, B);
@@ -1024,7 +1047,7 @@ int sample_window(float_fmt* h, int k, hipStream_t s) {
   rc = window_impl<T>(h, h->x0_c, h->wa_c, J.wr, dynamic ? h->we_c : J.we, dynamic ? L : 1, h->prev_x, h->prev_wa,
                       dynamic ? h->prev_we : nullptr, J.nfe, J.ts, J.a, J.r, J.e, J.include_r, s, B);
   if (rc) return rc;
-  const int rows = (k == J.n_chunks - 1) ? (Tn - k * L) : L;  // trim to T (FLOAT.py:252)
+  const int rows = (k == J.total - 1) ? (Tn - k * L) : L;  // trim to T (FLOAT.py:252)
   return dev_copy2d(J.r_d + (size_t)k * L * c.dim_w, (size_t)Tn * c.dim_w, h->xcur, (size_t)L * c.dim_w, rows * c.dim_w, B, s);
 }
 
@@ -1207,6 +1230,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   A(&h->kbuf, (size_t)4 * h->Bmax * kMaxTok * cfg->dim_w);
   A(&h->xres, (size_t)Mp * D);
   A(&h->slab, (size_t)8 * Mp * D);
+  A(&h->sat, 1);
   A(&h->xcur, (size_t)h->Bmax * cfg->n_cur * cfg->dim_w);
   A(&h->temb, (size_t)kMaxSteps * D);
   A(&h->vout, (size_t)h->Bmax * kMaxTok * cfg->dim_w);
@@ -1313,6 +1337,16 @@ int float_fmt_debug(float_fmt_t* h, int32_t what, const float* in, float* out, v
                                          : debug_impl<FP32>(h, what, in, out, (hipStream_t)stream);
 }
 
+int float_fmt_saturation(float_fmt_t* h, uint64_t* total, int32_t reset, void* stream) {
+  FH_REQUIRE(h && total, "null argument to float_fmt_saturation");
+  FH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  unsigned long long v = 0;
+  FH_CHECK_HIP(hipMemcpy(&v, h->sat, sizeof(v), hipMemcpyDeviceToHost));
+  *total = v;
+  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(v)));
+  return FLOAT_OK;
+}
+
 int float_fmt_set_method(float_fmt_t* h, int32_t method) {
   FH_REQUIRE(h != nullptr, "null FMT handle");
   FH_REQUIRE(method >= FLOAT_ODE_EULER && method <= FLOAT_ODE_HEUN3, "unknown ODE method %d", method);
@@ -1346,7 +1380,31 @@ int float_fmt_sample_begin(float_fmt_t* h, const float* wr, const float* wa, int
   J.B = 1;
   J.next = 0;
   J.n_chunks = (T + h->cfg.n_cur - 1) / h->cfg.n_cur;
+  J.first = 0;
+  J.total = J.n_chunks;
+  J.hist_x = J.hist_wa = J.hist_we = nullptr;
   linspace01(nfe, &J.ts);
+  J.active = true;
+  return FLOAT_OK;
+}
+
+int float_fmt_sample_begin_range(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we, int32_t we_len,
+                                 const float* noise, int32_t nfe, float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg,
+                                 float* r_d, int32_t first_window, int32_t end_window, const float* hist_x, const float* hist_wa,
+                                 const float* hist_we) {
+  int rc = float_fmt_sample_begin(h, wr, wa, T, we, we_len, noise, nfe, a_cfg, r_cfg, e_cfg, include_r_cfg, r_d);
+  if (rc) return rc;
+  auto& J = h->job;
+  J.active = false;
+  FH_REQUIRE(first_window >= 0 && first_window < end_window && end_window <= J.total,
+             "window range [%d, %d) outside the clip's %d windows", first_window, end_window, J.total);
+  FH_REQUIRE(we_len == 1 || hist_we != nullptr || hist_x == nullptr,
+             "a dynamic-emotion job that starts from a history needs hist_we too");
+  J.first = J.next = first_window;
+  J.n_chunks = end_window;
+  J.hist_x = hist_x;
+  J.hist_wa = hist_wa;
+  J.hist_we = we_len > 1 ? hist_we : nullptr;
   J.active = true;
   return FLOAT_OK;
 }

@@ -80,7 +80,8 @@ class SynthesisHIP:
         return self._run(native.lib().float_dec_frames, s_r, r_d, (self.size, self.size, 3))
 
     def saturation(self, reset=False, per_site=False):
-        """Activations the fp16 operator had to clamp at +-65504 since create / the last reset (float_dec_saturation):
+        """(thread, tile) groups of 16-bit activation stores that held an inf / NaN since create / the last reset
+        (float_dec_saturation; the decoder stores an out-of-range value as inf - loud - instead of clamping it):
         0 unless the checkpoint leaves fp16's range - then the frames are not the reference's and dtype="fp32" is the
         way to run it.  per_site: also the 40 per-layer counters.  Synchronises the current stream."""
         tot = C.c_uint64(0)

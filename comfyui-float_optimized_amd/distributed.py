@@ -49,6 +49,8 @@ def sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg,
     B = wa.shape[0]
     dev, dt = wa.device, wa.dtype
     dynamic = we.shape[1] > 1
+    if hasattr(fmt, "_h") and B == 1 and P > 0:
+        return _sample_range_native(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, hist)
     if hist is None:
         hist = (torch.zeros(B, P, cfg.dim_w, device=dev, dtype=dt), torch.zeros(B, P, cfg.dim_a, device=dev, dtype=dt),
                 torch.zeros(B, P, cfg.dim_e, device=dev, dtype=dt))
@@ -67,8 +69,32 @@ def sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg,
     return torch.cat(out, dim=1), (prev_x, prev_wa, prev_we)
 
 
+def _sample_range_native(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, hist):
+    """sample_range on the HIP operator's own window loop (float_fmt_sample_begin_range / _next): every window is one
+    hipGraph replay with the hand-off done on the device, instead of one sample_chunk call with host-side slicing per window.
+    Returns the range's rows of r_d trimmed to the clip (the last window of the clip has T - k L rows) and the tail."""
+    from .fmt import WindowSampler
+    L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
+    T = wa.shape[1]
+    dynamic = we.shape[1] > 1
+    ws = WindowSampler(fmt, r_s, wa, we, noise, nfe, a_cfg, r_cfg, e_cfg, windows=(w0, w1), hist=hist)
+    while ws.left > 0:
+        ws.next()
+    t0, t1 = w0 * L, min(T, w1 * L)
+    xs = ws.r_d[:, t0:t1]
+    fmt._last_job = ws  # keeps the job's tensors alive until the stream has run it
+    if w1 * L <= T:
+        prev_x = xs[:, -P:]
+    else:  # the clip's last, trimmed window: nobody samples after it
+        prev_x = torch.zeros(1, P, cfg.dim_w, device=xs.device, dtype=xs.dtype)
+    k = w1 - 1
+    prev_wa = _pad_rep(wa[:, k * L:(k + 1) * L], L)[:, -P:].to(xs.device, xs.dtype)
+    prev_we = (_pad_rep(we[:, k * L:(k + 1) * L], L)[:, -P:] if dynamic else torch.zeros(1, P, cfg.dim_e)).to(xs.device, xs.dtype)
+    return xs, (prev_x, prev_wa, prev_we)
+
+
 def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1.0, e_cfg=1.0, iters=1, group=None,
-                           resolve_chunks=0):
+                           resolve_chunks=0, exchange_at_world_1=False):
     """Window-parallel sampling of one clip.  Every rank passes the FULL wa/we/noise (they are tiny);
     returns (r_d_local, (t0, t1), report).
 
@@ -84,7 +110,9 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
       seam_next_rel_change  the error metric of the seam re-solve: rel-L2 change, in the last round, of the hand-off frames
                             (last num_prev_frames frames) of the last re-solved window - the history the NEXT, not re-solved
                             window was computed from.  0 means the rest of the rank's range is what a full re-solve would give;
-      windows_solved        windows this rank solved in total (the cost)."""
+      windows_solved        windows this rank solved in total (the cost).
+    exchange_at_world_1: run the all_gather rounds even in a one-rank group (nothing is re-solved: rank 0 has no predecessor) -
+    how a single-GPU box exercises the collective on the backend that N > 1 will use."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
@@ -96,7 +124,12 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
     seam = torch.zeros((), device=xs.device, dtype=torch.float32)  # stays on the device: no host sync per round
     seam_next = torch.zeros((), device=xs.device, dtype=torch.float32)
     k = (w1 - w0) if resolve_chunks <= 0 else min(int(resolve_chunks), w1 - w0)
-    for _ in range(iters if world > 1 else 0):
+    if resolve_chunks > 0 and iters > 1:
+        # a partial re-solve never changes a rank's own tail (its LAST window), so every later round would gather the same
+        # boundaries and re-solve the same windows to the same result: wasted work and a seam change of 0 that reads as
+        # converged.  Only the whole-range re-solve (resolve_chunks = 0) iterates.
+        raise ValueError("iters > 1 needs resolve_chunks = 0 (a seam re-solve of %d window(s) is a single round)" % resolve_chunks)
+    for _ in range(iters if (world > 1 or (exchange_at_world_1 and dist.is_initialized())) else 0):
         # boundary latents of every rank: [x tail | wa tail | we tail] flattened, one all_gather
         mine = torch.cat([t.reshape(t.shape[0], -1) for t in tail], dim=1).contiguous()
         gathered = [torch.empty_like(mine) for _ in range(world)]
@@ -121,9 +154,9 @@ def sample_window_parallel(fmt, cfg, r_s, wa, we, noise, nfe, a_cfg=2.0, r_cfg=1
                                        "rounds": iters, "resolve_chunks": k, "windows_solved": solved}
 
 
-def broadcast_latents(r_d, src=0, group=None):
+def broadcast_latents(r_d, src=0, group=None, at_world_1=False):
     """Exact mode, variant 2: rank `src` sampled the chain, everybody else receives r_d (B,T,512)."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or at_world_1):
         dist.broadcast(r_d, src=src, group=group)
     return r_d
 

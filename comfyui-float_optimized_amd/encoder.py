@@ -33,6 +33,13 @@ class EncoderHIP:
         self._h = h
         del keep
 
+    def saturation(self, reset=False):
+        """Threads with a clamped (+-65504) or non-finite 16-bit activation store since create / the last reset
+        (float_enc_saturation): 0 unless the checkpoint leaves fp16's range - then the result is not the reference's within the
+        stated tolerance; run it with dtype="fp32".  Always 0 for bf16 / fp32 handles.  Synchronises the current stream."""
+        with torch.cuda.device(self.device):
+            return native.saturation("float_enc_saturation", self._h, self.device, reset)
+
     def close(self):
         if getattr(self, "_h", None) and native is not None:
             native.lib().float_enc_destroy(self._h)

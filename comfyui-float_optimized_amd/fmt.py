@@ -64,6 +64,13 @@ class FlowMatchingTransformerHIP:
                                                       native.stream_ptr(self.device)))
         return out
 
+    def saturation(self, reset=False):
+        """Threads with a clamped (+-65504) or non-finite 16-bit activation store since create / the last reset
+        (float_fmt_saturation): 0 unless the checkpoint leaves fp16's range - then the result is not the reference's within the
+        stated tolerance; run it with dtype="fp32" (or "bf16").  Always 0 for bf16 / fp32 handles.  Synchronises the current stream."""
+        with torch.cuda.device(self.device):
+            return native.saturation("float_fmt_saturation", self._h, self.device, reset)
+
     def close(self):
         if getattr(self, "_h", None) and native is not None:  # `native` is None during interpreter shutdown
             native.lib().float_fmt_destroy(self._h)
@@ -172,7 +179,11 @@ class WindowSampler:
     one 50-frame window on the current stream, so the caller can decode window k on another stream
     while window k+1 is being sampled."""
 
-    def __init__(self, fmt, r_s, wa, we, noise, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg=False):
+    def __init__(self, fmt, r_s, wa, we, noise, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg=False,
+                 windows=None, hist=None, r_d=None):
+        """windows=(w0, w1): only that window range of the clip, starting from hist = (prev_x, prev_wa, prev_we) (each
+        (1, n_prev, dim) or None = zeros) - float_fmt_sample_begin_range, the multi-GPU window shard.  r_d: a (1, T, dim_w)
+        device tensor to write into (else a new one; rows outside the job's windows are left as they are)."""
         self.fmt = fmt
         c = fmt.cfg
         f = fmt._f
@@ -180,13 +191,20 @@ class WindowSampler:
         self.T = self.wa.shape[0]
         self.n_chunks = int(math.ceil(self.T / c.num_frames_for_clip))
         self.noise = f(noise).reshape(self.n_chunks, c.num_frames_for_clip, c.dim_w)
-        self.r_d = torch.empty(1, self.T, c.dim_w, device=fmt.device, dtype=torch.float32)
-        self.left = self.n_chunks
-        with torch.cuda.device(fmt.device):
-            native.check(native.lib().float_fmt_sample_begin(
-                fmt._h, native.dev_ptr(self.r_s), native.dev_ptr(self.wa), self.T, native.dev_ptr(self.we),
+        self.r_d = torch.empty(1, self.T, c.dim_w, device=fmt.device, dtype=torch.float32) if r_d is None else r_d
+        w0, w1 = windows if windows is not None else (0, self.n_chunks)
+        self.left = w1 - w0
+        args = (fmt._h, native.dev_ptr(self.r_s), native.dev_ptr(self.wa), self.T, native.dev_ptr(self.we),
                 self.we.shape[0], native.dev_ptr(self.noise), int(nfe), a_cfg_scale, r_cfg_scale, e_cfg_scale,
-                1 if include_r_cfg else 0, native.dev_ptr(self.r_d)))
+                1 if include_r_cfg else 0, native.dev_ptr(self.r_d))
+        with torch.cuda.device(fmt.device):
+            if windows is None and hist is None:
+                native.check(native.lib().float_fmt_sample_begin(*args))
+            else:
+                # the history tensors must stay alive until the first next() has run on the stream
+                self._hist = [None if t is None else f(t).reshape(c.num_prev_frames, -1) for t in (hist or (None, None, None))]
+                native.check(native.lib().float_fmt_sample_begin_range(
+                    *args, int(w0), int(w1), *[native.dev_ptr(t) if t is not None else None for t in self._hist]))
 
     def next(self):
         """Enqueue the next window on the current stream; returns (window index, frame range)."""

@@ -43,9 +43,18 @@ def resample_sinc(w, orig_rate, new_rate, zeros=24, rolloff=0.945):
         # the nearest multiple of 50 Hz by a linear-interpolation pre-pass (error band far above the wav2vec2 band's needs:
         # a ratio change of <= 0.06 %), then run the polyphase filter at the friendly ratio
         snapped = max(50, int(round(orig_rate / 50.0)) * 50)
-        n_mid = max(1, int(round(w.shape[-1] * snapped / float(orig_rate))))
-        w = F.interpolate(w[None, None].double(), size=n_mid, mode="linear", align_corners=False)[0, 0].to(w.dtype)
-        return resample_sinc(w, snapped, new_rate, zeros, rolloff)
+        if snapped != orig_rate:
+            n_mid = max(1, int(round(w.shape[-1] * snapped / float(orig_rate))))
+            w = F.interpolate(w[None, None].double(), size=n_mid, mode="linear", align_corners=False)[0, 0].to(w.dtype)
+            return resample_sinc(w, snapped, new_rate, zeros, rolloff)
+        # the SOURCE rate is friendly already, the TARGET is not (44100 -> 16001): filter to the nearest multiple of 50 Hz of
+        # the target, then a linear-interpolation post-pass of <= 0.16 % (the signal is band-limited below it by then)
+        tgt = max(50, int(round(new_rate / 50.0)) * 50)
+        if tgt == new_rate:
+            raise ValueError("cannot build a polyphase resampler for %d -> %d Hz" % (orig_rate, new_rate))
+        y = resample_sinc(w, orig_rate, tgt, zeros, rolloff)
+        n_out = max(1, int(math.ceil(w.shape[-1] * new_rate / float(orig_rate))))
+        return F.interpolate(y[None, None].double(), size=n_out, mode="linear", align_corners=False)[0, 0].to(w.dtype)
     base = min(up, down) * rolloff          # cut-off in units of the common rate's Nyquist / max(up, down)
     width = int(math.ceil(zeros * down / base))
     # kernel[phase p of `up`, tap k]: output sample n * up + p reads input samples around n * down + p * down / up

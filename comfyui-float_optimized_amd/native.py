@@ -13,6 +13,7 @@ ODE_METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "heun2": 3, "heun3": 4}
 DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16,
           "fp32": FLOAT_DT_FP32, "float32": FLOAT_DT_FP32}  # fp32: the verification mode of the FMT and decoder operators
 DEC_SAT_SITES = 40
+ABI_VERSION = 4
 
 
 class NativeLibraryError(RuntimeError):
@@ -71,6 +72,9 @@ _SIGNATURES = {
     "float_fmt_sample_begin": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                          C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p]),
     "float_fmt_sample_next": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "float_fmt_sample_begin_range": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                               C.c_int32] + [C.c_float] * 3 + [C.c_int32, C.c_void_p, C.c_int32, C.c_int32] +
+                                     [C.c_void_p] * 3),
     "float_dec_create": (C.c_int, [C.POINTER(DecCfg), C.POINTER(FloatTensor), C.c_int32, C.POINTER(C.c_void_p)]),
     "float_dec_destroy": (None, [C.c_void_p]),
     "float_dec_set_feats": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
@@ -94,6 +98,9 @@ _SIGNATURES = {
     "float_aud_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_aud_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_enc_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
+    "float_fmt_saturation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p]),
+    "float_enc_saturation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p]),
+    "float_aud_saturation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p]),
 }
 EXPORTS = tuple(_SIGNATURES)
 
@@ -120,7 +127,7 @@ def lib():
             raise NativeLibraryError("libfloat_hip.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if L.float_hip_abi_version() != 3:
+    if L.float_hip_abi_version() != ABI_VERSION:
         raise NativeLibraryError("libfloat_hip.so ABI version mismatch")
     _lib = L
     return L
@@ -171,6 +178,14 @@ def cu_range_stream(cu_begin, cu_end, device=None):
     p = C.c_void_p()
     check(lib().float_stream_create_cu_range(int(cu_begin), int(cu_end), C.byref(p)))
     return torch.cuda.ExternalStream(p.value, device=device)
+
+
+def saturation(fn_name, handle, device=None, reset=False):
+    """float_{fmt,enc,aud}_saturation of a handle: threads with a clamped / non-finite 16-bit activation store since the
+    handle was created (or last reset).  Synchronises the current stream."""
+    tot = C.c_uint64(0)
+    check(getattr(lib(), fn_name)(handle, C.byref(tot), 1 if reset else 0, stream_ptr(device)))
+    return int(tot.value)
 
 
 def set_profiling(on):

@@ -1,7 +1,10 @@
 """The hot path as one object: (conditioning tensors in HBM) -> r_d -> frames.
 Mirrors FLOAT.sample + decode_latent_into_processed_images (reference FLOAT.py:172-253, 113-169)
 with the noise stream explicit."""
+import logging
 import math
+import os
+import warnings
 
 import torch
 
@@ -11,17 +14,65 @@ from .decoder import SynthesisHIP
 from .fmt import FlowMatchingTransformerHIP, WindowSampler, draw_noise
 
 
+class Fp16RangeError(OverflowError):
+    """A 16-bit operator clamped (or stored inf for) activations beyond fp16's range: the result is not the reference's."""
+
+
+def report_range(counts, where, mode=None):
+    """counts: {operator name: float_*_saturation total}.  Any non-zero entry means a checkpoint / input left fp16's range in
+    that operator (the frames may hold wrong or black regions).  FLOAT_AMD_RANGE = warn (default: RuntimeWarning + log) |
+    raise (Fp16RangeError) | off."""
+    bad = {k: v for k, v in counts.items() if v}
+    mode = (mode or os.environ.get("FLOAT_AMD_RANGE", "warn")).lower()
+    if not bad or mode == "off":
+        return bad
+    msg = ("%s: fp16 range exceeded in %s - the frames are NOT the reference's within the stated tolerance (they may show wrong "
+           "or black regions). Run this checkpoint with dtype fp32 (decoder / encoder) or bf16 / fp32 (FMT / audio)."
+           % (where, ", ".join("%s (%d stores)" % kv for kv in sorted(bad.items()))))
+    if mode == "raise":
+        raise Fp16RangeError(msg)
+    logging.getLogger("float_amd").error(msg)
+    warnings.warn(msg, RuntimeWarning, stacklevel=3)
+    return bad
+
+
 class FloatHotPath:
     def __init__(self, fmt_state, dec_state, cfg: FmtConfig = None, device="cuda:0", size=512, fmt_dtype="fp16",
                  dec_dtype="fp16", max_frames=32, use_graph=2, max_batch=1):
         self.cfg = cfg or FmtConfig()
         self.device = torch.device(device)
         self.size = size
+        self._fmt_state, self._use_graph = fmt_state, use_graph
         self.fmt = FlowMatchingTransformerHIP(fmt_state, self.cfg, device, fmt_dtype, use_graph, max_batch)
         self.dec = SynthesisHIP(dec_state, size, self.cfg.dim_w, device, dec_dtype, max_frames)
 
     def n_chunks(self, T):
         return int(math.ceil(T / self.cfg.num_frames_for_clip))
+
+    def batched_fmt(self, n_clips):
+        """An FMT handle whose workspace holds `n_clips` stacked clips (float_fmt_sample_batch), built on first use from the
+        same weights and cached: the default handle is sized for ONE clip (3.1 GB of workspace per clip).  Up to
+        FLOAT_AMD_FMT_MAX_BATCH (default 4) clips per chain; larger batches run in chunks of that size."""
+        cap = max(1, min(16, int(os.environ.get("FLOAT_AMD_FMT_MAX_BATCH", "4"))))
+        mb = min(cap, max(1, int(n_clips)))
+        if mb <= self.fmt.max_batch:
+            return self.fmt
+        cache = self.__dict__.setdefault("_fmt_batched", {})
+        if mb not in cache:
+            for k in list(cache):
+                cache.pop(k).close()
+            cache[mb] = FlowMatchingTransformerHIP(self._fmt_state, self.cfg, self.device, self.fmt.dtype, self._use_graph, mb)
+            cache[mb].set_method(getattr(self.fmt, "method", "euler"))
+        return cache[mb]
+
+    def range_counts(self, reset=True):
+        """{operator: float_*_saturation total} of this object's 16-bit handles (synchronises the current stream)."""
+        out = {}
+        if self.fmt.dtype == "fp16":
+            out["fmt"] = self.fmt.saturation(reset) + sum(f.saturation(reset) for f in self.__dict__.get("_fmt_batched", {}).values())
+        if self.dec.dtype == "fp16":
+            out["decoder"] = self.dec.saturation(reset)
+        return out
 
     @torch.no_grad()
     def sample(self, r_s, wa, we, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, seed=15, noise=None,
@@ -64,9 +115,18 @@ class FloatHotPath:
         if frame_range is not None:
             rd = rd[frame_range[0]:frame_range[1]]
         n = rd.shape[0]
+        # The copy workgroups / hipMemcpyAsync of the PREVIOUS call may still be writing its host tensor, and torch's caching
+        # host allocator knows nothing about writes it did not issue: this object keeps a reference to that tensor until its
+        # event has completed, so the block cannot be handed out again (e.g. as `out` below) while the GPU stores into it.
+        prev = self.__dict__.pop("_host_inflight", None)
+        if prev is not None:
+            prev[1].synchronize()
         if out is None:
             out = torch.empty((n, self.size, self.size, 3), dtype=torch.float32, pin_memory=True)
         self.dec.decode_into_host(s_r, rd, out, self.staging(n))
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._host_inflight = (out, ev)
         return out
 
     @torch.no_grad()

@@ -1,5 +1,6 @@
 """InferenceAgent of the MI355X build (reference generate.py:84-173): owns the weights, the host-side
 conditioning encoders and the HIP hot path, and exposes run_inference with the reference signature."""
+import contextlib
 import math
 import os
 
@@ -9,7 +10,7 @@ from ... import host_models, weights
 from ...audio import Audio2EmotionHIP, AudioEncoderHIP
 from ...config import AudioConfig, FmtConfig, emotion_audio_config, small_audio_config, small_emotion_config
 from ...encoder import EncoderHIP
-from ...pipeline import FloatHotPath
+from ...pipeline import FloatHotPath, report_range
 from . import SYNTHETIC_MODEL, main_logger
 
 # key prefixes of the unified checkpoint (utils/downloader.py:35-42)
@@ -42,13 +43,27 @@ class InferenceAgent:
         if parts is None:
             parts = self._load_parts(opt)
         self.dec_sd = parts["dec"]
+        # the host copy of the weights stays with the agent (the reference's offload device, nodes.py:139): offload() frees
+        # every device allocation, to_target() rebuilds the operators from here
+        self._parts = parts
+        self._build = dict(max_frames=max_frames, use_graph=use_graph,
+                           fmt_dtype=fmt_dtype or os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
+                           dec_dtype=dec_dtype or os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"),
+                           aud_dtype=aud_dtype or os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16"))
+        self.G = None
+        self.to_target()
+
+    # ------------------------------------------------------------------ residency (reference: model_to_target, nodes.py:173-175)
+    def to_target(self):
+        """Build the HIP operators on self.rank from the host weights if they are not resident (no-op otherwise)."""
+        if self.G is not None:
+            return self
+        opt, parts, b = self.opt, self._parts, self._build
         # 16-bit MFMA operand types (fp32 accumulation): fp16 in both operators gives ~8x lower rounding error than
         # bf16 at the same rate (end-to-end 48.7 vs 34.1 dB on BASELINE configs[0]); FLOAT_AMD_FMT_DTYPE=bf16
         # selects the type BASELINE configs[1] names.
-        self.G = FloatHotPath(parts["fmt"], parts["dec"], self.cfg, self.rank, opt.input_size,
-                              fmt_dtype=fmt_dtype or os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
-                              dec_dtype=dec_dtype or os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"), max_frames=max_frames,
-                              use_graph=use_graph)
+        self.G = FloatHotPath(parts["fmt"], parts["dec"], self.cfg, self.rank, opt.input_size, fmt_dtype=b["fmt_dtype"],
+                              dec_dtype=b["dec_dtype"], max_frames=b["max_frames"], use_graph=b["use_graph"])
         self.G.fmt.set_method(getattr(opt, "torchdiffeq_ode_method", "euler"))
         # appearance encoder + Encoder.fc + Direction as one HIP operator (float_enc_*); same 16-bit type as the
         # decoder so the skip features go to it without an fp32 round trip
@@ -56,13 +71,48 @@ class InferenceAgent:
                               dtype=self.G.dec.dtype, direction_weight=parts["dec"]["direction.weight"])
         # wav2vec2 + audio projection as one HIP operator (float_aud_*)
         aud_sd, aud_cfg = parts["audio_encoder"]
-        aud_dtype = aud_dtype or os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16")
-        self.audio_encoder = AudioEncoderHIP(aud_sd, aud_cfg, self.rank, dtype=aud_dtype, sampling_rate=opt.sampling_rate, fps=opt.fps)
+        self.audio_encoder = AudioEncoderHIP(aud_sd, aud_cfg, self.rank, dtype=b["aud_dtype"], sampling_rate=opt.sampling_rate, fps=opt.fps)
         # speech-to-emotion (emotion="none"): the wav2vec2-large variant of the same operator with its classification head
         ser = parts.get("emotion_encoder")
-        self.emotion_encoder = Audio2EmotionHIP(ser[0], ser[1], self.rank, dtype=aud_dtype) if ser is not None else None
+        self.emotion_encoder = Audio2EmotionHIP(ser[0], ser[1], self.rank, dtype=b["aud_dtype"]) if ser is not None else None
         # callable(a) -> (1,7) softmax scores; None disables emotion="none"
         self.emotion_predictor = self.emotion_encoder.predict_emotion if ser is not None else parts.get("emotion_predictor")
+        return self
+
+    def offload(self):
+        """Free every device allocation of the agent (packed weights, workspaces, hipGraphs, staging and cached tensors:
+        ~6.5 GB at the default shapes) - the counterpart of the reference moving G back to the offload device after a node
+        call.  The next call rebuilds the operators from the host weights (to_target); results are bitwise the same."""
+        if self.G is None:
+            return
+        torch.cuda.current_stream(self.rank).synchronize()
+        for op in [self.G.fmt, self.G.dec, self.enc, self.audio_encoder, self.emotion_encoder] + list(self.G.__dict__.get("_fmt_batched", {}).values()):
+            if op is not None:
+                op.close()
+        if self.emotion_encoder is not None:
+            self.emotion_predictor = None
+        self.G = self.enc = self.audio_encoder = self.emotion_encoder = None
+        self.__dict__.pop("_we_cache", None)
+        self.__dict__.pop("_noise_pin", None)
+        with torch.cuda.device(self.rank):
+            torch.cuda.empty_cache()
+
+    @property
+    def resident(self):
+        return self.G is not None
+
+    @contextlib.contextmanager
+    def model_to_target(self, offload_after=None):
+        """The reference wraps every node call in `with model_to_target(logger, float_pipe.G)` (nodes.py:173-175): operators
+        on the target device inside, back on the offload device after.  Here staying resident is the default (288 GB of
+        HBM; a rebuild costs seconds of host packing): offload_after=True, or FLOAT_AMD_OFFLOAD=always, gives the reference's
+        behaviour; FLOAT_AMD_OFFLOAD=never (default) keeps the operators."""
+        self.to_target()
+        try:
+            yield self
+        finally:
+            if offload_after if offload_after is not None else os.environ.get("FLOAT_AMD_OFFLOAD", "never").lower() == "always":
+                self.offload()
 
     # ------------------------------------------------------------------ weights
     @staticmethod
@@ -157,13 +207,63 @@ class InferenceAgent:
         """Portrait and waveform in HBM -> (T,H,W,3) fp32 frames in [0,1] in pinned host memory: every operator of the path and
         the hand-over (frames of decode batch i leave inside the launches of batch i+1, float_dec_frames_host).  bench.py
         times exactly this call.  Like the reference, the grid size comes from opt.nfe (FLOAT.py:188)."""
+        self.to_target()  # no-op while resident
         c = self.conditions_device(s, a, emo)  # encoder kernels enqueued; nothing below waits for them on the host
         n_chunks = int(math.ceil(c["T"] / self.cfg.num_frames_for_clip))
         noise = self._noise_to_device(n_chunks, seed if seed is not None else self.opt.seed)
         host = self.G.generate_to_host(c["r_s"], c["wa"], c["we"], c["s_r"], None, self.opt.nfe, a_cfg_scale, r_cfg_scale,
                                        e_cfg_scale, noise=noise, out=out)
         torch.cuda.current_stream(self.rank).synchronize()  # the frames are in host memory
+        self.check_range("InferenceAgent.infer_device")
         return host
+
+    def range_counts(self, reset=True):
+        """{operator: clamped / non-finite 16-bit stores since the last call} over every fp16 handle of the agent."""
+        if self.G is None:
+            return {}
+        counts = self.G.range_counts(reset)
+        for name, op in (("encoder", self.enc), ("audio", self.audio_encoder), ("speech_emotion", self.emotion_encoder)):
+            if op is not None and op.dtype == "fp16":
+                counts[name] = op.saturation(reset)
+        return counts
+
+    def check_range(self, where):
+        """Once per clip, after the frames have arrived: an fp16 operator that left its range does not go unnoticed (a
+        RuntimeWarning + log line; FLOAT_AMD_RANGE=raise makes it an error, =off skips the four 8-byte reads)."""
+        if os.environ.get("FLOAT_AMD_RANGE", "warn").lower() == "off":
+            return {}
+        return report_range(self.range_counts(), where)
+
+    @torch.no_grad()
+    def infer_device_batch(self, items, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, emo="S2E", seeds=None):
+        """B clips of EQUAL length through one stacked FMT chain (float_fmt_sample_batch: every weight is read once per
+        evaluation for all of them), then decoded one after the other.  items: [(s (1,3,H,W), a (N,))] in HBM; seeds: one per
+        item (FloatProcess uses seed + i, nodes.py:189-209) - each item keeps its own noise stream, so item i is what
+        infer_device gives for it alone (bit for bit where the GEMM tilings coincide, within the fp16 tolerance otherwise).
+        Returns a list of (T,H,W,3) pinned host tensors."""
+        self.to_target()
+        B = len(items)
+        seeds = list(seeds) if seeds is not None else [self.opt.seed] * B
+        conds = [self.conditions_device(s, a, emo) for s, a in items]
+        T = conds[0]["T"]
+        if any(c["T"] != T for c in conds):
+            raise ValueError("infer_device_batch needs clips of equal length")
+        n_chunks = int(math.ceil(T / self.cfg.num_frames_for_clip))
+        from ...fmt import draw_noise
+        noise = torch.cat([draw_noise(n_chunks, 1, self.cfg, sd) for sd in seeds], dim=1).to(self.rank, non_blocking=True)
+        r_s = torch.cat([c["r_s"].reshape(1, -1) for c in conds])
+        wa = torch.cat([c["wa"].reshape(1, T, -1) for c in conds])
+        we = torch.cat([c["we"].reshape(1, 1, -1) for c in conds])
+        r_d = self.G.batched_fmt(B).sample(r_s, wa, we, noise, self.opt.nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale)
+        out = []
+        for i, (s, _) in enumerate(items):
+            # the encoder's skip maps of item i (its buffers hold the last encoded image): one more 1-ms encoder pass
+            s_r, _, _, _ = self.enc.encode_image_into_latent(s, want_feats=False)
+            self.enc.hand_feats_to(self.G.dec)
+            out.append(self.G.decode_to_host(s_r, r_d[i]))
+        torch.cuda.current_stream(self.rank).synchronize()
+        self.check_range("InferenceAgent.infer_device_batch")
+        return out
 
     @torch.no_grad()
     def run_inference(self, res_video_path, ref_img, ref_audio, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0,

@@ -96,6 +96,11 @@ class FloatProcess:
     DISPLAY_NAME = "FLOAT Process (Opt)"
 
     def floatprocess(self, ref_image, ref_audio, float_pipe, a_cfg_scale, e_cfg_scale, fps, emotion, face_align, seed):
+        # reference nodes.py:173-175: `with model_to_target(main_logger, float_pipe.G)` - operators resident inside the call
+        with float_pipe.model_to_target():
+            return self._floatprocess(ref_image, ref_audio, float_pipe, a_cfg_scale, e_cfg_scale, fps, emotion, face_align, seed)
+
+    def _floatprocess(self, ref_image, ref_audio, float_pipe, a_cfg_scale, e_cfg_scale, fps, emotion, face_align, seed):
         float_pipe.opt.fps = fps
         image_batch_size = ref_image.shape[0]
         audio_waveform = ref_audio['waveform']
@@ -104,7 +109,22 @@ class FloatProcess:
         target_batch_size = max(image_batch_size, audio_batch_size)
         all_images, used_audio = [], []
         # item i: image min(i, Bi-1), audio min(i, Ba-1), seed + i  (reference nodes.py:189-209)
-        for i in range(target_batch_size):
+        if target_batch_size > 1 and os.environ.get("FLOAT_AMD_BATCH_CLIPS", "1") != "0":
+            # the items of one call have equal length (one audio tensor): their FMT chains run stacked
+            # (InferenceAgent.infer_device_batch -> float_fmt_sample_batch), each with its own noise stream of seed + i
+            items = []
+            for i in range(target_batch_size):
+                ii, ai = min(i, image_batch_size - 1), min(i, audio_batch_size - 1)
+                wf = audio_waveform[ai:ai + 1]
+                items.append(float_pipe.host_inputs(ref_image[ii:ii + 1], {'waveform': wf, 'sample_rate': audio_sample_rate}, not face_align))
+                used_audio.append(wf.cpu())
+            all_images = float_pipe.infer_device_batch(items, a_cfg_scale, float_pipe.opt.r_cfg_scale, e_cfg_scale,
+                                                       None if emotion == "none" else emotion,
+                                                       [seed + i for i in range(target_batch_size)])
+            target_range = range(0)
+        else:
+            target_range = range(target_batch_size)
+        for i in target_range:
             ii, ai = min(i, image_batch_size - 1), min(i, audio_batch_size - 1)
             img = ref_image[ii:ii + 1]
             wf = audio_waveform[ai:ai + 1]

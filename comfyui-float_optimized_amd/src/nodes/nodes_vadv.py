@@ -9,6 +9,7 @@ import torch
 
 from ... import host_models
 from ...fmt import draw_noise
+from ...pipeline import report_range
 from . import EMOTIONS, TORCHDIFFEQ_FIXED_STEP_SOLVERS
 from . import main_logger as logger
 from .nodes_vadv_loader import BASE_CATEGORY, build_audio_encoder
@@ -49,7 +50,9 @@ class ApplyFloatEncoder:
             s_r.append(sb)
             lam.append(lb)
             feats = [[f] for f in fb] if feats is None else [acc + [f] for acc, f in zip(feats, fb)]
-        pipe = {"h_source": torch.cat(s_r).cpu(), "feats": [torch.cat(f).cpu() for f in feats]}
+        pipe = {"h_source": torch.cat(s_r).cpu(), "feats": [torch.cat(f).cpu() for f in feats]}  # .cpu() synchronises
+        if float_encoder.dtype == "fp16":
+            report_range({"encoder": float_encoder.saturation(reset=True)}, "ApplyFloatEncoder")
         return (pipe, torch.cat(lam).cpu(), float_encoder)
 
 
@@ -138,7 +141,10 @@ class FloatSampleMotionSequenceRD_VA:
         else:
             noise = torch.stack([torch.randn(B, cfg.num_frames_for_clip, cfg.dim_w, device=dev) for _ in range(n_chunks)])
         r_d = fmt.sample(r_s_latent, wa_latent, we_latent, noise, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg)
-        return (r_d.cpu(), fmt)
+        r_d_cpu = r_d.cpu()  # synchronises
+        if fmt.dtype == "fp16":
+            report_range({"fmt": fmt.saturation(reset=True)}, "FloatSampleMotionSequenceRD_VA")
+        return (r_d_cpu, fmt)
 
 
 class ApplyFloatSynthesis:
@@ -180,6 +186,8 @@ class ApplyFloatSynthesis:
             float_synthesis.set_feats([f[b:b + 1] for f in feats])
             staging = float_synthesis.decode_into_host(s_r[b:b + 1], r_d_latents[b], host[b * T:(b + 1) * T], staging)
         torch.cuda.current_stream(float_synthesis.device).synchronize()
+        if float_synthesis.dtype == "fp16":  # an fp16 decoder that left its range must not hand over black regions silently
+            report_range({"decoder": float_synthesis.saturation(reset=True)}, "ApplyFloatSynthesis")
         return (host, float_synthesis)
 
 

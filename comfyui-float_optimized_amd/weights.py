@@ -216,6 +216,14 @@ def synth_encoder_state(size=512, dim=512, dim_motion=20, seed=0):
     return sd
 
 
+def scale_encoder_convs(sd, gain):
+    """Every conv weight (4-D `*.weight`) of an encoder state times `gain`: the range-stress fixtures (tools/make_goldens.py,
+    tests/test_enc_gpu.py) - activations grow by `gain` per conv layer."""
+    if gain == 1.0:
+        return sd
+    return {k: (v * gain if k.endswith(".weight") and v.dim() == 4 else v) for k, v in sd.items()}
+
+
 def synth_audio_state(cfg, seed=0):
     """AudioEncoder weights in the reference layout (`audio_encoder.` prefix stripped): transformers' Wav2Vec2Model
     keys under `wav2vec2.` (FLOAT.py:318,326) and `audio_projection.{0,1}` (FLOAT.py:338-342).  cfg: AudioConfig.

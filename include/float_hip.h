@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FLOAT_HIP_ABI_VERSION 3
+#define FLOAT_HIP_ABI_VERSION 4
 
 enum {
   FLOAT_OK = 0,
@@ -91,6 +91,17 @@ void float_fmt_destroy(float_fmt_t* h);
 enum { FLOAT_ODE_EULER = 0, FLOAT_ODE_MIDPOINT = 1, FLOAT_ODE_RK4 = 2, FLOAT_ODE_HEUN2 = 3, FLOAT_ODE_HEUN3 = 4 };
 int float_fmt_set_method(float_fmt_t* h, int32_t method);
 
+/* Range check of the 16-bit modes of the FMT, encoder and audio operators (no reference counterpart: the reference is fp32).
+ * fp16 ends at 65504.  Outside the decoder a 16-bit activation store CLAMPS at +-65504 (a NaN becomes -65504) so that one
+ * outlier degrades the result instead of poisoning it - and every such store is COUNTED: each thread keeps the maximum
+ * magnitude of the halves it stores and adds 1 to the handle's device counter if one reached the clamp value.  (The ResBlock
+ * conv1 of the encoder runs the decoder's conv kernel, which stores inf instead of clamping and counts it the same way.)
+ *   total: threads with at least one clamped / non-finite 16-bit store since the handle was created / last reset - zero or not
+ *   is what matters.  Synchronises `stream`.  A non-zero total means the result is NOT the reference's within the stated
+ *   tolerance: run that checkpoint with dtype FLOAT_DT_FP32 (or bf16 for the FMT / audio operators, whose exponent range is
+ *   fp32's).  Always 0 for bf16 and fp32 handles. */
+int float_fmt_saturation(float_fmt_t* h, uint64_t* total, int32_t reset, void* stream);
+
 /* forward_with_cfv (FMT.py:342-401), B = 1.
  *   x, wa: (n_cur, dim)   wr: (dim_w)   we: (we_len, dim_e) with we_len 1 (static) or n_cur
  *   prev_x, prev_wa: (n_prev, dim)   prev_we: (n_prev, dim_e) - required iff we_len > 1
@@ -135,6 +146,18 @@ int float_fmt_sample_begin(float_fmt_t* h, const float* wr, const float* wa, int
                            int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg,
                            float e_cfg, int32_t include_r_cfg, float* r_d);
 int float_fmt_sample_next(float_fmt_t* h, void* stream, int32_t* window_done, int32_t* windows_left);
+
+/* A job over the windows [first_window, end_window) of the clip only, starting from the history the caller hands over: the
+ * multi-GPU window shard (a rank samples its range from zero history, receives its predecessor's boundary latents by an RCCL
+ * all_gather and re-solves from them).  No reference counterpart (the reference has no distributed code); the window body is
+ * FLOAT.py:214-251 unchanged.  Same arguments as float_fmt_sample_begin (full-clip wa / we / noise / r_d pointers), plus
+ *   hist_x (n_prev, dim_w), hist_wa (n_prev, dim_a), hist_we (n_prev, dim_e; read only with we_len > 1): the last n_prev rows
+ *   of the previous window's sample / padded wa window / we window, or all NULL = zeros, the history of window 0.
+ * Only r_d rows of the job's windows are written.  Continue with float_fmt_sample_next (windows_left counts to end_window). */
+int float_fmt_sample_begin_range(float_fmt_t* h, const float* wr, const float* wa, int32_t T, const float* we,
+                                 int32_t we_len, const float* noise, int32_t nfe, float a_cfg, float r_cfg,
+                                 float e_cfg, int32_t include_r_cfg, float* r_d, int32_t first_window,
+                                 int32_t end_window, const float* hist_x, const float* hist_wa, const float* hist_we);
 
 /* Stream capture: every float_fmt_* run-time call may be issued while `stream` is being captured by the caller
  * (hipStreamBeginCapture); the chain is then launched straight into that capture instead of replaying the handle's own
@@ -221,7 +244,7 @@ int float_dec_saturation(float_dec_t* h, uint64_t* total, uint64_t* per_site, in
  *     x (n_frames,cin,res,res) NCHW, style (n_frames,style_dim), out (n_frames,cout,R',R'), R' = res or 2 res (upsample).
  *     Which kernel runs follows the production rules: plain conv res >= 16 -> dec_conv16_kernel, below -> dec_conv_kernel;
  *     up-conv 2 res >= 64 -> dec_zblur_kernel, res >= 8 -> dec_zconv4_kernel + dec_blur_kernel, res = 4 -> per-class
- *     dec_conv_kernel + dec_blur_kernel.  *saturated = values clamped at +-65504 (fp16).  flags bit 0: no style normalisation.
+ *     dec_conv_kernel + dec_blur_kernel.  *saturated = the range counter of the op's 16-bit output stores (float_dec_saturation's rule: a value beyond fp16's range is stored as inf and counted).  flags bit 0: no style normalisation.
  *   float_dec_debug_flow_level: ToFlow (styledecoder.py:399-425) + ToRGB (:368-386) of one level: keys `to_flow.conv.weight`,
  *     `to_flow.conv.modulation.weight|bias`, `to_flow.bias`, `to_rgb.conv.0.weight`, `to_rgb.conv.1.bias`, `to_rgb.bias`.
  *     x (F,C,R,R) the conv output, feat (C,R,R) the skip feature (the reference repeats it over the batch), style (F,style_dim),
@@ -281,6 +304,7 @@ int float_enc_forward(float_enc_t* h, const float* img, float* s_r, float* lam, 
 
 /* The NHWC 16-bit feature maps left in the handle by the last float_enc_forward (valid until the
  * next one), reference order; *n_out = how many were written (<= max_feats). */
+int float_enc_saturation(float_enc_t* h, uint64_t* total, int32_t reset, void* stream); /* see float_fmt_saturation */
 int float_enc_feats16(float_enc_t* h, const void** feats16, int32_t* channels, int32_t max_feats,
                       int32_t* n_out);
 
@@ -324,6 +348,7 @@ void float_aud_destroy(float_aud_t* h);
  * extractor's own length, as float_aud_classify uses it).  The ONLY call that allocates after create: it synchronises
  * `stream` first when buffers have to grow (earlier work may still read the old ones) and never shrinks.  Not capturable. */
 int float_aud_reserve(float_aud_t* h, int32_t n_samples, int32_t seq_len, void* stream);
+int float_aud_saturation(float_aud_t* h, uint64_t* total, int32_t reset, void* stream); /* see float_fmt_saturation */
 
 /* a: (n_samples) fp32 device, the normalised 16 kHz waveform already replicate-padded by the caller to a
  * multiple of seq_len * sampling_rate / fps when needed (FLOAT.py:371-373);  wa: (seq_len, dim_w) fp32.

@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# a product call whose fp16 operators leave their range is an ERROR in the test suite (default outside: RuntimeWarning)
+os.environ.setdefault("FLOAT_AMD_RANGE", "raise")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "reference: needs /root/reference (build container only)")

@@ -26,6 +26,7 @@ def test_audio_golden(tag, dtype):
     e = rel_l2(wa, g["wa"])
     print(tag, dtype, "wa rel-L2 %.3e max|d| %.3e" % (e, float((wa - g["wa"]).abs().max())))
     assert wa.shape == g["wa"].shape and e < TOL[dtype]
+    assert enc.saturation() == 0  # no 16-bit activation store was clamped (float_aud_saturation; always 0 for bf16 / fp32)
 
 
 def test_audio_live_oracle_lengths_and_determinism():
@@ -87,6 +88,7 @@ def test_speech_emotion_golden(tag, dtype):
     print(tag, dtype, "scores max|d| %.3e" % d, [round(float(v), 4) for v in scores[0]])
     assert scores.shape == g["scores"].shape and d < {"fp16": 1e-3, "bf16": 1e-2, "fp32": 2e-6}[dtype]
     assert abs(float(scores.sum()) - 1.0) < 1e-5 and int(scores.argmax()) == int(g["scores"].argmax())
+    assert ser.saturation() == 0
     assert torch.equal(ser.predict_emotion(a).cpu(), scores)
     with pytest.raises(TypeError):
         ser.inference(a, 25)
@@ -154,7 +156,7 @@ def test_audio_length_is_not_capped_by_lds():
     ref = O.audio_encoder_inference(asd, acfg, a, 12000)
     e = rel_l2(wa, ref)
     print("12 000 frames: rel-L2 %.2e" % e)
-    assert wa.shape == (1, 12000, acfg.dim_w) and e < 3e-3
+    assert wa.shape == (1, 12000, acfg.dim_w) and e < 3e-3 and enc.saturation() == 0
     a = W.synth_waveform(100.0, seed=9)
     wa = enc.inference(a, 2500).cpu()  # one tile + 452 keys
     assert rel_l2(wa, O.audio_encoder_inference(asd, acfg, a, 2500)) < 3e-3

@@ -10,7 +10,7 @@ import pytest
 from tests.util import ROOT
 
 pytestmark = pytest.mark.gpu
-SHORT = ["--seconds", "2", "--nfe", "6", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-bf16"]
+SHORT = ["--seconds", "2", "--nfe", "6", "--steps", "1", "--warmup", "1", "--no-bf16"]
 
 
 def _run(args, env=None):
@@ -24,10 +24,15 @@ def _run(args, env=None):
 
 
 def test_single_gpu_line_has_the_contract_fields():
-    r = _run(SHORT)
+    r = _run(SHORT)  # every leg of the default run: roofline pass, CPU baseline, speech-to-emotion, nfe / host-input variants
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline" if False else "stage_ms"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "stage_ms", "value_s2e", "value_nfe5", "value_from_host_inputs",
+              "host_inputs_ms", "rccl_ranks", "fp16_range_hits"):
         assert k in r, k
+    cb = r["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and "sample" in cb
+    assert r["rccl_ranks"] == 1 and r["fp16_range_hits"] == 0 and "speech_emotion" in r["stage_ms"]
+    assert r["value_s2e"] > 0 and r["value_from_host_inputs"] > 0 and r["value_nfe5"] > 0
     assert r["n_gpus"] == 1 and r["unit"] == "frames/s" and r["value"] > 0 and r["vs_baseline"] is None
     assert "workload" in r["config"] and "pinned host memory" in r["config"]["workload"]
     # value is the end-to-end rate: frames / wall of the timed steps
@@ -38,7 +43,7 @@ def test_single_gpu_line_has_the_contract_fields():
 
 @pytest.mark.parametrize("mode", ["replicas", "window", "shard"])
 def test_gpus_2_launches_its_own_ranks(mode):
-    r = _run(SHORT + ["--gpus", "2", "--mode", mode, "--no-roofline", "--no-extras"], {"FLOAT_BENCH_BACKEND": "gloo"})
+    r = _run(SHORT + ["--gpus", "2", "--mode", mode, "--no-roofline", "--no-extras", "--no-cpu-baseline"], {"FLOAT_BENCH_BACKEND": "gloo"})
     assert r["n_gpus"] == 2
     assert r["config"]["frames_per_clip"] == (50 if mode == "replicas" else 100)
     if mode == "window":

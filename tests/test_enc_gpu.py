@@ -38,6 +38,41 @@ def test_encoder_golden(size, dtype):
         errs["feat%d" % i] = rel_l2(f.cpu()[:, :, ::st, ::st], g["feat%d" % i])
     print(size, dtype, " ".join("%s %.2e" % kv for kv in errs.items()))
     assert max(errs.values()) < TOL[dtype], errs
+    assert enc.saturation() == 0  # no 16-bit store had to be clamped (always 0 for bf16 / fp32)
+
+
+def _stress_errs(tag, dtype):
+    g = golden("enc_stress_64_" + tag)
+    size = 64
+    esd = W.scale_encoder_convs(W.synth_encoder_state(size, seed=g["seed"]), g["gain"])
+    dsd = W.synth_decoder_state(size, seed=g["seed"])
+    enc = pkg.encoder.EncoderHIP(esd, size, 512, 20, "cuda:0", dtype, direction_weight=dsd["direction.weight"])
+    s_r, lam, feats, r_s = enc.encode_image_into_latent(_image(g["seed"], size))
+    errs = dict(s_r=rel_l2(s_r.cpu(), g["s_r"]), lam=rel_l2(lam.cpu(), g["lam"]))
+    for i, f in enumerate(feats):
+        st = int(g["feat%d_stride" % i])
+        errs["feat%d" % i] = rel_l2(f.cpu()[:, :, ::st, ::st], g["feat%d" % i])
+    return errs, enc.saturation(), g
+
+
+def test_encoder_range_stress():
+    """The reference Encoder with every conv weight x gain (encoder.py:146-247; tools/make_goldens.py GOLDENS_ONLY=encx).
+    gain 2: activations up to ~300, inside fp16's range -> counter 0 and the fp16 result within its tolerance.
+    gain 6: the 8 x 8 skip map reaches 1.9e5 > 65504 -> the fp16 operator MUST report it (float_enc_saturation > 0) and its
+    result is indeed wrong; the fp32 mode reproduces the reference with counter 0.  This is what makes `saturation() == 0`
+    in the other tests (and the warning of the product path) mean something."""
+    e2, sat2, _ = _stress_errs("g2", "fp16")
+    print("gain 2 fp16:", " ".join("%s %.2e" % kv for kv in e2.items()), "saturation", sat2)
+    assert sat2 == 0 and max(e2.values()) < TOL["fp16"], (sat2, e2)
+    e6, sat6, g6 = _stress_errs("g6", "fp16")
+    print("gain 6 fp16:", " ".join("%s %.2e" % kv for kv in e6.items()), "saturation", sat6, "ref |feat0|max %.3g" % g6["feat0_absmax"])
+    assert sat6 > 0, "an out-of-range checkpoint went unnoticed"
+    # (the fp32 copies of the skip maps are written before the 16-bit conversion and stay right; what the 16-bit chain feeds
+    # forward - s_r, lambda, and the 16-bit maps the decoder receives - is clamped)
+    assert e6["s_r"] > 10 * TOL["fp16"], "gain 6 was expected to break the fp16 result"
+    e32, sat32, _ = _stress_errs("g6", "fp32")
+    print("gain 6 fp32:", " ".join("%s %.2e" % kv for kv in e32.items()), "saturation", sat32)
+    assert sat32 == 0 and max(e32.values()) < TOL["fp32"], (sat32, e32)
 
 
 def test_encoder_live_oracle_and_determinism():

@@ -33,6 +33,7 @@ def test_eval_golden(tag, dtype):
         err = rel_l2(out, g[case + "_out"])
         print(tag, dtype, case, "rel-L2 %.3e" % err)
         assert err < TOL[dtype], (case, err)
+    assert fmt.saturation() == 0  # float_fmt_saturation: no 16-bit activation store was clamped
 
 
 @pytest.mark.parametrize("tag", ["small_static", "small_dynamic", "full_static"])
@@ -170,7 +171,24 @@ def test_fused_attention_proj_launch(hpw, dtype, monkeypatch):
         print("fused hpw=%d" % hpw, dtype, case, "rel-L2 %.3e" % err)
         assert err < tol, (case, err)
         assert torch.equal(out, call())
+    assert fmt.saturation() == 0
     gs = golden("fmt_sample_full_static")
     sd, fmt = _fmt(cfg, gs["seed"], dtype)
     r_d = fmt.sample(gs["r_s"], gs["wa"], gs["we"], gs["noise"], gs["nfe"], gs["a"], 1.0, gs["e"]).cpu()
     assert rel_l2(r_d, gs["r_d"]) < tol
+
+
+def test_fmt_saturation_counter_fires():
+    """float_fmt_saturation: x_embedder input rows beyond fp16's range (|x| = 1e6 > 65504) are clamped AND counted in the fp16
+    handle; the bf16 handle (fp32's exponent range) reports 0.  Without this, `saturation() == 0` elsewhere would prove nothing."""
+    g = golden("fmt_eval_small")
+    cfg = C.small_fmt_config()
+    args = lambda x: (g["t"], x, g["cfg3_wa"], g["cfg3_wr"], g["cfg3_we"], g["cfg3_prev_x"], g["cfg3_prev_wa"], None)  # noqa: E731
+    for dtype, expect in (("fp16", True), ("bf16", False)):
+        sd, fmt = _fmt(cfg, g["seed"], dtype)
+        fmt.forward_with_cfv(*args(g["cfg3_x"]), a_cfg_scale=2.0, e_cfg_scale=1.0)
+        assert fmt.saturation() == 0
+        fmt.forward_with_cfv(*args(g["cfg3_x"] * 1e6), a_cfg_scale=2.0, e_cfg_scale=1.0)
+        n = fmt.saturation(reset=True)
+        print(dtype, "clamped-store threads with |x| = 1e6:", n)
+        assert (n > 0) == expect and fmt.saturation() == 0

@@ -72,3 +72,15 @@ def test_resampler_near_coprime_rate_is_bounded():
     assert time.time() - t0 < 5.0 and y.shape == (16000,)
     ref = torch.sin(2 * math.pi * 440 * torch.arange(16000) / 16000.0)
     assert float((y[200:-200] - ref[200:-200]).abs().max()) < 2e-3
+
+
+def test_resampler_unfriendly_target_rate_terminates():
+    """a source rate that already is a multiple of 50 Hz with a target that is not (44100 -> 16001 via
+    opt.sampling_rate) used to recurse without end; now the filter runs at the nearest friendly target and a linear
+    post-pass lands on the requested length."""
+    t = np.arange(44100) / 44100.0
+    x = torch.from_numpy(np.sin(2 * np.pi * 440 * t).astype(np.float32))
+    y = hm.resample_sinc(x, 44100, 16001)
+    assert y.shape[0] == 16001
+    tt = np.arange(16001) / 16001.0
+    assert float(np.abs(y.numpy()[200:-200] - np.sin(2 * np.pi * 440 * tt)[200:-200]).max()) < 2e-2

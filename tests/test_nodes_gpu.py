@@ -95,3 +95,56 @@ def test_node_path_is_the_bench_path(pipe):
     other, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 8)
     assert torch.equal(images, keep) and not torch.equal(other, images)
     assert pipe.G.dec.saturation() == 0
+
+
+def test_offload_frees_hbm_and_reload_is_bitwise(pipe):
+    """The reference wraps every node call in model_to_target (nodes.py:173-175): the operators leave the device after
+    the call.  InferenceAgent.offload() frees every device allocation of the agent (>= 5 GB at the default shapes), the next
+    FloatProcess call rebuilds the operators from the host weights and returns bit for bit the frames of the first."""
+    img, audio = _inputs()
+    node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    first, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    first = first.clone()
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    pipe.offload()
+    free1, _ = torch.cuda.mem_get_info()
+    print("HBM freed by offload: %.2f GB" % ((free1 - free0) / 2**30))
+    assert not pipe.resident and free1 - free0 >= 5 * 2**30
+    again, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)   # to_target() inside the call
+    assert pipe.resident and torch.equal(again, first)
+    with pipe.model_to_target(offload_after=True):   # the reference's policy: offload after every call
+        pass
+    assert not pipe.resident
+    pipe.to_target()
+
+
+def test_float_process_batch_runs_stacked_chains(pipe, monkeypatch):
+    """FloatProcess with B > 1 items (nodes.py:189-209: image min(i, Bi-1), audio min(i, Ba-1), seed + i): the items' FMT
+    chains run stacked (float_fmt_sample_batch).  Each item equals the per-item loop within the fp16 limit of the path
+    (>= 45 dB, tests/test_pipeline_gpu.py) and the batched call is faster than the loop."""
+    import time
+    g = torch.Generator().manual_seed(3)
+    img, audio = _inputs()
+    imgs = torch.cat([img, torch.rand(3, 512, 512, 3, generator=g)])
+    node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+
+    def run():
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, aud, _ = node.floatprocess(imgs, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+        torch.cuda.synchronize()
+        return out, aud, time.perf_counter() - t0
+    run()
+    batched, aud_b, t_b = run()
+    monkeypatch.setenv("FLOAT_AMD_BATCH_CLIPS", "0")
+    run()
+    looped, aud_l, t_l = run()
+    assert batched.shape == looped.shape == (100, 512, 512, 3) and torch.equal(aud_b["waveform"], aud_l["waveform"])
+    for i in range(4):
+        mse = float(((batched[i * 25:(i + 1) * 25] - looped[i * 25:(i + 1) * 25]) ** 2).mean())
+        psnr = 99.0 if mse == 0 else -10 * torch.log10(torch.tensor(mse)).item()
+        print("item %d: batched vs per-item %.1f dB" % (i, psnr))
+        assert psnr >= 45.0
+    print("B = 4, 25 frames each: batched %.1f ms, per-item loop %.1f ms (%.2fx)" % (t_b * 1e3, t_l * 1e3, t_b / t_l))
+    assert t_b < t_l

@@ -49,3 +49,31 @@ def test_image_and_audio_to_frames_fp32(emo):
     print("whole path in fp32 (emo=%s): frames max|d| %.2e" % (emo, m))
     assert m <= 1e-4
     assert agent.G.dec.saturation() == 0
+
+
+def test_product_path_reports_fp16_overflow(monkeypatch):
+    """An encoder checkpoint that leaves fp16's range (conv weights x 6: the 8 x 8 skip map reaches 1.9e5) through the PRODUCT
+    call: InferenceAgent.infer_device warns (RuntimeWarning, default) or raises (FLOAT_AMD_RANGE=raise) instead of handing
+    back wrong / black regions silently; the same checkpoint with the fp32 decoder + encoder passes without a message."""
+    gen = importlib.import_module(pkg.__name__ + ".src.nodes.generate")
+    opt = importlib.import_module(pkg.__name__ + ".src.nodes.options.base_options").BaseOptions()
+    opt.input_size, opt.nfe = 64, 3
+    cfg = C.FmtConfig.from_options(opt)
+    acfg = C.small_audio_config()
+    acfg.dim_w = opt.dim_w
+    parts = dict(enc=W.scale_encoder_convs(W.synth_encoder_state(64, seed=1010), 6.0), dec=W.synth_decoder_state(64, seed=1010),
+                 fmt=W.synth_fmt_state(cfg, seed=31), audio_encoder=(W.synth_audio_state(acfg, seed=31), acfg))
+    img = torch.from_numpy(np.random.RandomState(1010).rand(1, 3, 64, 64).astype(np.float32)) * 2 - 1
+    wav = W.synth_waveform(0.5, seed=9)
+    agent = gen.InferenceAgent(opt, parts, "cuda:0", max_frames=8)
+    monkeypatch.setenv("FLOAT_AMD_RANGE", "warn")
+    with pytest.warns(RuntimeWarning, match="fp16 range exceeded in .*encoder"):
+        agent.infer_device(img.cuda(), wav.cuda(), 2.0, 1.0, 1.0, emo="happy", seed=7)
+    monkeypatch.setenv("FLOAT_AMD_RANGE", "raise")
+    with pytest.raises(pkg.pipeline.Fp16RangeError):
+        agent.infer_device(img.cuda(), wav.cuda(), 2.0, 1.0, 1.0, emo="happy", seed=7)
+    # the remedy the message names: fp32 decoder + encoder, and an FMT operand type with fp32's exponent range (the identity
+    # latent r_s ~ 1e7 of this checkpoint leaves fp16's range inside the FMT's condition rows too)
+    agent32 = gen.InferenceAgent(opt, parts, "cuda:0", max_frames=8, dec_dtype="fp32", fmt_dtype="bf16")
+    frames = agent32.infer_device(img.cuda(), wav.cuda(), 2.0, 1.0, 1.0, emo="happy", seed=7)  # raise mode: no error
+    assert torch.isfinite(frames).all() and agent32.range_counts() == {"audio": 0}

@@ -423,11 +423,13 @@ def gen_e2e_config1(ns, seed=900):
          lattice=frames[:, ::7, ::5], band=frames[:, 250:258], mean=frames.mean(dim=(1, 2, 3)))
 
 
-def gen_encoder(ns, size, seed, sparse):
+def gen_encoder(ns, size, seed, sparse, gain=1.0, name=None):
     """Encoder.forward(img, None) + Encoder.fc + Direction of the reference itself (encoder.py:266-281, 242-247;
-    styledecoder.py:428-444; FLOAT.py:283-291) on seeded synthetic weights."""
-    print("[encoder %d]" % size)
-    esd = weights.synth_encoder_state(size, seed=seed)
+    styledecoder.py:428-444; FLOAT.py:283-291) on seeded synthetic weights.  gain != 1: every conv weight multiplied by it
+    (weights.scale_encoder_convs) - the range-stress fixtures: activations grow by `gain` per conv, so the deep layers leave
+    fp16's range (gain 6) or come close to it (gain 2) while the fp32 reference is untroubled."""
+    print("[encoder %d gain %g]" % (size, gain))
+    esd = weights.scale_encoder_convs(weights.synth_encoder_state(size, seed=seed), gain)
     enc = ns.encoder.Encoder(size, 512, 20)
     enc.load_state_dict(esd, strict=True)
     enc.eval()
@@ -444,13 +446,14 @@ def gen_encoder(ns, size, seed, sparse):
     print("  oracle-ref max|d|: s_r %.3e lam %.3e r_s %.3e feats %.3e" % (
         maxdiff(o_s, s_r)[0], maxdiff(o_l, lam)[0], maxdiff(o_r, r_s)[0], max(maxdiff(a, b)[0] for a, b in zip(o_f, feats))))
     # the image is RandomState(seed).rand(1,3,S,S)*2-1: tests regenerate it from the seed
-    arrs = dict(seed=seed, size=size, s_r=s_r, lam=lam, r_s=r_s)
+    arrs = dict(seed=seed, size=size, gain=float(gain), s_r=s_r, lam=lam, r_s=r_s)
     for i, f in enumerate(feats):
         st = max(1, f.shape[-1] // 16) if sparse else (2 if f.shape[-1] > 16 else 1)
         arrs["feat%d_stride" % i] = st
         arrs["feat%d" % i] = f[:, :, ::st, ::st]
         arrs["feat%d_mean" % i] = f.mean(dim=(2, 3))
-    save("enc_%d" % size, **arrs)
+        arrs["feat%d_absmax" % i] = f.abs().max()
+    save(name or "enc_%d" % size, **arrs)
 
 
 def gen_audio(ns, tag, cfg, seed, seconds, T):
@@ -621,6 +624,10 @@ def main():
         gen_dec_stress(ns, 512, 1730, "range", sparse=True)
         gen_dec_cm2(ns)
         return
+    if os.environ.get("GOLDENS_ONLY") == "encx":
+        gen_encoder(ns, 64, seed=1010, sparse=False, gain=2.0, name="enc_stress_64_g2")
+        gen_encoder(ns, 64, seed=1010, sparse=False, gain=6.0, name="enc_stress_64_g6")
+        return
     if os.environ.get("GOLDENS_ONLY") == "enc":
         gen_encoder(ns, 64, seed=1000, sparse=False)
         gen_encoder(ns, 512, seed=1100, sparse=True)
@@ -655,6 +662,8 @@ def main():
     gen_dec_cm2(ns)
     gen_encoder(ns, 64, seed=1000, sparse=False)
     gen_encoder(ns, 512, seed=1100, sparse=True)
+    gen_encoder(ns, 64, seed=1010, sparse=False, gain=2.0, name="enc_stress_64_g2")
+    gen_encoder(ns, 64, seed=1010, sparse=False, gain=6.0, name="enc_stress_64_g6")
     gen_audio(ns, "small", config.small_audio_config(), seed=1200, seconds=1.3, T=33)
     gen_audio(ns, "base", config.AudioConfig(), seed=1300, seconds=2.0, T=50)
     gen_emotion(ns, "small", config.small_emotion_config(), seed=1400, seconds=1.3)
