@@ -1,6 +1,7 @@
 """Simple nodes (reference nodes.py:23-222): Load FLOAT Models (Opt) and FLOAT Process (Opt), same
 class attributes, widget names, return tuples and batch/seed semantics; the body runs the MI355X
 hot path (HIP) with the host-side encoders on PyTorch-ROCm."""
+import contextlib
 import os
 
 import torch
@@ -97,7 +98,8 @@ class FloatProcess:
 
     def floatprocess(self, ref_image, ref_audio, float_pipe, a_cfg_scale, e_cfg_scale, fps, emotion, face_align, seed):
         # reference nodes.py:173-175: `with model_to_target(main_logger, float_pipe.G)` - operators resident inside the call
-        with float_pipe.model_to_target():
+        ctx = float_pipe.model_to_target() if hasattr(float_pipe, "model_to_target") else contextlib.nullcontext()
+        with ctx:
             return self._floatprocess(ref_image, ref_audio, float_pipe, a_cfg_scale, e_cfg_scale, fps, emotion, face_align, seed)
 
     def _floatprocess(self, ref_image, ref_audio, float_pipe, a_cfg_scale, e_cfg_scale, fps, emotion, face_align, seed):
@@ -109,7 +111,7 @@ class FloatProcess:
         target_batch_size = max(image_batch_size, audio_batch_size)
         all_images, used_audio = [], []
         # item i: image min(i, Bi-1), audio min(i, Ba-1), seed + i  (reference nodes.py:189-209)
-        if target_batch_size > 1 and os.environ.get("FLOAT_AMD_BATCH_CLIPS", "1") != "0":
+        if target_batch_size > 1 and hasattr(float_pipe, "infer_device_batch") and os.environ.get("FLOAT_AMD_BATCH_CLIPS", "1") != "0":
             # the items of one call have equal length (one audio tensor): their FMT chains run stacked
             # (InferenceAgent.infer_device_batch -> float_fmt_sample_batch), each with its own noise stream of seed + i
             items = []

@@ -77,6 +77,23 @@ def test_floatprocess_batch_schedule():
     assert list(out[1]["waveform"].shape) == s["audio_shape"] and out[1]["waveform"][0, 0].tolist() == s["audio_values"]
     assert out[2] == s["fps"] and FakePipe.opt.fps == 30.0
 
+    # the stacked-chain path (InferenceAgent.infer_device_batch) keeps the reference's schedule: item i = image min(i, Bi-1),
+    # audio min(i, Ba-1), seed + i, same scales / emotion / crop flag, and the same outputs
+    calls2 = []
+
+    class BatchPipe(FakePipe):
+        def host_inputs(self, img, audio, no_crop):
+            return (float(img[0, 0, 0, 0]), float(audio["waveform"][0, 0, 0]), no_crop)
+
+        def infer_device_batch(self, items, a, r, e, emo, seeds):
+            for (im, au, nc), sd in zip(items, seeds):
+                calls2.append(dict(image_mark=im, audio_mark=au, seed=sd, emo=emo, no_crop=nc, a=a, e=e, r=r))
+            return [torch.full((2, 4, 4, 3), float(i + 1)) for i in range(len(items))]
+
+    out2 = nodes["FloatProcessOpt"]().floatprocess(img, {"waveform": wav, "sample_rate": 16000}, BatchPipe(), 2.0, 1.0, 30.0,
+                                                   "happy", False, 1000)
+    assert calls2 == s["calls"] and torch.equal(out2[0], out[0]) and torch.equal(out2[1]["waveform"], out[1]["waveform"])
+
 
 def test_host_preprocessing():
     hm = pkg.host_models
