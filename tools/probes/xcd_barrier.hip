@@ -68,9 +68,13 @@ __global__ __launch_bounds__(256) void chain(float4* buf, unsigned* cnt, unsigne
     if (t == 0) {
       unsigned* c = cnt + (size_t)s * 8 + x;
       if (MODE == 0) {
-        __hip_atomic_fetch_add((gu32*)c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        // atomics always execute in the L2; without sc1 they stop at THIS XCD's L2 (sc0 = return the old value)
+        unsigned one = 1u, zero = 0u, seen;
+        asm volatile("global_atomic_add %0, %1, off" ::"v"(c), "v"(one) : "memory");
         unsigned spins = 0;
-        while (__hip_atomic_fetch_or((gu32*)c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (unsigned)per_xcd) {
+        for (;;) {
+          asm volatile("global_atomic_add %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(seen) : "v"(c), "v"(zero) : "memory");
+          if (seen >= (unsigned)per_xcd) break;
           if (++spins > (1u << 22)) { atomicAdd(&info[2], 1u); break; }
           __builtin_amdgcn_s_sleep(1);
         }
