@@ -221,6 +221,33 @@ struct FP32 {
   }
 };
 
+// Coherent loads (COH = true): data another workgroup stored EARLIER IN THE SAME KERNEL (fmt_mega_kernel, whose stages meet at
+// an in-kernel grid barrier instead of a launch boundary).  Such data is stored write-through (sc1) and must be read past the
+// CU's vector L1 and this XCD's possibly stale L2 copy: agent-scope relaxed atomic loads are how HIP spells "load with sc1"
+// (8 bytes at most per instruction), and unlike inline asm the compiler still schedules them and counts their waits.
+template <bool COH>
+__device__ __forceinline__ u32x4 fh_load16(const void* p) {
+  if constexpr (COH) {
+    const unsigned long long lo = __hip_atomic_load((const fh_gu64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long hi = __hip_atomic_load((const fh_gu64*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return u32x4{(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+  } else {
+    return *reinterpret_cast<const u32x4*>(p);
+  }
+}
+template <bool COH>
+__device__ __forceinline__ float4 fh_load_f4(const float* p) {
+  if constexpr (COH) {
+    const u32x4 v = fh_load16<true>(p);
+    return float4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+// store-site selector: inside the persistent kernel every activation store writes through, whatever FMT_WT says
+template <bool COH>
+constexpr int fh_site(int site) { return COH ? 0xFF : site; }
+
 // ---------------------------------------------------------------- range tracking of 16-bit stores (float_{fmt,enc,aud}_saturation)
 // FP16::from_float clamps at +-65504 (a NaN becomes -65504): outside the decoder an out-of-range activation degrades the
 // result instead of poisoning it, but it must not do so silently.  Every 16-bit activation store of the FMT, encoder and

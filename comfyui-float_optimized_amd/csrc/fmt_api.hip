@@ -35,6 +35,16 @@ struct float_fmt {
   float *wa_c, *we_c, *prev_x, *prev_wa, *prev_we, *x0_c;
   int method = 0;          // FLOAT_ODE_*
   int attnproj = 0;        // heads per workgroup of the fused attention + proj launch (FLOAT_FMT_ATTNPROJ), 0 = two launches
+  // the step chain of one evaluation as ONE persistent kernel (fmt_mega_kernel): stage table per CFG shape, barrier words
+  int mega_on = 0;         // FLOAT_FMT_MEGA=1 selects it; default 0 = the 59-launch chain (faster: fmt_kernels.hpp, fmt_mega_kernel)
+  int n_cu = 0;
+  struct MegaPlan {
+    MegaStage* dev = nullptr;
+    int nstage = 0, bc = 0, tried = 0;
+    MegaCtx ctx{};
+  } mega[5];               // by CFG rows (1, 3, 4)
+  unsigned* mega_sync = nullptr;  // [8 x 32 | 32 | 8 x 32 | seq | err] words
+  u16* mega_ws = nullptr;         // write-once A operands of the persistent kernel: per block h16 x 2, att16, hid16; + the head's
   float* kbuf = nullptr;   // [4][kMaxTok][dim_w] stage velocities of the Runge-Kutta solvers
   // Modulations of up to kScSteps evaluations of a window, [step][Mmod][Ntot] fp32: c = t_emb + c_embedder(wr, wa, we) does not
   // depend on x (FMT.py:333-335, 163-166), so every adaLN projection of those evaluations is ONE GEMM per window.
@@ -314,6 +324,8 @@ void prime_kernels() {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     (void)launch_wide<T>(g, true, nullptr);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fmt_mega_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 48 * 64 * 4) != hipSuccess)
+      (void)hipGetLastError();
   }
 }
 
@@ -638,6 +650,177 @@ int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
   return FLOAT_OK;
 }
 
+// ---- the persistent evaluation kernel (fmt_mega_kernel): stage table of run_blocks' chain for one clip
+constexpr int kMegaWgs = 256, kMegaSmem = 8 * 48 * 64 * 4;
+MegaSync mega_sync_of(const float_fmt* h) {
+  unsigned* m = h->mega_sync;
+  static const int wg = getenv("FLOAT_FMT_MEGA_STAMP_WG") ? atoi(getenv("FLOAT_FMT_MEGA_STAMP_WG")) : 0;
+  return MegaSync{m, m + 8 * 32, m + 9 * 32, m + 17 * 32, m + 18 * 32, reinterpret_cast<unsigned long long*>(m + 20 * 32), (unsigned)wg};
+}
+// The chain's shapes this kernel is built for: one clip, 3 CFG rows of 60 tokens (M = 180), dim_h 1024, the default launch
+// options - i.e. exactly the tilings run_blocks would pick.  Anything else keeps the launch chain.
+template <class T>
+bool mega_shape_ok(const float_fmt* h, int nclip, int bc) {
+  if (T::is32 || !h->mega_on || nclip != 1 || bc != 3 || h->D != 1024 || h->cfg.heads != 8 || h->n_cu < kMegaWgs) return false;
+  if (attnproj_hpw(h) || g_fmt_fc2_split != 4 || g_fmt_proj_split != 0) return false;
+  const int M = bc * h->ntok;
+  auto is = [](Tiling t, int a, int b, int c) { return t.mtw == a && t.nt == b && t.nw == c; };
+  const Blk& B = h->blk[0];
+  return (M + 15) / 16 == 12 && (h->ntok + 15) / 16 == 4 && h->x_embed.K % 256 == 0 && h->final_lin.K % 256 == 0 &&
+         is(pick_tiling(M, B.qkv.N, B.qkv.K, false), 3, 4, 8) && is(pick_tiling(M, B.proj.N, B.proj.K, false), 3, 1, 8) &&
+         is(pick_tiling(M, B.fc1.N, B.fc1.K, false), 3, 4, 8) && is(pick_tiling(M, B.fc2.N * 4, B.fc2.K / 4, false), 3, 4, 8) &&
+         B.fc2.K % 512 == 0;
+}
+
+template <class T>
+int build_mega(float_fmt* h, int bc) {
+  float_fmt::MegaPlan& P = h->mega[bc];
+  P.tried = 1;
+  const float_fmt_cfg_t& c = h->cfg;
+  const int D = h->D, ntok = h->ntok, M = bc * ntok;
+  std::vector<MegaStage> st;
+  // A operands of the GEMM stages: one buffer per producing stage, written once per launch (see fmt_gemm_body, ldA)
+  const size_t esz = sizeof(typename T::elem) / sizeof(u16);
+  const size_t n_h = (size_t)h->Mpad * D * esz, n_hid = (size_t)h->Mpad * c.mlp_hidden * esz;
+  if (!h->mega_ws) {
+    int rc0 = h->pool.alloc(&h->mega_ws, (size_t)c.depth * (3 * n_h + n_hid), true);
+    if (rc0) return rc0;
+  }
+  auto ws_h1 = [&](int b) { return h->mega_ws + (size_t)b * (3 * n_h + n_hid); };
+  auto ws_h2 = [&](int b) { return ws_h1(b) + n_h; };
+  auto ws_att = [&](int b) { return ws_h1(b) + 2 * n_h; };
+  auto ws_hid = [&](int b) { return ws_h1(b) + 3 * n_h; };
+  auto gemm_stage = [&](int kind, GemmArgs g, int mtw, int nt) {
+    MegaStage m;
+    memset(&m, 0, sizeof(m));
+    m.kind = kind;
+    g.sat = h->sat;
+    g.mblk = ((g.M + 15) / 16 + mtw - 1) / mtw;
+    if (g.ksplit < 1) g.ksplit = 1;
+    m.g = g;
+    m.nblk = (unsigned)((g.N / (nt * 16)) * g.mblk * g.ksplit);
+    return m;
+  };
+  auto ln_stage = [&](int b_mod, int which, int ks, const float* bias, int gate_col, const Lin* next, int touch_bit, u16* out, int perm) {
+    MegaStage m;
+    memset(&m, 0, sizeof(m));
+    m.kind = MS_LN;
+    m.nblk = (unsigned)(((M + 63) / 64) * 64);
+    m.shift_off = (long long)b_mod * 6 * D + (long long)which * D;
+    m.scale_off = m.shift_off + D;
+    m.ks = ks;
+    m.red_bias = bias;
+    m.red_gate_off = (long long)b_mod * 6 * D + (long long)gate_col * D;
+    m.ln_out = out ? out : h->h16;
+    m.perm = perm;
+    if (next && (g_fmt_touch & (1 | touch_bit))) m.pf = make_touch(*next, M, 0, (m.nblk / 8) * 64, 6);
+    return m;
+  };
+  {  // x_embedder + pos_embed (run_blocks): 8 K-splitting waves here instead of 4 (every stage runs the 512-thread workgroup)
+    GemmArgs g = base_args(h->xin16, h->x_embed, ntok);
+    g.out_f32 = h->xres;
+    g.ldo = D;
+    g.pos = h->pos;
+    g.bc = bc;
+    g.ntok = ntok;
+    st.push_back(gemm_stage(MS_XEMBED, g, 4, 1));
+  }
+  for (int b = 0; b < c.depth; ++b) {
+    const Blk& B = h->blk[b];
+    // LN1: folds the previous block's fc2 slabs (gate_mlp of block b - 1)
+    if (b == 0) st.push_back(ln_stage(b, 0, 0, nullptr, 0, &B.qkv, 128, ws_h1(b), 0));
+    else {
+      MegaStage m = ln_stage(b, 0, 4, h->blk[b - 1].fc2.b, 0, &B.qkv, 128, ws_h1(b), 0);
+      m.red_gate_off = (long long)(b - 1) * 6 * D + 5LL * D;
+      st.push_back(m);
+    }
+    {
+      GemmArgs g = base_args(ws_h1(b), B.qkv, M);
+      g.out16 = h->qkv16;
+      g.ldo16 = 3 * D;
+      if (g_fmt_touch & 8) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
+      st.push_back(gemm_stage(MS_QKV, g, 3, 4));
+    }
+    {
+      MegaStage m;
+      memset(&m, 0, sizeof(m));
+      m.kind = MS_ATTN;
+      m.nblk = (unsigned)(c.heads * ((M + 7) / 8));
+      if (g_fmt_touch & 2) m.pf = make_touch(B.proj, M, 0, (m.nblk / 8) * 128, 2);
+      m.att_out = ws_att(b);
+      st.push_back(m);
+    }
+    {
+      GemmArgs g = base_args(ws_att(b), B.proj, M);
+      g.out_f32 = h->xres;
+      g.ldo = D;
+      g.ldg = h->Ntot;
+      if (g_fmt_touch & 16) g.touch = make_touch(B.fc1, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
+      MegaStage m = gemm_stage(MS_PROJ, g, 3, 1);
+      m.gate_off = (long long)b * 6 * D + 2LL * D;
+      st.push_back(m);
+    }
+    st.push_back(ln_stage(b, 3, 0, nullptr, 0, &B.fc1, 64, ws_h2(b), 0));
+    {
+      GemmArgs g = base_args(ws_h2(b), B.fc1, M);
+      g.out16 = ws_hid(b);
+      g.ldo16 = B.fc2.K / 32;
+      if (g_fmt_touch & 4) g.touch = make_touch(B.fc2, M, 4, gemm_lanes_per_xcd(M, g.N, g.K), 2);
+      st.push_back(gemm_stage(MS_FC1, g, 3, 4));
+    }
+    {
+      GemmArgs g = base_args(ws_hid(b), B.fc2, M);
+      g.ksplit = 4;
+      g.out_f32 = h->slab;
+      g.ldo = g.N;
+      g.slab_stride = (size_t)h->Mpad * g.N;
+      if (g_fmt_touch & 32) {
+        const unsigned lanes = gemm_lanes_per_xcd(M, g.N * 4, g.K / 4);
+        if (b + 1 < c.depth) g.touch = make_touch(h->blk[b + 1].qkv, M, 0, lanes, 2);
+        else g.touch = make_touch(h->final_lin, M, 0, lanes, 2, 1);
+      }
+      st.push_back(gemm_stage(MS_FC2, g, 3, 4));
+    }
+  }
+  {
+    const int nblk = (ntok + 15) / 16, seqs = bc;
+    MegaStage m = ln_stage(c.depth, 0, 4, h->blk[c.depth - 1].fc2.b, 0, nullptr, 0, h->hfin16, seqs * 16);
+    m.red_gate_off = (long long)(c.depth - 1) * 6 * D + 5LL * D;
+    st.push_back(m);
+    GemmArgs g = base_args(h->hfin16, h->final_lin, nblk * seqs * 16);
+    g.tokblk = 1;
+    g.nclip = 1;
+    g.bc = bc;
+    g.ntok = ntok;
+    g.n_prev = c.n_prev;
+    g.xcur = h->xcur;
+    g.xin16 = h->xin16;
+    g.ldx = h->Kx / 32;
+    st.push_back(gemm_stage(MS_HEAD, g, bc, 1));
+  }
+  for (const MegaStage& m : st) FH_REQUIRE(m.nblk <= (unsigned)kMegaWgs, "persistent kernel: a stage needs %u workgroups", m.nblk);
+  int rc;
+  if (!h->mega_sync && (rc = h->pool.alloc(&h->mega_sync, 32 * 20 + 2 * 3 * 64, true))) return rc;  // + stamps of <= 64 stages
+  if ((rc = h->pool.alloc(&P.dev, st.size(), false))) return rc;
+  FH_CHECK_HIP(hipMemcpy(P.dev, st.data(), st.size() * sizeof(MegaStage), hipMemcpyHostToDevice));
+  P.nstage = (int)st.size();
+  P.bc = bc;
+  P.ctx = MegaCtx{h->xres, h->qkv16, h->slab, (size_t)h->Mpad * D, M, D, ntok, h->Ntot, c.attn_window, c.heads, h->sat};
+  return FLOAT_OK;
+}
+
+template <class T>
+int run_mega(float_fmt* h, int bc, const float* modbuf, bool euler, float dt, float a, float r, float e, hipStream_t s, float* vout_to) {
+  float_fmt::MegaPlan& P = h->mega[bc];
+  MegaDyn d{modbuf, dt, a, r, e, euler ? 1 : 0, vout_to ? vout_to : h->vout};
+  hipEvent_t e0, e1;
+  if (fh_prof_pair(0, &e0, &e1))
+    hipExtLaunchKernelGGL((fmt_mega_kernel<T>), dim3(kMegaWgs), dim3(512), kMegaSmem, s, e0, e1, 0, P.dev, P.nstage, d, P.ctx, mega_sync_of(h));
+  else hipLaunchKernelGGL((fmt_mega_kernel<T>), dim3(kMegaWgs), dim3(512), kMegaSmem, s, P.dev, P.nstage, d, P.ctx, mega_sync_of(h));
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
 // Block chain of an evaluation on the rows staged in the workspace, using the modulations in modbuf.
 // euler: update xcur/xin16 with dt, else write vout.
 template <class T>
@@ -646,6 +829,11 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
   const float_fmt_cfg_t& c = h->cfg;
   const int D = h->D, ntok = h->ntok, M = nclip * bc * ntok;
   int rc;
+  if constexpr (!T::is32) {
+    if (bc <= 4 && mega_shape_ok<T>(h, nclip, bc)) {
+      if (h->mega[bc].dev) return run_mega<T>(h, bc, modbuf, euler, dt, a, r, e, s, vout_to);  // table built at create
+    }
+  }
   // x_embedder + pos_embed; the CFG rows share x, so 60 rows are computed and broadcast
   {
     GemmArgs g = base_args(h->xin16, h->x_embed, nclip * ntok);
@@ -1157,6 +1345,17 @@ static int debug_impl(float_fmt* h, int what, const float* in, float* out, hipSt
   if (what == 0) {
     return dev_copy(out, h->pos, (size_t)ntok * D, s);
   }
+  if (what == 2) {  // diagnostic builds (-DMEGA_STAMPS): per stage [start, body end, stores drained] of the persistent kernel's last launch, in us
+    FH_REQUIRE(h->mega_sync && h->mega[3].nstage > 0 && h->mega[3].nstage <= 64, "no persistent-kernel plan");
+    FH_CHECK_HIP(hipStreamSynchronize(s));
+    const int n = h->mega[3].nstage * 3;
+    std::vector<unsigned long long> st(n);
+    FH_CHECK_HIP(hipMemcpy(st.data(), h->mega_sync + 20 * 32, n * 8, hipMemcpyDeviceToHost));
+    std::vector<float> us(n);
+    for (int i = 0; i < n; ++i) us[i] = st[i] ? (float)((double)(st[i] - st[0]) * 0.01) : -1.f;  // 100 MHz
+    FH_CHECK_HIP(hipMemcpy(out, us.data(), n * 4, hipMemcpyHostToDevice));
+    return FLOAT_OK;
+  }
   FH_REQUIRE(what == 1 && in != nullptr, "float_fmt_debug: unknown request %d (or null input)", what);
   const int n = ntok * 3 * D;
   hipLaunchKernelGGL((fmt_dbg_to16_kernel<T>), dim3((n + 255) / 256), dim3(256), 0, s, h->qkv16, in, n);
@@ -1195,6 +1394,12 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
   h->attnproj = getenv("FLOAT_FMT_ATTNPROJ") ? atoi(getenv("FLOAT_FMT_ATTNPROJ")) : 0;
+  h->mega_on = getenv("FLOAT_FMT_MEGA") ? atoi(getenv("FLOAT_FMT_MEGA")) : 0;
+  {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) h->n_cu = ncu;
+    else (void)hipGetLastError();
+  }
   if (const char* v = getenv("FLOAT_FMT_HOIST")) g_fmt_hoist = atoi(v) != 0;
   if (const char* v = getenv("FLOAT_FMT_ZGROUP")) g_fmt_zgroup = std::max(0, atoi(v));
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
@@ -1261,6 +1466,12 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
       fh_set_error("hipMemcpy of FMT tables failed");
       rc = FLOAT_E_HIP;
     }
+  }
+  if (!rc && cfg->dtype != FLOAT_DT_FP32) {
+    // stage table of the persistent evaluation kernel for the 3-way CFG shape, built now: the first evaluation may already
+    // run under stream capture, where nothing can be allocated or copied
+    const bool ok = cfg->dtype == FLOAT_DT_BF16 ? mega_shape_ok<BF16>(h, 1, 3) : mega_shape_ok<FP16>(h, 1, 3);
+    if (ok) rc = cfg->dtype == FLOAT_DT_BF16 ? build_mega<BF16>(h, 3) : build_mega<FP16>(h, 3);
   }
   if (rc) {
     float_fmt_destroy(h);
@@ -1344,6 +1555,17 @@ int float_fmt_saturation(float_fmt_t* h, uint64_t* total, int32_t reset, void* s
   FH_CHECK_HIP(hipMemcpy(&v, h->sat, sizeof(v), hipMemcpyDeviceToHost));
   *total = v;
   if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(v)));
+  if (h->mega_sync) {  // the persistent kernel's barrier watchdog
+    unsigned err = 0;
+    FH_CHECK_HIP(hipMemcpy(&err, h->mega_sync + 18 * 32, sizeof(err), hipMemcpyDeviceToHost));
+    if (err) {
+      FH_CHECK_HIP(hipMemset(h->mega_sync + 18 * 32, 0, sizeof(err)));
+      h->mega_on = 0;  // the launch chain from here on
+      fh_set_error("fmt_mega_kernel: a grid barrier timed out (not all %d workgroups were resident) - the results of this call are "
+                   "invalid; the handle falls back to the launch chain (FLOAT_FMT_MEGA=0 selects it from the start)", 256);
+      return FLOAT_E_HIP;
+    }
+  }
   return FLOAT_OK;
 }
 

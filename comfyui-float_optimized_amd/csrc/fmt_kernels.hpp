@@ -15,11 +15,19 @@
 #include "common.hpp"
 #include "fmt_pack.hpp"
 
-template <class T, int MTW, int NT, int NW, int EPI>
-__global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
+// The kernel's body as a device function: `bid` of `nblk` workgroups (blockIdx.x of gridDim.x for the stand-alone launch, the
+// stage's virtual block for fmt_mega_kernel).  COH: the activations (A operand, residual stream) were produced earlier in the
+// same kernel -> coherent loads (fh_load16<true>), and every activation store writes through.
+template <class T, int MTW, int NT, int NW, int EPI, bool COH>
+__device__ __forceinline__ void fmt_gemm_body(const GemmArgs& g, const unsigned bid, const unsigned nblk) {
   constexpr int BN = NT * 16;
   constexpr int ROWS = MTW * 16;
-  constexpr bool WT = NW >= 8;  // the single-clip tilings (stacked clips split K over 4 waves): see common.hpp, FMT_WT
+  constexpr bool WT = NW >= 8 || COH;  // the single-clip tilings (stacked clips split K over 4 waves): see common.hpp, FMT_WT
+  // A operand: plain (L2-cached) loads also inside the persistent kernel.  There the operand lives in a buffer that is written
+  // exactly ONCE per launch (write-through) before its first read - no cache of any level can hold an older copy of it - and
+  // it is re-read by every column block of the XCD: as agent-scope (sc1) loads those re-reads all crossed the fabric
+  // (415 vs 320 us per evaluation).  The residual stream and the split-K slabs (read once, by one workgroup) stay coherent.
+  auto ldA = [](const typename T::elem* p) -> typename T::pack8 { return T::load8(p); };
   constexpr int NTHR = NW * 64;
   // k-steps of operands in flight per wave.  With 4 k-blocks per wave (K = 1024 over 8 waves) PF = 4 puts the whole
   // K slice in flight at once: one memory round trip instead of two for the 48x64 tilings (7 fragments per k-step,
@@ -35,7 +43,7 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
   // weights: give them consecutive slots on ONE XCD (ids congruent mod 8 share an XCD's L2).
   int bx, by, ks = 0;
   {
-    const int nbn = g.N / BN, id = blockIdx.x;
+    const int nbn = g.N / BN, id = (int)bid;
     const int nbx = (EPI == EPI_PARTIAL) ? nbn * g.ksplit : nbn;  // (column block, K slice) pairs
     if ((nbx & 7) == 0) {
       const int slot = id >> 3;
@@ -84,8 +92,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
     if (r < ROWS && row < g.M) {
       const float* o = g.out_f32 + (size_t)row * g.ldo + nb;
       const float* gt = g.gate + (size_t)row * g.ldg + nb;
-      res_pf[0] = *reinterpret_cast<const float4*>(o);
-      res_pf[1] = *reinterpret_cast<const float4*>(o + 4);
+      res_pf[0] = fh_load_f4<COH>(o);
+      res_pf[1] = fh_load_f4<COH>(o + 4);
       gate_pf[0] = *reinterpret_cast<const float4*>(gt);
       gate_pf[1] = *reinterpret_cast<const float4*>(gt + 4);
     }
@@ -98,14 +106,14 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) b[p][j] = T::load8_nt(Wp + j * tstride + (size_t)p * 512);
 #pragma unroll
-      for (int i = 0; i < MTW; ++i) a[p][i] = T::load8(Ap + i * tstride + (size_t)p * 512);
+      for (int i = 0; i < MTW; ++i) a[p][i] = ldA(Ap + i * tstride + (size_t)p * 512);
     }
   }
   // only the epilogue kinds whose launches are given a TouchSpec carry the code (2 registers, a branch)
   constexpr bool kTouch = (EPI == EPI_GELU_P16 || EPI == EPI_T16 || EPI == EPI_GATE_RES || EPI == EPI_PARTIAL);
   unsigned touched[2] = {0u, 0u};
   if constexpr (kTouch) {
-    if (g.touch.W) fmt_touch(g.touch, blockIdx.x & 7, (blockIdx.x >> 3) * NTHR + threadIdx.x, (gridDim.x >> 3) * NTHR, touched);
+    if (g.touch.W) fmt_touch(g.touch, bid & 7, (bid >> 3) * NTHR + threadIdx.x, (nblk >> 3) * NTHR, touched);
   }
   for (int kb0 = 0; kb0 < KBw; kb0 += PF) {
 #pragma unroll
@@ -121,7 +129,7 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
           for (int j = 0; j < NT; ++j)
             b[p][j] = T::load8_nt(Wp + j * tstride + (size_t)(kb + PF) * 512);
 #pragma unroll
-          for (int i = 0; i < MTW; ++i) a[p][i] = T::load8(Ap + i * tstride + (size_t)(kb + PF) * 512);
+          for (int i = 0; i < MTW; ++i) a[p][i] = ldA(Ap + i * tstride + (size_t)(kb + PF) * 512);
         }
       }
     }
@@ -216,8 +224,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
       }
       if constexpr (EPI == EPI_F32 || EPI == EPI_PARTIAL) {
         float* o = g.out_f32 + (size_t)ks * g.slab_stride + (size_t)row * g.ldo + nb;
-        fh_store_f4_wt<4, WT>(o, float4{v[0], v[1], v[2], v[3]});
-        fh_store_f4_wt<4, WT>(o + 4, float4{v[4], v[5], v[6], v[7]});
+        fh_store_f4_wt<fh_site<COH>(4), WT>(o, float4{v[0], v[1], v[2], v[3]});
+        fh_store_f4_wt<fh_site<COH>(4), WT>(o + 4, float4{v[4], v[5], v[6], v[7]});
       } else if constexpr (EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16 || EPI == EPI_GELUERF_P16) {
         P8 u;
 #pragma unroll
@@ -230,8 +238,8 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         }
         fh_track_pack<T>(rm, u);
         E* const o16 = reinterpret_cast<E*>(g.out16);
-        if constexpr (EPI == EPI_T16) T::template store8_wt<8, WT>(o16 + (size_t)row * g.ldo16 + nb, u);
-        else T::template store8_wt<8, WT>(o16 + fmt_pack_off(row, nb, g.ldo16), u);
+        if constexpr (EPI == EPI_T16) T::template store8_wt<fh_site<COH>(8), WT>(o16 + (size_t)row * g.ldo16 + nb, u);
+        else T::template store8_wt<fh_site<COH>(8), WT>(o16 + fmt_pack_off(row, nb, g.ldo16), u);
       } else if constexpr (EPI == EPI_GATE_RES) {
         float* o = g.out_f32 + (size_t)row * g.ldo + nb;
         const float* gt = g.gate + (size_t)row * g.ldg + nb;
@@ -242,14 +250,14 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
             x = res_pf[e / 4];
             gg = gate_pf[e / 4];
           } else {
-            x = *reinterpret_cast<const float4*>(o + e);
+            x = fh_load_f4<COH>(o + e);
             gg = *reinterpret_cast<const float4*>(gt + e);
           }
           x.x += gg.x * v[e + 0];
           x.y += gg.y * v[e + 1];
           x.z += gg.z * v[e + 2];
           x.w += gg.w * v[e + 3];
-          fh_store_f4_wt<16, WT>(o + e, x);
+          fh_store_f4_wt<fh_site<COH>(16), WT>(o + e, x);
         }
       } else if constexpr (EPI == EPI_XEMBED) {
         // input row = clip * ntok + token (the CFG rows of a clip share x); output rows (clip * bc + b2) * ntok + token
@@ -259,13 +267,18 @@ __global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
         for (int i = 0; i < 8; ++i) v[i] += ps[i];
         for (int b2 = 0; b2 < g.bc; ++b2) {
           float* o = g.out_f32 + (size_t)((q * g.bc + b2) * g.ntok + tok) * g.ldo + nb;
-          fh_store_f4_wt<32, WT>(o, float4{v[0], v[1], v[2], v[3]});
-          fh_store_f4_wt<32, WT>(o + 4, float4{v[4], v[5], v[6], v[7]});
+          fh_store_f4_wt<fh_site<COH>(32), WT>(o, float4{v[0], v[1], v[2], v[3]});
+          fh_store_f4_wt<fh_site<COH>(32), WT>(o + 4, float4{v[4], v[5], v[6], v[7]});
         }
       }
     }
   }
   if constexpr (EPI == EPI_CFG || EPI == EPI_T16 || EPI == EPI_SILU_P16 || EPI == EPI_GELU_P16 || EPI == EPI_GELUERF_P16) fh_range_flush<T>(g.sat, rm);
+}
+
+template <class T, int MTW, int NT, int NW, int EPI>
+__global__ __launch_bounds__(NW * 64) void fmt_gemm_kernel(GemmArgs g) {
+  fmt_gemm_body<T, MTW, NT, NW, EPI, false>(g, blockIdx.x, gridDim.x);
 }
 
 // Wide-N variant for the fused adaLN projection (N = depth*6D + 2D = 51 200, K = D): here re-reading
@@ -681,26 +694,30 @@ struct LnRed {
 
 constexpr int kLnTouch = 6;  // lines per lane: 192 single-wave workgroups cover 8 XCDs x 1 MB (fc1) with 6
 
-template <class T, int NV, int KS, bool TOUCH, bool WT>
-__global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, int M, const float* __restrict__ shift,
-                                                        const float* __restrict__ scale, int ldm, u16* __restrict__ out,
-                                                        LnRed red, TouchSpec pf, int ntok, int perm, unsigned long long* sat) {
+// Body: workgroup `bid` of `nblk`, `wpb` waves per workgroup AS THE ROW MAPPING SEES IT (1 = one row per workgroup, the
+// XCD-grouped mapping; fmt_mega_kernel calls it with the first wave of its 8-wave workgroups).  COH as in fmt_gemm_body.
+template <class T, int NV, int KS, bool TOUCH, bool WT_, bool COH>
+__device__ __forceinline__ void fmt_lnmod_body(float* __restrict__ x, int M, const float* __restrict__ shift,
+                                               const float* __restrict__ scale, int ldm, u16* __restrict__ out, const LnRed& red,
+                                               const TouchSpec& pf, int ntok, int perm, unsigned long long* sat, const unsigned bid,
+                                               const unsigned nblk, const int wpb) {
   constexpr int D = NV * 256;
+  constexpr bool WT = WT_ || COH;
   const int lane = threadIdx.x & 63;
-  int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  int row = bid * wpb + (threadIdx.x >> 6);
   unsigned touched[kLnTouch] = {};
-  const unsigned tfirst = (blockIdx.x >> 3) * 64 + lane, tstride = (gridDim.x >> 3) * 64;
-  const bool touch = TOUCH && blockDim.x == 64;
-  if (blockDim.x == 64) {
+  const unsigned tfirst = (bid >> 3) * 64 + lane, tstride = (nblk >> 3) * 64;
+  const bool touch = TOUCH && wpb == 1;
+  if (wpb == 1) {
     // One row per workgroup: a 128-byte line of the packed output holds the 16-byte pieces of 8 consecutive rows, so give
     // those 8 rows to workgroups of ONE XCD (ids congruent mod 8 share an XCD's L2, where the pieces merge into full lines
     // before they are written back; ablation: the stores cost 1 of the kernel's 4.7 us when 8 XCDs each owned a piece).
-    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int x = bid & 7, j = bid >> 3;
     row = (((j >> 3) * 8 + x) << 3) + (j & 7);
   }
   if (row >= M) {
     if (touch) {
-      fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);
+      fmt_touch(pf, bid & 7, tfirst, tstride, touched);
       fmt_touch_retire(touched);
     }
     return;
@@ -713,22 +730,22 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
-    v[i] = *reinterpret_cast<const float4*>(xr + c);
+    v[i] = fh_load_f4<COH>(xr + c);
     a[i] = *reinterpret_cast<const float4*>(sh + c);
     b[i] = *reinterpret_cast<const float4*>(sc + c);
   }
-  if (KS == 0 && touch) fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);  // behind the row's own loads (in-order retirement)
+  if (KS == 0 && touch) fmt_touch(pf, bid & 7, tfirst, tstride, touched);  // behind the row's own loads (in-order retirement)
   if constexpr (KS > 0) {
     float4 p[KS][NV], gt[NV], bi[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int c = i * 256 + lane * 4;
 #pragma unroll
-      for (int k = 0; k < KS; ++k) p[k][i] = *reinterpret_cast<const float4*>(red.slab + k * red.slab_stride + (size_t)row * D + c);
+      for (int k = 0; k < KS; ++k) p[k][i] = fh_load_f4<COH>(red.slab + k * red.slab_stride + (size_t)row * D + c);
       gt[i] = *reinterpret_cast<const float4*>(red.gate + (size_t)row * ldm + c);
       bi[i] = *reinterpret_cast<const float4*>(red.bias + c);
     }
-    if (touch) fmt_touch(pf, blockIdx.x & 7, tfirst, tstride, touched);
+    if (touch) fmt_touch(pf, bid & 7, tfirst, tstride, touched);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       float4 t = p[0][i];
@@ -743,7 +760,7 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
       v[i].y += gt[i].y * (t.y + bi[i].y);
       v[i].z += gt[i].z * (t.z + bi[i].z);
       v[i].w += gt[i].w * (t.w + bi[i].w);
-      fh_store_f4_wt<1, WT>(xr + i * 256 + lane * 4, v[i]);
+      fh_store_f4_wt<fh_site<COH>(1), WT>(xr + i * 256 + lane * 4, v[i]);
     }
   }
 #pragma unroll
@@ -767,12 +784,20 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
-    fh_store4_wt<T, 1, WT>(reinterpret_cast<typename T::elem*>(out) + fmt_pack_off(orow, c, D / 32),
+    fh_store4_wt<T, fh_site<COH>(1), WT>(reinterpret_cast<typename T::elem*>(out) + fmt_pack_off(orow, c, D / 32),
               (v[i].x - mu) * rstd * (1.f + b[i].x) + a[i].x, (v[i].y - mu) * rstd * (1.f + b[i].y) + a[i].y,
               (v[i].z - mu) * rstd * (1.f + b[i].z) + a[i].z, (v[i].w - mu) * rstd * (1.f + b[i].w) + a[i].w, rm);
   }
   fh_range_flush<T>(sat, rm);
   if (touch) fmt_touch_retire(touched);
+}
+
+template <class T, int NV, int KS, bool TOUCH, bool WT>
+__global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, int M, const float* __restrict__ shift,
+                                                        const float* __restrict__ scale, int ldm, u16* __restrict__ out,
+                                                        LnRed red, TouchSpec pf, int ntok, int perm, unsigned long long* sat) {
+  fmt_lnmod_body<T, NV, KS, TOUCH, WT, false>(x, M, shift, scale, ldm, out, red, pf, ntok, perm, sat, blockIdx.x, gridDim.x,
+                                              (int)(blockDim.x >> 6));
 }
 
 // Banded attention (FMT.py:71-88 with the mask of FMT.py:15-19): query i sees keys |i-j| <= window.
@@ -782,21 +807,26 @@ __global__ __launch_bounds__(256) void fmt_lnmod_kernel(float* __restrict__ x, i
 // per query this is 0.3 % of the evaluation's flops - MFMA/LDS tiling would only add latency - so q/k/v come straight from
 // L2.  For window <= 2 every load of the query's band is issued before the first use (one memory round trip); wider
 // windows loop.  Output is written in the packed A-operand order of the proj GEMM (K = D).
-template <class T, int LPQ, bool TOUCH, bool WT>
-__global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ntok,
-                                                       int M, int D, int window, TouchSpec pf, unsigned long long* sat) {
+// Body: head `h`, run `run` of `qpw` queries (nthr = qpw * LPQ threads take part), `lin` of `nwg` workgroups for the touch.
+template <class T, int LPQ, bool TOUCH, bool WT_, bool COH>
+__device__ __forceinline__ void fmt_attn_body(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ntok, int M, int D,
+                                              int window, const TouchSpec& pf, unsigned long long* sat, const int h, const int run,
+                                              const int nthr, const unsigned lin, const unsigned nwg) {
   constexpr int HD = 128, PD = HD / LPQ, NU = PD / 8;
+  constexpr bool WT = WT_ || COH;
+  auto ld8 = [](const typename T::elem* p) -> typename T::pack8 {
+    if constexpr (COH && !T::is32) return fh_load16<true>(p);
+    else return T::load8(p);
+  };
   // blockIdx.x = head, blockIdx.y = run of blockDim.x / LPQ consecutive ROWS of the (cfg rows x tokens) batch: with 8 rows per
   // workgroup the run is one 8-row group of the packed output, whose 128-byte lines then come whole from a single wave
-  const int h = blockIdx.x;
-  const int row_ = blockIdx.y * (blockDim.x / LPQ) + threadIdx.x / LPQ, part = threadIdx.x % LPQ;
+  const int row_ = run * (nthr / LPQ) + threadIdx.x / LPQ, part = threadIdx.x % LPQ;
   unsigned touched[2] = {0u, 0u};
   // issued BEHIND the wave's own q / k / v loads (memory operations retire in order: in front of them, the wave would wait
   // for the touched HBM lines before it could use operands that come from the Infinity Cache)
   auto touch = [&]() {
     if constexpr (TOUCH) {
-      const unsigned lin = blockIdx.x + gridDim.x * blockIdx.y, nwg = gridDim.x * gridDim.y;
-      fmt_touch(pf, lin & 7, (lin >> 3) * blockDim.x + threadIdx.x, (nwg >> 3) * blockDim.x, touched);
+      fmt_touch(pf, lin & 7, (lin >> 3) * nthr + threadIdx.x, (nwg >> 3) * nthr, touched);
     }
   };
   if (row_ >= M) {  // whole LPQ-lane groups leave together
@@ -813,7 +843,7 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
   float qf[PD], o[PD];
 #pragma unroll
   for (int u = 0; u < NU; ++u) {
-    const P8 uu = T::load8(base + (size_t)qi * ld + u * 8);
+    const P8 uu = ld8(base + (size_t)qi * ld + u * 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[u * 8 + j] = T::get(uu, j) * scale;
   }
@@ -848,8 +878,8 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
       const E* kp = base + (size_t)kj * ld + D;
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        kk[t][u] = T::load8(kp + u * 8);
-        vv[t][u] = T::load8(kp + D + u * 8);
+        kk[t][u] = ld8(kp + u * 8);
+        vv[t][u] = ld8(kp + D + u * 8);
       }
     }
     touch();
@@ -867,8 +897,8 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
       P8 k[NU], v[NU];
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
-        k[u] = T::load8(kp + u * 8);
-        v[u] = T::load8(kp + D + u * 8);
+        k[u] = ld8(kp + u * 8);
+        v[u] = ld8(kp + D + u * 8);
       }
       fold(k, v, kj >= 0 && kj < ntok);
     }
@@ -882,10 +912,17 @@ __global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ q
 #pragma unroll
     for (int j = 0; j < 8; ++j) T::set(uo, j, o[u * 8 + j] * inv);
     fh_track_pack<T>(rm, uo);
-    T::template store8_wt<2, WT>(reinterpret_cast<E*>(out) + fmt_pack_off(row, d0 + u * 8, D / 32), uo);
+    T::template store8_wt<fh_site<COH>(2), WT>(reinterpret_cast<E*>(out) + fmt_pack_off(row, d0 + u * 8, D / 32), uo);
   }
   fh_range_flush<T>(sat, rm);
   if constexpr (TOUCH) fmt_touch_retire(touched);
+}
+
+template <class T, int LPQ, bool TOUCH, bool WT>
+__global__ __launch_bounds__(512) void fmt_attn_kernel(const u16* __restrict__ qkv, int ld, u16* __restrict__ out, int ntok,
+                                                       int M, int D, int window, TouchSpec pf, unsigned long long* sat) {
+  fmt_attn_body<T, LPQ, TOUCH, WT, false>(qkv, ld, out, ntok, M, D, window, pf, sat, blockIdx.x, blockIdx.y, blockDim.x,
+                                          blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
 }
 
 // Banded attention AND attn.proj in one launch (FMT.py:71-89): attention is per head, the projection sums over heads, so a
@@ -1092,6 +1129,184 @@ __global__ __launch_bounds__(512) void fmt_attnproj_kernel(const u16* __restrict
     // non-temporal: the slabs are read once, by the LayerNorm launch, from other XCDs (80.8 vs 81.4 ms per 250 evaluations with plain stores)
     if (row < g.M) __builtin_nontemporal_store(acc[i], reinterpret_cast<f32x4*>(outp + (size_t)row * g.ldo));
   }
+}
+
+// ------------------------------------------------------------------------------------------
+// ONE evaluation of the step chain as ONE persistent kernel (fmt_mega_kernel): x-embed, 8 x [LN, qkv, attention, proj, LN,
+// fc1, fc2], LN, head = 59 stages that were 59 dependent launches.  The stages are the SAME bodies (fmt_gemm_body /
+// fmt_lnmod_body / fmt_attn_body: same tilings, same arithmetic, bit for bit the launch chain's results); what changes is how
+// they meet: 256 workgroups (one per CU, all resident) pass a grid barrier between stages instead of a kernel boundary.
+// MEASURED (round 4, MI355X, one box): 375 us per evaluation against 322 for the launch chain - it LOSES, so it is opt-in
+// (FLOAT_FMT_MEGA=1) and the launch chain stays the default.  In-kernel stamps (-DMEGA_STAMPS, tools/probes/mega_stamps.py), us
+// per stage: bodies LN 2.7 / qkv 3.9 / attention 2.6 / proj 2.8 / fc1 5.5 / fc2 4.6 (the launch chain's kernels minus ~2.5 us
+// of boundary: 2.2 / 2.9 / 2.2 / 2.4 / 4.9 / 4.4), + 0.4-1.7 draining the write-through stores, + 1.6-2.5 in the barrier:
+// the software hand-off costs what the hardware's launch boundary costs, the bodies pay for coherent loads and sc1 stores,
+// and a 256 x 512-thread launch adds ~29 us per evaluation (workgroup dispatch skew ~6 us at the first stage).
+// Probes (tools/probes/grid_barrier.hip): hierarchical in-kernel barrier 2.1 us, 2.8 us with a stage's data exchanged through
+// sc1 stores / loads; agent-scope release / acquire FENCES (buffer_wbl2 / buffer_inv) 31 us, buffer_inv sc1 alone 4-9 us -
+// so the kernel never fences: every activation store of a stage writes through (sc1), a
+// workgroup drains its stores (s_waitcnt vmcnt(0)) before it arrives, and every activation load of the next stage is an
+// agent-scope load (COH = true).  Weights, biases and modulations are read-only for the whole kernel: plain loads.
+// Barrier: 8 group counters (workgroups congruent mod 8 = one XCD, 32 arrivals each on their own 128-byte line), the last
+// arriver of a group bumps a top counter, the last of those writes the generation into 8 per-group release words that the
+// waiters poll - three dependent memory round trips instead of 256 serialized atomics on one line.  Counters only ever count
+// up: generation = launches so far (a device word read at kernel start, bumped by workgroup 0 at the end) x barriers per
+// launch + stage, so a hipGraph can replay the same launch.  A waiter that does not see its release within ~0.3 s (a CU was
+// not available, so not all workgroups are resident) sets the error word and leaves; the host reports it
+// (float_fmt_saturation / the next call) instead of hanging the GPU.
+enum { MS_XEMBED = 0, MS_LN, MS_QKV, MS_ATTN, MS_PROJ, MS_FC1, MS_FC2, MS_HEAD };
+struct MegaStage {
+  int kind;
+  unsigned nblk;                 // workgroups with work in this stage (the rest only pass the barrier)
+  GemmArgs g;                    // GEMM stages; gate / head fields are patched per launch
+  long long gate_off;            // MS_PROJ: gate = mod + gate_off
+  long long shift_off, scale_off, red_gate_off;  // MS_LN: modulation rows / gate of the folded split-K GEMM, from `mod`
+  int ks;                        // MS_LN: slabs folded first (0 / 4)
+  const float* red_bias;
+  u16* ln_out;
+  int perm;
+  TouchSpec pf;                  // MS_LN / MS_ATTN: weights of the next GEMM to pull into L2
+  u16* att_out;                  // MS_ATTN: this block's attention output (A operand of its proj: a write-once buffer)
+};
+struct MegaCtx {                 // per handle and CFG shape
+  float* xres;
+  const u16* qkv16;
+  const float* slab;
+  size_t slab_stride;
+  int M, D, ntok, ldm, window, heads;
+  unsigned long long* sat;
+};
+struct MegaDyn {                 // per launch
+  const float* mod;
+  float dt, a, r, e;
+  int euler;
+  float* vout;
+};
+struct MegaSync {
+  unsigned* grp;   // [8] x 32 words
+  unsigned* top;   // [1]
+  unsigned* rel;   // [8] x 32 words
+  unsigned* seq;   // launches so far
+  unsigned* err;   // != 0: a barrier timed out
+  unsigned long long* stamps;  // diagnostic builds (-DMEGA_STAMPS): [stage][3] s_memrealtime of workgroup `stamp_wg`
+  unsigned stamp_wg;
+};
+
+// (A flat form - every workgroup adds 1 to its group's counter and polls all 8 counters, two dependent round trips instead of
+// four - measured WORSE: 2.4-4.0 us per barrier against 1.6-2.5, 256 pollers x 8 lines.)  Called by thread 0.
+__device__ __forceinline__ bool fmt_grid_barrier(const MegaSync& sy, unsigned gen, unsigned nwg) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  const unsigned g = blockIdx.x & 7u, per = nwg >> 3;
+  const unsigned old = __hip_atomic_fetch_add((gu32*)(sy.grp + g * 32), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (old + 1u == gen * per) {
+    const unsigned t = __hip_atomic_fetch_add((gu32*)sy.top, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1u == gen * 8u) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) __hip_atomic_store((gu32*)(sy.rel + i * 32), gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  unsigned spins = 0;
+  while ((int)(__hip_atomic_load((gu32*)(sy.rel + g * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen) < 0) {
+    if (++spins > (1u << 18) || ((spins & 63u) == 0u && __hip_atomic_load((gu32*)sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+      __hip_atomic_store((gu32*)sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  return true;
+}
+
+template <class T>
+__global__ __launch_bounds__(512) void fmt_mega_kernel(const MegaStage* __restrict__ tab, int nstage, MegaDyn d, MegaCtx c,
+                                                       MegaSync sy) {
+  typedef __attribute__((address_space(1))) unsigned int gu32;
+  __shared__ unsigned s_flag[2];
+  const unsigned bid = blockIdx.x, nwg = gridDim.x;
+  if (threadIdx.x == 0) {
+    s_flag[0] = __hip_atomic_load((gu32*)sy.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_flag[1] = 1u;
+  }
+  __syncthreads();
+  const unsigned seq0 = s_flag[0];
+  const unsigned gen0 = seq0 * (unsigned)(nstage - 1);
+#ifdef MEGA_STAMPS
+#define MEGA_STAMP(k) do { if (sy.stamps && bid == sy.stamp_wg && threadIdx.x == 0) sy.stamps[s * 3 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define MEGA_STAMP(k) do { } while (0)
+#endif
+  for (int s = 0; s < nstage; ++s) {
+    const MegaStage& st = tab[s];
+    MEGA_STAMP(0);
+    if (bid < st.nblk) {
+      switch (st.kind) {
+        case MS_XEMBED:
+          fmt_gemm_body<T, 4, 1, 8, EPI_XEMBED, true>(st.g, bid, st.nblk);
+          break;
+        case MS_LN:
+          if (threadIdx.x < 64) {
+            const LnRed red{c.slab, c.slab_stride, st.red_bias, d.mod + st.red_gate_off};
+            if (st.ks == 0)
+              fmt_lnmod_body<T, 4, 0, true, true, true>(c.xres, c.M, d.mod + st.shift_off, d.mod + st.scale_off, c.ldm, st.ln_out, red,
+                                                        st.pf, c.ntok, st.perm, c.sat, bid, st.nblk, 1);
+            else
+              fmt_lnmod_body<T, 4, 4, true, true, true>(c.xres, c.M, d.mod + st.shift_off, d.mod + st.scale_off, c.ldm, st.ln_out, red,
+                                                        st.pf, c.ntok, st.perm, c.sat, bid, st.nblk, 1);
+          }
+          break;
+        case MS_QKV:
+          fmt_gemm_body<T, 3, 4, 8, EPI_T16, true>(st.g, bid, st.nblk);
+          break;
+        case MS_ATTN:
+          if (threadIdx.x < 128)
+            fmt_attn_body<T, 16, true, true, true>(c.qkv16, 3 * c.D, st.att_out, c.ntok, c.M, c.D, c.window, st.pf, c.sat,
+                                                   (int)(bid % (unsigned)c.heads), (int)(bid / (unsigned)c.heads), 128, bid, st.nblk);
+          break;
+        case MS_PROJ: {
+          GemmArgs g = st.g;
+          g.gate = d.mod + st.gate_off;
+          fmt_gemm_body<T, 3, 1, 8, EPI_GATE_RES, true>(g, bid, st.nblk);
+          break;
+        }
+        case MS_FC1:
+          fmt_gemm_body<T, 3, 4, 8, EPI_GELU_P16, true>(st.g, bid, st.nblk);
+          break;
+        case MS_FC2:
+          fmt_gemm_body<T, 3, 4, 8, EPI_PARTIAL, true>(st.g, bid, st.nblk);
+          break;
+        default: {  // MS_HEAD
+          GemmArgs g = st.g;
+          g.a_cfg = d.a;
+          g.r_cfg = d.r;
+          g.e_cfg = d.e;
+          g.dt = d.dt;
+          if (!d.euler) {
+            g.xcur = nullptr;
+            g.xin16 = nullptr;
+            g.vout = d.vout;
+          }
+          fmt_gemm_body<T, 3, 1, 8, EPI_CFG, true>(g, bid, st.nblk);
+          break;
+        }
+      }
+    }
+    MEGA_STAMP(1);
+    if (s + 1 < nstage) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's write-through stores have left
+      __syncthreads();
+      MEGA_STAMP(2);
+      if (threadIdx.x == 0) {
+        // the next stage's descriptor (5 lines of the table) into the scalar cache while the barrier is awaited (-0.3 us per stage)
+        int pre = 0;
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(MegaStage) + 63) / 64; ++i) pre ^= reinterpret_cast<const int*>(&tab[s + 1])[i * 16];
+        asm volatile("" ::"s"(pre));
+        if (!fmt_grid_barrier(sy, gen0 + (unsigned)s + 1u, nwg)) s_flag[1] = 0u;
+      }
+      __syncthreads();
+      if (s_flag[1] == 0u) return;
+    }
+  }
+  if (bid == 0 && threadIdx.x == 0) __hip_atomic_store((gu32*)sy.seq, seq0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Condition rows for c_embedder: [wr | wa | we | 0-pad] per (cfg row b, token i) with the CFG nulling

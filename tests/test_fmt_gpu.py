@@ -192,3 +192,21 @@ def test_fmt_saturation_counter_fires():
         n = fmt.saturation(reset=True)
         print(dtype, "clamped-store threads with |x| = 1e6:", n)
         assert (n > 0) == expect and fmt.saturation() == 0
+
+
+def test_persistent_evaluation_kernel(monkeypatch):
+    """FLOAT_FMT_MEGA=1: the 59 stages of an evaluation as ONE persistent kernel with in-kernel grid barriers (write-through
+    stores, coherent loads, no fences) instead of 59 dependent launches.  Same stage bodies, so it agrees with the launch chain
+    to rounding (x-embed splits K over 8 waves instead of 4), holds the goldens, is bitwise reproducible, and its barrier
+    watchdog stays silent (float_fmt_saturation returns an error if a barrier timed out)."""
+    g = golden("fmt_sample_full_static")
+    cfg = C.FmtConfig()
+    sd, chain = _fmt(cfg, g["seed"], "fp16")
+    ref = chain.sample(g["r_s"], g["wa"], g["we"], g["noise"], g["nfe"], g["a"], 1.0, g["e"]).cpu()
+    monkeypatch.setenv("FLOAT_FMT_MEGA", "1")
+    sd, mega = _fmt(cfg, g["seed"], "fp16")
+    a = mega.sample(g["r_s"], g["wa"], g["we"], g["noise"], g["nfe"], g["a"], 1.0, g["e"]).cpu()
+    b = mega.sample(g["r_s"], g["wa"], g["we"], g["noise"], g["nfe"], g["a"], 1.0, g["e"]).cpu()
+    print("persistent kernel vs launch chain rel-L2 %.3e, vs reference %.3e" % (rel_l2(a, ref), rel_l2(a, g["r_d"])))
+    assert torch.equal(a, b) and rel_l2(a, ref) < 5e-4 and rel_l2(a, g["r_d"]) < TOL["fp16"]
+    assert mega.saturation() == 0  # also raises if the barrier watchdog fired
