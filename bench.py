@@ -105,6 +105,27 @@ def launch_ranks(n):
     sys.exit(0)
 
 
+class stdout_to_stderr:
+    """RCCL prints a banner (ROCm version / hostname / library path) on the C-level stdout when the first communicator comes
+    up; the driver reads ONE JSON line from this process's stdout, so file descriptor 1 points at stderr meanwhile."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        try:  # the banner sits in libc's buffer (stdout is a pipe: fully buffered): push it out while fd 1 still is stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
 def source_hash():
     """Identity of the kernels a profile summary belongs to: sha256 over the HIP sources of the profiled kernel classes - the
     FMT and decoder operators and what they share (the GPU box has no .git; the encoder / audio operators have no counters)."""
@@ -178,10 +199,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group(backend)
         if dist.get_world_size() != world:
             raise RuntimeError("rendezvous gave %d ranks, expected %d" % (dist.get_world_size(), world))
     elif backend == "nccl" and os.environ.get("FLOAT_BENCH_RCCL1", "1") != "0":
@@ -189,20 +211,22 @@ def main():
         # run on the box at least once; a failure here is reported on the line, it does not fail the single-GPU measurement
         try:
             import torch.distributed as dist
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=dev)
+            with stdout_to_stderr():
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1, device_id=dev)
         except Exception as e:  # noqa: BLE001
             rccl_note = "RCCL one-rank communicator failed: %s" % (str(e).splitlines()[0][:200],)
             dist = None
     if dist is not None and backend == "nccl":
         # ranks as RCCL itself counts them: all_reduce of ones on the device, plus the other two collectives of
         # distributed.py (all_gather of boundary latents, broadcast of the chain) on tensors of their real sizes
-        ones = torch.ones(1, device=dev)
-        dist.all_reduce(ones)
-        tail = torch.zeros(2, 10, 512, device=dev)
-        gathered = [torch.empty_like(tail) for _ in range(dist.get_world_size())]
-        dist.all_gather(gathered, tail)
-        dist.broadcast(tail, src=0)
-        torch.cuda.synchronize()
+        with stdout_to_stderr():  # the communicator (and its banner) comes up with the first collective
+            ones = torch.ones(1, device=dev)
+            dist.all_reduce(ones)
+            tail = torch.zeros(2, 10, 512, device=dev)
+            gathered = [torch.empty_like(tail) for _ in range(dist.get_world_size())]
+            dist.all_gather(gathered, tail)
+            dist.broadcast(tail, src=0)
+            torch.cuda.synchronize()
         rccl_ranks = int(ones.item())
 
     pkg = load_pkg()

@@ -198,6 +198,10 @@ int raise_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, NTv, TYv, TXv>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3)
 #undef CONV16_ATTR
+  if constexpr (!T::is32) {  // the double-buffered form (FLOAT_DEC_CONV_DB): two buffer sets, up to 115 KB
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, 4, 3, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, 2, 3, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+  }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zconv4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -485,10 +489,21 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
       g.ncb = (unsigned)(s.cout / bn);
       grid = dim3(g.ngroups * g.ncb + g.ct.nwg, 1);
     }
+    // FLOAT_DEC_CONV_DB bit mask: 1 = double-buffered LDS for the 64-channel tiles, 2 = for the 32-channel tiles (A/B switch)
+    static const int db_env = env_int("FLOAT_DEC_CONV_DB", 0, 0, 3);
+    const bool db = !T::is32 && ((bn == 64 && (db_env & 1)) || (bn == 32 && (db_env & 2)));
 #define CONV16(NTv, TYv, TXv)                                                                                    \
   if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv) {                                                       \
-    if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
-    else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);                  \
+    if constexpr (!T::is32) {                                                                                     \
+      if (db) {                                                                                                   \
+        if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv, 1>), grid, dim3(256), 2 * smem, st, e0, e1, 0, g); \
+        else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv, 1>), grid, dim3(256), 2 * smem, st, g);      \
+      }                                                                                                           \
+    }                                                                                                             \
+    if (!db) {                                                                                                    \
+      if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
+      else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);                \
+    }                                                                                                             \
   }
     CONV16(4, 3, 3) CONV16(2, 3, 3)
 #undef CONV16

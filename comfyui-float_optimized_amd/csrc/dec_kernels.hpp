@@ -809,8 +809,12 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv_kernel(ConvArgs
 //     depends on the halo column only, so fragment rows differ by a constant), one offset for the stores - tiles are decoded
 //     by carrying (f, ty, tx) along instead of dividing, interior tiles load without any bounds logic, border tiles take one
 //     4-bit mask per chunk (top / bottom / left / right halo membership, formed once) against the tile's border bits.
-template <class T, int NT, int TY, int TX>
-__global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvArgs g) {
+// DB = 1 (round 4, review item 2a): the halo tile, the weight slab and the epilogue operands are DOUBLE-BUFFERED in LDS: item
+// i + 1 is written into the other buffer while item i is multiplied (the writes are spread between the three tap-column
+// groups of MFMAs), and the K loop has ONE barrier per item instead of two.  115 KB of LDS at 64 output channels: one
+// workgroup per CU instead of two.  Bitwise the same results.  MEASURED: see DESIGN.md section 7 (FLOAT_DEC_CONV_DB selects it).
+template <class T, int NT, int TY, int TX, int DB = 0>
+__global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kernel(ConvArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
   DEC_PH_BEGIN
   typedef typename T::elem E;
@@ -824,6 +828,7 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
   unsigned char* const sA = smem;              // [NPIX][RB], chunk ^ ((halo column >> 1) & 3)
   unsigned char* const sB = smem + NPIX * RB;  // [NTAPS][BN][RB], chunk ^ ((row >> 1) & 3)
   float* const sE = reinterpret_cast<float*>(sB + NBROWS * RB);  // [3][BN]: demod, bias, next style of the tile's (frame, channels)
+  constexpr int BUF = NPIX * RB + NBROWS * RB + 3 * BN * (int)sizeof(float);  // DB: the second buffer set follows the first
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave index is uniform: scalar arithmetic
   const int r16 = lane & 15, q = lane >> 4;
   const int Wi = g.Wi, Cin = g.Cin;
@@ -933,100 +938,234 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv16_kernel(ConvAr
   bool first = true;
   issue();
   DEC_PH(8);
-  for (int item = 0; item < nitems; ++item) {
-    __syncthreads();  // every wave is done reading the previous item's tiles
-    if (s_edge == 0u) {
+  if constexpr (DB) {
+    // write the staged registers (item `it`) into buffer set `bs`, in three parts: part 0 = halo tile, 1 = weights, 2 = epilogue operands
+    const bool wdb = nchunks > 1;  // one chunk per tile: the weight slab is staged once and shared by both buffer sets
+    auto commit = [&](int bs, int part, bool wfirst, bool lastchunk) {
+      unsigned char* const dA = sA + bs * BUF;
+      unsigned char* const dB = sB + (wdb ? bs * BUF : 0);
+      if (part == 0) {
+        if (s_edge == 0u) {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ra[i];
-    } else {
+          for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(dA + a_lds[i]) = ra[i];
+        } else {
 #pragma unroll
-      for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ((s_hit >> (4 * i)) & 15u) ? T::zero8() : ra[i];
+          for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(dA + a_lds[i]) = ((s_hit >> (4 * i)) & 15u) ? T::zero8() : ra[i];
+        }
+      } else if (part == 1) {
+        if (wdb || wfirst) {
+#pragma unroll
+          for (int i = 0; i < NB - 1; ++i) *reinterpret_cast<P8*>(dB + b_lds + i * 64 * RB) = rb[i];
+          *reinterpret_cast<P8*>(dB + b_lds_l) = rb[NB - 1];
+        }
+      } else {
+        if (lastchunk && tid < 3 * BN / 4) *reinterpret_cast<float4*>(reinterpret_cast<unsigned char*>(sE) + bs * BUF + tid * 16) = re;
+      }
+    };
+    // chunk index of the item being STAGED (issue() advanced schunk already): the item whose registers are pending
+    int pchunk = 0;  // chunk of the pending (loaded, not yet committed) item
+    commit(0, 0, true, nchunks == 1);
+    commit(0, 1, true, nchunks == 1);
+    commit(0, 2, true, nchunks == 1);
+    if (nitems > 1) {
+      pchunk = nchunks > 1 ? 1 : 0;
+      issue();
     }
-    if (nchunks > 1 || first) {
-#pragma unroll
-      for (int i = 0; i < NB - 1; ++i) *reinterpret_cast<P8*>(sB + b_lds + i * 64 * RB) = rb[i];
-      *reinterpret_cast<P8*>(sB + b_lds_l) = rb[NB - 1];
-      first = false;
-    }
-    if (chunk == nchunks - 1 && tid < 3 * BN / 4) *reinterpret_cast<float4*>(sE + tid * 4) = re;
     __syncthreads();
-    DEC_PH(9);
-    if (item + 1 < nitems) issue();  // in flight while this item computes
-    if (chunk == 0) {
+    for (int item = 0; item < nitems; ++item) {
+      const int cur = item & 1;
+      const bool more = item + 1 < nitems;
+      const bool plast = pchunk == nchunks - 1;
+      const unsigned char* const cA = sA + cur * BUF;
+      const unsigned char* const cB = sB + (wdb ? cur * BUF : 0);
+      if (chunk == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+          for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
 #pragma unroll
-    for (int tx = 0; tx < TX; ++tx) {
-      P8 b[TY][NT];
+      for (int tx = 0; tx < TX; ++tx) {
+        P8 b[TY][NT];
 #pragma unroll
-      for (int ty = 0; ty < TY; ++ty)
+        for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + fb + ((ty * TX + tx) * BN + j * 16) * RB);
+          for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(cB + fb + ((ty * TX + tx) * BN + j * 16) * RB);
+        P8 a[3 + TY];
 #pragma unroll
-      for (int hr = 0; hr < 3 + TY; ++hr) {
-        const P8 a = *reinterpret_cast<const P8*>(sA + fa[tx] + hr * HW * RB);
+        for (int hr = 0; hr < 3 + TY; ++hr) a[hr] = *reinterpret_cast<const P8*>(cA + fa[tx] + hr * HW * RB);
+        // the next item's LDS image, one part behind each tap column's fragment reads: it is written while the MFMAs below run
+        if (more && tx < 3) commit(cur ^ 1, tx, false, plast);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-          const int ty = hr - mt;
-          if (ty >= 0 && ty < TY) {
+        for (int hr = 0; hr < 3 + TY; ++hr) {
 #pragma unroll
-            for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[ty][j], a, acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+          for (int mt = 0; mt < 4; ++mt) {
+            const int ty = hr - mt;
+            if (ty >= 0 && ty < TY) {
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[ty][j], a[hr], acc[mt][j]);
+            }
           }
         }
       }
-    }
-    DEC_PH(10);
-    if (++chunk == nchunks) {
-      chunk = 0;
-      DEC_PH_COUNT(15);
-      // v = lrelu(acc * d + b) * (sqrt2 * s): leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf) (one instruction; fmaxf
-      // costs a canonicalising v_max first), slope = 1 when the layer has no activation; the sqrt(2) rides in the style
-      v2f ed[NT][2], eb[NT][2], es[NT][2];
+      if (more) {
+        if (TX < 3) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const float4 d = *reinterpret_cast<const float4*>(sE + j * 16 + q * 4);
-        const float4 bb = *reinterpret_cast<const float4*>(sE + BN + j * 16 + q * 4);
-        float4 sn = *reinterpret_cast<const float4*>(sE + 2 * BN + j * 16 + q * 4);
-        if (g.act) {
-          sn.x *= 1.4142135623730951f;
-          sn.y *= 1.4142135623730951f;
-          sn.z *= 1.4142135623730951f;
-          sn.w *= 1.4142135623730951f;
+          for (int part = TX; part < 3; ++part) commit(cur ^ 1, part, false, plast);
         }
-        ed[j][0] = v2f{d.x, d.y};
-        ed[j][1] = v2f{d.z, d.w};
-        eb[j][0] = v2f{bb.x, bb.y};
-        eb[j][1] = v2f{bb.z, bb.w};
-        es[j][0] = v2f{sn.x, sn.y};
-        es[j][1] = v2f{sn.z, sn.w};
+        if (item + 2 < nitems) {
+          pchunk = (pchunk + 1 == nchunks) ? 0 : pchunk + 1;
+          issue();  // the registers are free again: item + 2 is in flight during the next item
+        }
       }
-      const float slope = g.act ? 0.2f : 1.0f;
-      unsigned char* yt = reinterpret_cast<unsigned char*>(g.Y) +
-                          ((((size_t)cf * g.OH + (size_t)cty * 16 * g.sy + g.py) * g.OW + (size_t)ctx * 16 * g.sx + g.px) * g.Cout + n0) * EB;
-      unsigned sm = 0u;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
+      if (++chunk == nchunks) {
+        chunk = 0;
+        const float* const cE = reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(sE) + cur * BUF);
+        // v = lrelu(acc * d + b) * (sqrt2 * s): leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf) (one instruction; fmaxf
+        // costs a canonicalising v_max first), slope = 1 when the layer has no activation; the sqrt(2) rides in the style
+        v2f ed[NT][2], eb[NT][2], es[NT][2];
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          v2f v0 = v2f{acc[mt][j][0], acc[mt][j][1]} * ed[j][0] + eb[j][0];
-          v2f v1 = v2f{acc[mt][j][2], acc[mt][j][3]} * ed[j][1] + eb[j][1];
-          const v2f l0 = slope * v0, l1 = slope * v1;
-          v0 = v2f{__builtin_amdgcn_fmed3f(v0.x, l0.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v0.y, l0.y, __builtin_inff())} * es[j][0];
-          v1 = v2f{__builtin_amdgcn_fmed3f(v1.x, l1.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v1.y, l1.y, __builtin_inff())} * es[j][1];
-          dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + j * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
+          const float4 d = *reinterpret_cast<const float4*>(cE + j * 16 + q * 4);
+          const float4 bb = *reinterpret_cast<const float4*>(cE + BN + j * 16 + q * 4);
+          float4 sn = *reinterpret_cast<const float4*>(cE + 2 * BN + j * 16 + q * 4);
+          if (g.act) {
+            sn.x *= 1.4142135623730951f;
+            sn.y *= 1.4142135623730951f;
+            sn.z *= 1.4142135623730951f;
+            sn.w *= 1.4142135623730951f;
+          }
+          ed[j][0] = v2f{d.x, d.y};
+          ed[j][1] = v2f{d.z, d.w};
+          eb[j][0] = v2f{bb.x, bb.y};
+          eb[j][1] = v2f{bb.z, bb.w};
+          es[j][0] = v2f{sn.x, sn.y};
+          es[j][1] = v2f{sn.z, sn.w};
+        }
+        const float slope = g.act ? 0.2f : 1.0f;
+        unsigned char* yt = reinterpret_cast<unsigned char*>(g.Y) +
+                            ((((size_t)cf * g.OH + (size_t)cty * 16 * g.sy + g.py) * g.OW + (size_t)ctx * 16 * g.sx + g.px) * g.Cout + n0) * EB;
+        unsigned sm = 0u;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            v2f v0 = v2f{acc[mt][j][0], acc[mt][j][1]} * ed[j][0] + eb[j][0];
+            v2f v1 = v2f{acc[mt][j][2], acc[mt][j][3]} * ed[j][1] + eb[j][1];
+            const v2f l0 = slope * v0, l1 = slope * v1;
+            v0 = v2f{__builtin_amdgcn_fmed3f(v0.x, l0.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v0.y, l0.y, __builtin_inff())} * es[j][0];
+            v1 = v2f{__builtin_amdgcn_fmed3f(v1.x, l1.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v1.y, l1.y, __builtin_inff())} * es[j][1];
+            dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + j * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
+          }
+        }
+        dec_sat_flush<T>(g.sat, sm);
+        // the next tile to compute
+        if (++ctx == g.tiles_x) {
+          ctx = 0;
+          if (++cty == g.tiles_y) {
+            cty = 0;
+            ++cf;
+          }
         }
       }
-      dec_sat_flush<T>(g.sat, sm);
-      DEC_PH(11);
-      // the next tile to compute
-      if (++ctx == g.tiles_x) {
-        ctx = 0;
-        if (++cty == g.tiles_y) {
-          cty = 0;
-          ++cf;
+      __syncthreads();  // the one barrier of the item: buffer `cur` is free, buffer `cur ^ 1` is complete
+    }
+  } else {
+    for (int item = 0; item < nitems; ++item) {
+      __syncthreads();  // every wave is done reading the previous item's tiles
+      if (s_edge == 0u) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ra[i];
+      } else {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ((s_hit >> (4 * i)) & 15u) ? T::zero8() : ra[i];
+      }
+      if (nchunks > 1 || first) {
+#pragma unroll
+        for (int i = 0; i < NB - 1; ++i) *reinterpret_cast<P8*>(sB + b_lds + i * 64 * RB) = rb[i];
+        *reinterpret_cast<P8*>(sB + b_lds_l) = rb[NB - 1];
+        first = false;
+      }
+      if (chunk == nchunks - 1 && tid < 3 * BN / 4) *reinterpret_cast<float4*>(sE + tid * 4) = re;
+      __syncthreads();
+      DEC_PH(9);
+      if (item + 1 < nitems) issue();  // in flight while this item computes
+      if (chunk == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int tx = 0; tx < TX; ++tx) {
+        P8 b[TY][NT];
+#pragma unroll
+        for (int ty = 0; ty < TY; ++ty)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + fb + ((ty * TX + tx) * BN + j * 16) * RB);
+#pragma unroll
+        for (int hr = 0; hr < 3 + TY; ++hr) {
+          const P8 a = *reinterpret_cast<const P8*>(sA + fa[tx] + hr * HW * RB);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) {
+            const int ty = hr - mt;
+            if (ty >= 0 && ty < TY) {
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[ty][j], a, acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+            }
+          }
+        }
+      }
+      DEC_PH(10);
+      if (++chunk == nchunks) {
+        chunk = 0;
+        DEC_PH_COUNT(15);
+        // v = lrelu(acc * d + b) * (sqrt2 * s): leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf) (one instruction; fmaxf
+        // costs a canonicalising v_max first), slope = 1 when the layer has no activation; the sqrt(2) rides in the style
+        v2f ed[NT][2], eb[NT][2], es[NT][2];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const float4 d = *reinterpret_cast<const float4*>(sE + j * 16 + q * 4);
+          const float4 bb = *reinterpret_cast<const float4*>(sE + BN + j * 16 + q * 4);
+          float4 sn = *reinterpret_cast<const float4*>(sE + 2 * BN + j * 16 + q * 4);
+          if (g.act) {
+            sn.x *= 1.4142135623730951f;
+            sn.y *= 1.4142135623730951f;
+            sn.z *= 1.4142135623730951f;
+            sn.w *= 1.4142135623730951f;
+          }
+          ed[j][0] = v2f{d.x, d.y};
+          ed[j][1] = v2f{d.z, d.w};
+          eb[j][0] = v2f{bb.x, bb.y};
+          eb[j][1] = v2f{bb.z, bb.w};
+          es[j][0] = v2f{sn.x, sn.y};
+          es[j][1] = v2f{sn.z, sn.w};
+        }
+        const float slope = g.act ? 0.2f : 1.0f;
+        unsigned char* yt = reinterpret_cast<unsigned char*>(g.Y) +
+                            ((((size_t)cf * g.OH + (size_t)cty * 16 * g.sy + g.py) * g.OW + (size_t)ctx * 16 * g.sx + g.px) * g.Cout + n0) * EB;
+        unsigned sm = 0u;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            v2f v0 = v2f{acc[mt][j][0], acc[mt][j][1]} * ed[j][0] + eb[j][0];
+            v2f v1 = v2f{acc[mt][j][2], acc[mt][j][3]} * ed[j][1] + eb[j][1];
+            const v2f l0 = slope * v0, l1 = slope * v1;
+            v0 = v2f{__builtin_amdgcn_fmed3f(v0.x, l0.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v0.y, l0.y, __builtin_inff())} * es[j][0];
+            v1 = v2f{__builtin_amdgcn_fmed3f(v1.x, l1.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v1.y, l1.y, __builtin_inff())} * es[j][1];
+            dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + j * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
+          }
+        }
+        dec_sat_flush<T>(g.sat, sm);
+        DEC_PH(11);
+        // the next tile to compute
+        if (++ctx == g.tiles_x) {
+          ctx = 0;
+          if (++cty == g.tiles_y) {
+            cty = 0;
+            ++cf;
+          }
         }
       }
     }

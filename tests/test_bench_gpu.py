@@ -18,8 +18,8 @@ def _run(args, env=None):
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, capture_output=True, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), lines  # ONE JSON line and nothing else on stdout (RCCL's banner goes to stderr)
     return json.loads(lines[0])
 
 
