@@ -421,7 +421,15 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
       if ((rc = fmt_gemm_run(c.dtype, EPI_T16, g, st))) return rc;
     }
     {
-      hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), 0, st, reinterpret_cast<const E*>(h->qkv16), Tn, D, c.heads,
+      // 16-bit operands: the matrix-pipe kernel (64 queries per workgroup, K / V shared); fp32 mode and FLOAT_AUD_ATTN_MFMA=0: one wave per query
+      static const bool mfma_on = !(getenv("FLOAT_AUD_ATTN_MFMA") && atoi(getenv("FLOAT_AUD_ATTN_MFMA")) == 0);
+      if constexpr (!T::is32) {
+        if (mfma_on)
+          hipLaunchKernelGGL((aud_attn_mfma_kernel<T>), dim3((Tn + 63) / 64, c.heads), dim3(256), 0, st, reinterpret_cast<const E*>(h->qkv16), Tn, D,
+                             c.heads, reinterpret_cast<E*>(h->att16), h->sat);
+      }
+      if (T::is32 || !mfma_on)
+        hipLaunchKernelGGL((aud_attn_kernel<T>), dim3((Tn + 3) / 4, c.heads), dim3(256), 0, st, reinterpret_cast<const E*>(h->qkv16), Tn, D, c.heads,
                          reinterpret_cast<E*>(h->att16), h->sat);
     }
     {

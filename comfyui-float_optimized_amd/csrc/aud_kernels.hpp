@@ -456,6 +456,114 @@ __global__ __launch_bounds__(256) void aud_attn_kernel(const typename T::elem* _
 }
 
 // ------------------------------------------------------------------------------------------
+// The same attention on the matrix pipe (16-bit operand types; round 4).  aud_attn_kernel above gives every query its own
+// wave, and each wave streams ALL keys and values of its head from L2: 6000 waves x 128 KB = 770 MB per layer at 500 frames,
+// 87 us per launch - 1.04 of the audio encoder's 1.58 ms per 10-s clip, 2.1 of the speech-emotion model's 6.5 ms.  Here a
+// workgroup owns 64 queries of one head (16 per wave) and walks the keys in tiles of 64:
+//   S^T = K Q^T   MFMA(A = K tile rows [16 keys x 32 dims], B = Q^T): operands straight from global memory, a lane's 16 bytes
+//                 are 8 consecutive dims of one key / query; D[key][query] leaves a lane with 4 consecutive keys of ONE query
+//                 per 16-key sub-tile, so the softmax statistics of a query are in-lane sums + two cross-group exchanges;
+//   O^T += V^T P^T  MFMA(A = V^T [16 dims x 32 keys], B = P^T): the probabilities go from the S^T accumulators to the B operand
+//                 without leaving the lane (contraction index e of lane group g = key 16*(e/4) + 4g + e%4 of the 32-key block);
+//                 V^T is staged in LDS transposed with the keys in exactly that order (row stride 144 B: conflict-free
+//                 ds_read_b128), once per workgroup and tile.
+// Online softmax over the tiles as before (running max, accumulators rescaled by exp(m_old - m_new)); keys past Tn get
+// probability 0.  Output packed as the A operand of the out-projection.  K / V bytes per layer: 49 MB instead of 770.
+template <class T>
+__global__ __launch_bounds__(256) void aud_attn_mfma_kernel(const typename T::elem* __restrict__ qkv, int Tn, int D, int heads,
+                                                            typename T::elem* __restrict__ out, unsigned long long* sat) {
+  static_assert(!T::is32, "16-bit operand types only (the fp32 mode runs aud_attn_kernel)");
+  typedef typename T::elem E;
+  typedef typename T::pack8 P8;
+  constexpr int HD = 64, KT = 64, VSTR = 72;  // V^T row stride in elements (144 B)
+  __shared__ __attribute__((aligned(16))) E sV[HD * VSTR];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, c16 = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, ld = 3 * D;
+  const int q_raw = blockIdx.x * 64 + w * 16 + c16, qi = min(q_raw, Tn - 1);
+  const E* const qp = qkv + (size_t)qi * ld + h * HD + g * 8;
+  const P8 qB0 = T::load8(qp), qB1 = T::load8(qp + 32);  // B operand: query c16, dims kb*32 + g*8 .. +7
+  f32x4 oT[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) oT[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = -INFINITY, l = 0.f;
+  // staging of V: thread -> (key = tid / 4 [+ 0], 16 dims = two 8-packs) of the tile
+  const int vkey = tid >> 2, vd0 = (tid & 3) * 16;
+  const int vpos = (vkey & 32) + ((vkey >> 2) & 3) * 8 + ((vkey >> 4) & 1) * 4 + (vkey & 3);  // key' of this thread's key
+  for (int j0 = 0; j0 < Tn; j0 += KT) {
+    // K fragments of the tile (this wave's own copy, from L2): sub-tile st, dims kb*32 + g*8
+    P8 kA[4][2];
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const E* kp = qkv + (size_t)min(j0 + st * 16 + c16, Tn - 1) * ld + D + h * HD + g * 8;
+      kA[st][0] = T::load8(kp);
+      kA[st][1] = T::load8(kp + 32);
+    }
+    const E* vp = qkv + (size_t)min(j0 + vkey, Tn - 1) * ld + 2 * D + h * HD + vd0;
+    const P8 v0 = T::load8(vp), v1 = T::load8(vp + 8);
+    __syncthreads();  // the previous tile's V^T has been read by every wave
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      sV[(vd0 + i) * VSTR + vpos] = reinterpret_cast<const E*>(&v0)[i];
+      sV[(vd0 + 8 + i) * VSTR + vpos] = reinterpret_cast<const E*>(&v1)[i];
+    }
+    __syncthreads();
+    f32x4 sT[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
+      a = T::mfma(kA[st][0], qB0, a);
+      a = T::mfma(kA[st][1], qB1, a);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = j0 + st * 16 + g * 4 + r;
+        a[r] = key < Tn ? a[r] * 0.125f : -INFINITY;  // head_dim^-0.5
+        mx = fmaxf(mx, a[r]);
+      }
+      sT[st] = a;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m, mx);       // finite: key j0 exists for every query
+    const float alpha = __expf(m - mn);  // first tile: exp(-inf) = 0 on zero accumulators
+    m = mn;
+    float sum = 0.f;
+    P8 pB[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      float pv[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        pv[e] = __expf(sT[kb * 2 + (e >> 2)][e & 3] - mn);
+        sum += pv[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) T::set(pB[kb], e, pv[e]);
+    }
+    l = l * alpha + sum;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 o = oT[dt] * alpha;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+        const P8 vA = *reinterpret_cast<const P8*>(sV + (dt * 16 + c16) * VSTR + kb * 32 + g * 8);
+        o = T::mfma(vA, pB[kb], o);
+      }
+      oT[dt] = o;
+    }
+  }
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
+  if (q_raw >= Tn) return;
+  const float inv = 1.f / l;
+  unsigned rm = 0u;
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+    fh_store4<T>(out + fmt_pack_off(q_raw, h * HD + dt * 16 + g * 4, D / 32), oT[dt][0] * inv, oT[dt][1] * inv, oT[dt][2] * inv, oT[dt][3] * inv, rm);
+  fh_range_flush<T>(sat, rm);
+}
+
+// ------------------------------------------------------------------------------------------
 // feat_extract_norm = "layer" (wav2vec2-large / the speech-emotion model, Wav2Vec2LayerNormConvLayer): every conv is
 // followed by LayerNorm over the CHANNELS of each time step (affine) and GELU.
 // Layer 0: Conv1d(1 -> C, k = 10) + bias, LayerNorm, GELU; one wave per time step, 8 channels per lane (C = 512).
