@@ -327,7 +327,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
     const int tchunk = 64, nchunk = (L + tchunk - 1) / tchunk;
     hipLaunchKernelGGL((aud_conv0_stats_kernel<10>), dim3(nchunk, (C + 255) / 256), dim3(256), 0, st, a, n_samples, h->w0, c.conv_stride[0], L, C,
                        tchunk, h->part);
-    hipLaunchKernelGGL(aud_gn_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, h->part, nchunk, C, L, h->gn.g, h->gn.b, 1e-5f, h->scsh);
+    hipLaunchKernelGGL(aud_gn_final_kernel, dim3((C + 3) / 4), dim3(256), 0, st, h->part, nchunk, C, L, h->gn.g, h->gn.b, 1e-5f, h->scsh);
     const size_t tot = (size_t)L * (C / 8);
     hipLaunchKernelGGL((aud_conv0_apply_kernel<T, 10>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, a, h->w0, c.conv_stride[0], L, C,
                        h->scsh, reinterpret_cast<E*>(h->fa), h->sat);
@@ -467,7 +467,7 @@ int inference_impl(float_aud* h, const float* a, int n_samples, int Tn, float* o
   }
   if (c.num_labels > 0) {
     // ---- mean over time -> dense -> tanh -> out_proj -> softmax (wav2vec2_ser.py:58-75,94-96; FLOAT.py:396-401)
-    hipLaunchKernelGGL(aud_meanpool_kernel, dim3((D + 255) / 256), dim3(256), 0, st, h->h, Tn, D, h->pooled);
+    hipLaunchKernelGGL(aud_meanpool_kernel, dim3((D + 63) / 64), dim3(256), 0, st, h->h, Tn, D, h->pooled);
     hipLaunchKernelGGL(aud_dense_kernel, dim3((D + 3) / 4), dim3(256), 0, st, h->pooled, h->cls_dense_w, h->cls_dense_b, h->cls_h, D, D, 1);
     hipLaunchKernelGGL(aud_dense_kernel, dim3((c.num_labels + 3) / 4), dim3(256), 0, st, h->cls_h, h->cls_out_w, h->cls_out_b, h->cls_logits,
                        c.num_labels, D, 0);

@@ -73,15 +73,20 @@ def resample_sinc(w, orig_rate, new_rate, zeros=24, rolloff=0.945):
     return y[: int(math.ceil(n * up / down))]
 
 
-def preprocess_audio(waveform, sample_rate, target_rate=16000):
+def preprocess_audio(waveform, sample_rate, target_rate=16000, device=None):
     """ComfyUI AUDIO item (C,N) -> mono 16 kHz, zero-mean / unit-variance like
     Wav2Vec2FeatureExtractor(do_normalize=True) (generate.py:69-73).  A different source rate goes through a band-limited
     resampler (the reference: librosa soxr_hq)."""
-    w = waveform.float()
+    w = waveform
+    if device is not None and sample_rate == target_rate:
+        w = w.to(device, non_blocking=True)  # nothing to resample: mono mix and normalisation run where the encoder runs
+    w = w.float()
     if w.dim() == 2:
         w = w.mean(dim=0)
     if sample_rate != target_rate:
-        w = resample_sinc(w, sample_rate, target_rate)
+        w = resample_sinc(w, sample_rate, target_rate)  # on the waveform's own device (the host for a ComfyUI AUDIO item)
+    if device is not None:
+        w = w.to(device, non_blocking=True)
     return ((w - w.mean()) / torch.sqrt(w.var(unbiased=False) + 1e-7))[None]
 
 
