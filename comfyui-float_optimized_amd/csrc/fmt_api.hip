@@ -1560,7 +1560,9 @@ int float_fmt_saturation(float_fmt_t* h, uint64_t* total, int32_t reset, void* s
     FH_CHECK_HIP(hipMemcpy(&err, h->mega_sync + 18 * 32, sizeof(err), hipMemcpyDeviceToHost));
     if (err) {
       FH_CHECK_HIP(hipMemset(h->mega_sync + 18 * 32, 0, sizeof(err)));
-      h->mega_on = 0;  // the launch chain from here on
+      h->mega_on = 0;  // the launch chain from here on: captured window graphs hold the persistent kernel, drop them
+      for (auto& gr : h->graphs) (void)hipGraphExecDestroy(gr.exec);
+      h->graphs.clear();
       fh_set_error("fmt_mega_kernel: a grid barrier timed out (not all %d workgroups were resident) - the results of this call are "
                    "invalid; the handle falls back to the launch chain (FLOAT_FMT_MEGA=0 selects it from the start)", 256);
       return FLOAT_E_HIP;
