@@ -180,6 +180,9 @@ def cpu_baseline(pkg, torch, cfg, fmt_sd, dec_sd, feats, cond, nfe_evals):
 
 def main():
     args = parse()
+    if os.environ.get("FLOAT_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after that many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["FLOAT_BENCH_WATCHDOG"]), exit=True)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         launch_ranks(args.gpus)  # never returns
 
@@ -196,7 +199,9 @@ def main():
     torch.cuda.set_device(dev)
     dist = None
     rccl_ranks, rccl_note = None, None
-    if world > 1:
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ  # torchrun / launch_ranks: env rendezvous
+    if world > 1 or (launched and backend == "nccl"):
+        # (also a one-rank launch by torchrun: its agent owns the store, a private tcp:// rendezvous would wait for ever)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         with stdout_to_stderr():

@@ -217,7 +217,8 @@ class InferenceAgent:
         host = self.G.generate_to_host(c["r_s"], c["wa"], c["we"], c["s_r"], None, self.opt.nfe, a_cfg_scale, r_cfg_scale,
                                        e_cfg_scale, noise=noise, out=out)
         torch.cuda.current_stream(self.rank).synchronize()  # the frames are in host memory
-        self.check_range("InferenceAgent.infer_device")
+        if self.check_range("InferenceAgent.infer_device", allow_rebuild=True) == "rebuilt":
+            return self.infer_device(s, a, a_cfg_scale, r_cfg_scale, e_cfg_scale, emo, seed, out)  # once more, in the wider types
         return host
 
     def range_counts(self, reset=True):
@@ -230,12 +231,31 @@ class InferenceAgent:
                 counts[name] = op.saturation(reset)
         return counts
 
-    def check_range(self, where):
-        """Once per clip, after the frames have arrived: an fp16 operator that left its range does not go unnoticed (a
-        RuntimeWarning + log line; FLOAT_AMD_RANGE=raise makes it an error, =off skips the four 8-byte reads)."""
-        if os.environ.get("FLOAT_AMD_RANGE", "warn").lower() == "off":
+    def check_range(self, where, allow_rebuild=False):
+        """Once per clip, after the frames have arrived: an fp16 operator that left its range does not go unnoticed.
+        FLOAT_AMD_RANGE = warn (default: RuntimeWarning + log line) | raise (Fp16RangeError) | off (skip the 8-byte reads) |
+        auto: warn, then REBUILD the operators that overflowed in a type with the range - decoder + encoder in fp32 (the
+        verification mode: same kernels, 1/16 of the MFMA rate), FMT / audio / speech-emotion in bf16 - and tell the caller to
+        run the clip again ("rebuilt"); the agent keeps those types from then on."""
+        mode = os.environ.get("FLOAT_AMD_RANGE", "warn").lower()
+        if mode == "off":
             return {}
-        return report_range(self.range_counts(), where)
+        bad = report_range(self.range_counts(), where, mode="warn" if mode == "auto" else mode)
+        if mode == "auto" and bad and allow_rebuild:
+            b, changed = self._build, False
+            if ("decoder" in bad or "encoder" in bad) and b["dec_dtype"] != "fp32":
+                b["dec_dtype"], changed = "fp32", True
+            if "fmt" in bad and b["fmt_dtype"] == "fp16":
+                b["fmt_dtype"], changed = "bf16", True
+            if ("audio" in bad or "speech_emotion" in bad) and b["aud_dtype"] == "fp16":
+                b["aud_dtype"], changed = "bf16", True
+            if changed:
+                main_logger.warning("%s: rebuilding the operators as fmt=%s, decoder/encoder=%s, audio=%s and running the clip again",
+                                    where, b["fmt_dtype"], b["dec_dtype"], b["aud_dtype"])
+                self.offload()
+                self.to_target()
+                return "rebuilt"
+        return bad
 
     @torch.no_grad()
     def infer_device_batch(self, items, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, emo="S2E", seeds=None):

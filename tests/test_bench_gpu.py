@@ -48,3 +48,21 @@ def test_gpus_2_launches_its_own_ranks(mode):
     assert r["config"]["frames_per_clip"] == (50 if mode == "replicas" else 100)
     if mode == "window":
         assert "seam change" in r["config"]["parallelism"]
+
+
+def test_torchrun_launch_at_world_1():
+    """The driver starts N > 1 through `python -m torch.distributed.run ... bench.py --gpus N`: the same launch with one rank (the
+    agent owns the rendezvous store; a private tcp:// rendezvous inside the rank would wait for ever) comes up on RCCL."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + SHORT + [
+               "--no-cpu-baseline", "--no-roofline", "--no-extras", "--no-s2e", "--no-variants"]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, FLOAT_BENCH_WATCHDOG="400"), capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    r = json.loads(lines[-1])
+    assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["value"] > 0

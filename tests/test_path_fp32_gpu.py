@@ -72,8 +72,16 @@ def test_product_path_reports_fp16_overflow(monkeypatch):
     monkeypatch.setenv("FLOAT_AMD_RANGE", "raise")
     with pytest.raises(pkg.pipeline.Fp16RangeError):
         agent.infer_device(img.cuda(), wav.cuda(), 2.0, 1.0, 1.0, emo="happy", seed=7)
+    # FLOAT_AMD_RANGE=auto: warn, rebuild the operators that overflowed in a type with the range, run the clip again
+    monkeypatch.setenv("FLOAT_AMD_RANGE", "auto")
+    auto = gen.InferenceAgent(opt, parts, "cuda:0", max_frames=8)
+    with pytest.warns(RuntimeWarning, match="fp16 range exceeded"):
+        frames_auto = auto.infer_device(img.cuda(), wav.cuda(), 2.0, 1.0, 1.0, emo="happy", seed=7)
+    assert auto.G.dec.dtype == "fp32" and auto.enc.dtype == "fp32" and auto.G.fmt.dtype == "bf16" and torch.isfinite(frames_auto).all()
+    monkeypatch.setenv("FLOAT_AMD_RANGE", "raise")
     # the remedy the message names: fp32 decoder + encoder, and an FMT operand type with fp32's exponent range (the identity
     # latent r_s ~ 1e7 of this checkpoint leaves fp16's range inside the FMT's condition rows too)
     agent32 = gen.InferenceAgent(opt, parts, "cuda:0", max_frames=8, dec_dtype="fp32", fmt_dtype="bf16")
     frames = agent32.infer_device(img.cuda(), wav.cuda(), 2.0, 1.0, 1.0, emo="happy", seed=7)  # raise mode: no error
     assert torch.isfinite(frames).all() and agent32.range_counts() == {"audio": 0}
+    assert torch.equal(frames, frames_auto)  # the automatic rebuild ended in the same operators
