@@ -486,6 +486,26 @@ def main():
             torch.cuda.synchronize()
             variants.update({"value_from_host_inputs": round(T * k / el, 3), "ms_per_step_from_host_inputs": round(el / k * 1e3, 3),
                              "host_inputs_ms": round((time.perf_counter() - t1) / k * 1e3, 3)})
+            # THROUGHPUT form of the same product path: B clips of equal length through ONE stacked FMT chain
+            # (InferenceAgent.infer_device_batch -> float_fmt_sample_batch; what FLOAT Process runs for a batch of portraits,
+            # BASELINE configs[3] on one GPU): every weight is read once per evaluation for all of them
+            nb = 4
+            items = [(torch.roll(img, i, dims=-1), wav) for i in range(nb)]
+
+            def batch_step():
+                last.pop("host", None)
+                last["hosts"] = agent.infer_device_batch(items, a_cfg, 1.0, e_cfg, "neutral", [15 + i for i in range(nb)])
+            batch_step()
+            barrier()
+            kb = max(2, k // 4)
+            t0 = time.perf_counter()
+            for _ in range(kb):
+                batch_step()
+            barrier()
+            el = time.perf_counter() - t0
+            last.pop("hosts", None)
+            variants.update({"value_batch4": round(nb * T * kb / el, 3), "ms_per_step_batch4": round(el / kb * 1e3, 3),
+                             "batch4_what": "4 clips of 10 s stacked in one FMT chain, decoded one after the other, 1000 frames per step"})
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -27,7 +27,7 @@ def test_single_gpu_line_has_the_contract_fields():
     r = _run(SHORT)  # every leg of the default run: roofline pass, CPU baseline, speech-to-emotion, nfe / host-input variants
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "stage_ms", "value_s2e", "value_nfe5", "value_from_host_inputs",
-              "host_inputs_ms", "rccl_ranks", "fp16_range_hits"):
+              "host_inputs_ms", "rccl_ranks", "fp16_range_hits", "value_batch4"):
         assert k in r, k
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1 and cb["unit"] == "frames/s" and "sample" in cb
