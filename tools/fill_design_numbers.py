@@ -17,6 +17,7 @@ for tag, key in (("", "value"), ("_S2E", "value_s2e"), ("_NFE", "value_nfe50"), 
     rep["@MS%s@" % tag], rep["@FPS%s@" % tag] = ms, fps
 rep["@MS_HOT@"], rep["@FPS_HOT@"] = "%.1f" % d["hot_path"]["ms_per_clip"], "%.0f" % d["hot_path"]["frames_per_s"]
 rep["@HOSTMS@"] = "%.2f ms" % d["host_inputs_ms"]
+rep["@MS_B4@"], rep["@FPS_B4@"] = "%.1f per 4 clips" % d["ms_per_step_batch4"], "%.0f" % d["value_batch4"]
 for f in sys.argv[1:]:
     s = open(f).read()
     for k, v in rep.items():
