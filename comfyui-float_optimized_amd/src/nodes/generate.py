@@ -176,15 +176,36 @@ class InferenceAgent:
             raise NotImplementedError(
                 "emotion='none' asks the speech-emotion model for scores (FLOAT.py:196-198) but the checkpoint has "
                 "no `emotion_encoder.wav2vec2_for_emotion.` weights - pick an emotion or attach agent.emotion_predictor")
+        T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
+        need_ser = host_models.emotion_index(emo) is None
+        # The speech-emotion model (emotion = "none", the reference's default widget) is independent of the other two producers
+        # and the longest of the three (2.6 ms of ~200 small launches against 0.9 + 1.2): it runs on a side stream beside them
+        # and joins before the FMT starts (111.8 -> 111.1 ms per clip, same box).  Only here: a second ACTIVE queue during the FMT chain
+        # costs it 12 ms; and not for the label case - encoder || audio encoder on two streams measured
+        # 0.45 ms SLOWER than one after the other (the stream hand-offs cost more than the 0.9 ms they hide).
+        cur = torch.cuda.current_stream(self.rank)
+        side = self._cond_stream() if (need_ser and os.environ.get("FLOAT_AMD_COND_STREAMS", "1") != "0") else None
+        we = None
+        if need_ser:
+            if side is not None:
+                side.wait_stream(cur)  # `a` was produced on the caller's stream
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
+        wa = self.audio_encoder.inference(a, seq_len=T)
         s_r, _, _, r_s = self.enc.encode_image_into_latent(s, want_feats=False)  # FLOAT.py:283-291
         self.enc.hand_feats_to(self.G.dec)
-        T = math.ceil(a.shape[-1] * o.fps / o.sampling_rate)  # FLOAT.py:192
-        wa = self.audio_encoder.inference(a, seq_len=T)
-        if host_models.emotion_index(emo) is None:
-            we = self.emotion_predictor(a).reshape(1, 1, -1).to(self.rank)
-        else:
+        if side is not None:
+            cur.wait_stream(side)
+            we.record_stream(cur)  # allocated on the side stream, consumed on the caller's
+        if we is None:
             we = self._one_hot(emo)
         return dict(s_r=s_r, feats=None, r_s=r_s, wa=wa, we=we, T=T)  # feats: already in the decoder (NHWC 16-bit)
+
+    def _cond_stream(self):
+        st = self.__dict__.get("_side_stream")
+        if st is None:
+            st = self._side_stream = torch.cuda.Stream(self.rank)
+        return st
 
     def host_inputs(self, ref_img, ref_audio, no_crop=True):
         """Host plumbing of the reference's DataProcessor (generate.py:34-81): optional face crop, area resize to the model
