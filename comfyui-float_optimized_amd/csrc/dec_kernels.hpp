@@ -829,21 +829,9 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
   unsigned char* const sB = smem + NPIX * RB;  // [NTAPS][BN][RB], chunk ^ ((row >> 1) & 3)
   float* const sE = reinterpret_cast<float*>(sB + NBROWS * RB);  // [3][BN]: demod, bias, next style of the tile's (frame, channels)
   constexpr int BUF = NPIX * RB + NBROWS * RB + 3 * BN * (int)sizeof(float);  // DB: the second buffer set follows the first
-  // Wave layout inside the 16 x 16 x BN tile.  Default: the 4 waves split the ROWS (4 rows x all NT channel tiles each: 6 x 3
-  // halo fragments + 9 x NT weight fragments = 54 ds_read_b128 per 144 MFMAs at NT = 4).  DEC_CONV_W22 (build switch, 64-channel
-  // tiles): 2 x 2 - 8 rows x 2 channel tiles per wave: 10 x 3 + 9 x 2 = 48 reads for the same 144 MFMAs (the kernel is
-  // LDS-read-bound at 64 / 128 px).
-#ifdef DEC_CONV_W22
-  constexpr bool W22 = NT == 4 && !DB;
-#else
-  constexpr bool W22 = false;
-#endif
-  constexpr int MTW = W22 ? 8 : 4, NTW = W22 ? 2 : NT;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);  // the wave index is uniform: scalar arithmetic
   const int r16 = lane & 15, q = lane >> 4;
   const int Wi = g.Wi, Cin = g.Cin;
-  const int wrow = W22 ? (w >> 1) * 8 : w * 4;  // first tile row of this wave
-  const int jb = W22 ? (w & 1) * 2 : 0;         // its first 16-channel tile
 
   // ---- per-lane constants of the staging pass.  Chunk e = tid + 256 i of the halo tile: pixel p = e >> 2, pack ch = e & 3;
   // lanes past the last pixel repeat the last pixel's chunk (same bytes to the same place: no mask anywhere).
@@ -873,10 +861,10 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
   // ---- per-lane constants of the MFMA pass: A fragment (hr, tx) = halo row w*4 + hr, columns r16 + tx; B fragment rows t*BN + j*16 + r16
   unsigned fa[TX];
 #pragma unroll
-  for (int tx = 0; tx < TX; ++tx) fa[tx] = (unsigned)((wrow * HW + r16 + tx) * RB + (q ^ (((r16 + tx) >> 1) & 3)) * CB);
+  for (int tx = 0; tx < TX; ++tx) fa[tx] = (unsigned)(((w * 4) * HW + r16 + tx) * RB + (q ^ (((r16 + tx) >> 1) & 3)) * CB);
   const unsigned fb = (unsigned)(r16 * RB + (q ^ ((r16 >> 1) & 3)) * CB);
-  // ---- epilogue: output pixel (ty*16 + wrow + mt, tx*16 + r16), channels n0 + (jb + j)*16 + q*4 .. +3
-  const unsigned y_off = (unsigned)(((wrow * g.sy * g.OW + r16 * g.sx) * g.Cout + q * 4) * EB);
+  // ---- epilogue: output pixel (ty*16 + w*4 + mt, tx*16 + r16), channels n0 + j*16 + q*4 .. +3
+  const unsigned y_off = (unsigned)((((w * 4) * g.sy * g.OW + r16 * g.sx) * g.Cout + q * 4) * EB);
   const size_t y_row = (size_t)g.sy * g.OW * g.Cout * EB;  // bytes between the wave's m-tiles
 
   const int tiles_pf = g.tiles_x * g.tiles_y;
@@ -945,7 +933,7 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
     }
   };
 
-  f32x4 acc[MTW][NTW];
+  f32x4 acc[4][NT];
   int chunk = 0;
   bool first = true;
   issue();
@@ -1104,26 +1092,26 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
       if (item + 1 < nitems) issue();  // in flight while this item computes
       if (chunk == 0) {
 #pragma unroll
-        for (int i = 0; i < MTW; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int j = 0; j < NT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int tx = 0; tx < TX; ++tx) {
-        P8 b[TY][NTW];
+        P8 b[TY][NT];
 #pragma unroll
         for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + fb + ((ty * TX + tx) * BN + (jb + j) * 16) * RB);
+          for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + fb + ((ty * TX + tx) * BN + j * 16) * RB);
 #pragma unroll
-        for (int hr = 0; hr < MTW - 1 + TY; ++hr) {
+        for (int hr = 0; hr < 3 + TY; ++hr) {
           const P8 a = *reinterpret_cast<const P8*>(sA + fa[tx] + hr * HW * RB);
 #pragma unroll
-          for (int mt = 0; mt < MTW; ++mt) {
+          for (int mt = 0; mt < 4; ++mt) {
             const int ty = hr - mt;
             if (ty >= 0 && ty < TY) {
 #pragma unroll
-              for (int j = 0; j < NTW; ++j) acc[mt][j] = T::mfma(b[ty][j], a, acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+              for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[ty][j], a, acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
             }
           }
         }
@@ -1134,12 +1122,12 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
         DEC_PH_COUNT(15);
         // v = lrelu(acc * d + b) * (sqrt2 * s): leaky_relu(0.2) as max(v, 0.2 v) = med3(v, slope v, +inf) (one instruction; fmaxf
         // costs a canonicalising v_max first), slope = 1 when the layer has no activation; the sqrt(2) rides in the style
-        v2f ed[NTW][2], eb[NTW][2], es[NTW][2];
+        v2f ed[NT][2], eb[NT][2], es[NT][2];
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) {
-          const float4 d = *reinterpret_cast<const float4*>(sE + (jb + j) * 16 + q * 4);
-          const float4 bb = *reinterpret_cast<const float4*>(sE + BN + (jb + j) * 16 + q * 4);
-          float4 sn = *reinterpret_cast<const float4*>(sE + 2 * BN + (jb + j) * 16 + q * 4);
+        for (int j = 0; j < NT; ++j) {
+          const float4 d = *reinterpret_cast<const float4*>(sE + j * 16 + q * 4);
+          const float4 bb = *reinterpret_cast<const float4*>(sE + BN + j * 16 + q * 4);
+          float4 sn = *reinterpret_cast<const float4*>(sE + 2 * BN + j * 16 + q * 4);
           if (g.act) {
             sn.x *= 1.4142135623730951f;
             sn.y *= 1.4142135623730951f;
@@ -1158,15 +1146,15 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
                             ((((size_t)cf * g.OH + (size_t)cty * 16 * g.sy + g.py) * g.OW + (size_t)ctx * 16 * g.sx + g.px) * g.Cout + n0) * EB;
         unsigned sm = 0u;
 #pragma unroll
-        for (int mt = 0; mt < MTW; ++mt) {
+        for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) {
+          for (int j = 0; j < NT; ++j) {
             v2f v0 = v2f{acc[mt][j][0], acc[mt][j][1]} * ed[j][0] + eb[j][0];
             v2f v1 = v2f{acc[mt][j][2], acc[mt][j][3]} * ed[j][1] + eb[j][1];
             const v2f l0 = slope * v0, l1 = slope * v1;
             v0 = v2f{__builtin_amdgcn_fmed3f(v0.x, l0.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v0.y, l0.y, __builtin_inff())} * es[j][0];
             v1 = v2f{__builtin_amdgcn_fmed3f(v1.x, l1.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v1.y, l1.y, __builtin_inff())} * es[j][1];
-            dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + (jb + j) * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
+            dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + j * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
           }
         }
         dec_sat_flush<T>(g.sat, sm);
