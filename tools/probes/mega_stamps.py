@@ -6,6 +6,7 @@ import sys
 
 import torch
 
+os.environ.setdefault("FLOAT_FMT_MEGA", "1")  # the persistent kernel is opt-in
 sys.path.insert(0, ".")
 from tests.util import load_pkg  # noqa: E402
 
