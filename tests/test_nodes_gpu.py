@@ -128,6 +128,7 @@ def test_float_process_batch_runs_stacked_chains(pipe, monkeypatch):
     img, audio = _inputs()
     imgs = torch.cat([img, torch.rand(3, 512, 512, 3, generator=g)])
     node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    monkeypatch.setattr(pipe.opt, "nfe", 51)  # the headline grid: with the fixture's 4 evaluations per window there is no chain to stack
 
     def run():
         torch.cuda.synchronize()
@@ -147,4 +148,4 @@ def test_float_process_batch_runs_stacked_chains(pipe, monkeypatch):
         print("item %d: batched vs per-item %.1f dB" % (i, psnr))
         assert psnr >= 45.0
     print("B = 4, 25 frames each: batched %.1f ms, per-item loop %.1f ms (%.2fx)" % (t_b * 1e3, t_l * 1e3, t_b / t_l))
-    assert t_b < t_l
+    assert t_b < 0.9 * t_l
