@@ -84,3 +84,21 @@ def test_resampler_unfriendly_target_rate_terminates():
     assert y.shape[0] == 16001
     tt = np.arange(16001) / 16001.0
     assert float(np.abs(y.numpy()[200:-200] - np.sin(2 * np.pi * 440 * tt)[200:-200]).max()) < 2e-2
+
+
+def test_range_report_modes(monkeypatch):
+    """pipeline.report_range: what the product calls do with the fp16 range counters (float_*_saturation totals)."""
+    import warnings
+    P = pkg.pipeline
+    assert P.report_range({"fmt": 0, "decoder": 0}, "x") == {}
+    monkeypatch.setenv("FLOAT_AMD_RANGE", "warn")
+    with pytest.warns(RuntimeWarning, match="fp16 range exceeded in decoder \\(3 stores\\)"):
+        assert P.report_range({"fmt": 0, "decoder": 3}, "clip") == {"decoder": 3}
+    monkeypatch.setenv("FLOAT_AMD_RANGE", "raise")
+    with pytest.raises(P.Fp16RangeError, match="encoder"):
+        P.report_range({"encoder": 1}, "clip")
+    assert issubclass(P.Fp16RangeError, OverflowError)
+    monkeypatch.setenv("FLOAT_AMD_RANGE", "off")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert P.report_range({"encoder": 1}, "clip") == {"encoder": 1}
