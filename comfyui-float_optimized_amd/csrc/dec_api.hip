@@ -14,6 +14,9 @@ struct Styled {  // one StyledConv (styledecoder.py:302-325)
   float* WsqT = nullptr;  // [Cin][Cout] sum over taps of W^2 (fp32)
   float* abias = nullptr; // [Cout] FusedLeakyReLU bias
   int style_off = 0, demod_off = 0;
+  // up: 1-D taps of the Blur behind the transposed conv (styledecoder.py:209-213: make_kernel(k) * 4, applied by upfirdn2d as a
+  // true convolution): fir[b] = weight of z[X - 1 + b] in output X = 2 k[3 - b] / sum(k); {0.25, 0.75, 0.75, 0.25} for [1,3,3,1]
+  float fir[4] = {0.25f, 0.75f, 0.75f, 0.25f};
 };
 
 struct Level {  // ToFlow + ToRGB of one resolution
@@ -140,6 +143,73 @@ ClassTaps class_taps(int pu, int pv) {
   return c;
 }
 
+// 1-D taps of an up-sampling FIR (the Blur behind a transposed conv, styledecoder.py:209-213).  What the reference ends up
+// with: Synthesis(blur_kernel=...) builds make_kernel(k) * 4 = outer(k, k) * 4 / sum(k)^2 as a registered BUFFER, and the strict
+// load_state_dict (nodes_vadv_loader.py:632) then overwrites it with the checkpoint's `<conv>.blur.kernel` - so the checkpoint's
+// buffer wins when it is there, the loader's widget (`blur_kernel`, optional tensor of 4 taps) only when it is not, [1,3,3,1]
+// otherwise.  upfirdn2d convolves (correlates with the flipped kernel, styledecoder.py:28-29): fir[b] = weight of z[X - 1 + b]
+// in output X.  A buffer must be a 4 x 4 outer product a (x) a (what make_kernel produces); anything else is refused.
+int blur_taps(const TensorTable& tt, const std::string& buffer_key, float fir[4]) {
+  const float_tensor_t* wk = tt.find("blur_kernel");
+  if (wk && TensorTable::numel(wk) != 4) {
+    fh_set_error("blur_kernel has %lld taps; the HIP decoder implements 4-tap kernels", (long long)TensorTable::numel(wk));
+    return FLOAT_E_INVALID;
+  }
+  if (const float_tensor_t* kb = tt.find(buffer_key)) {
+    if (TensorTable::numel(kb) != 16 || kb->ndim != 2 || kb->shape[0] != 4) {
+      fh_set_error("'%s' is not a 4 x 4 kernel; the HIP decoder implements 4-tap blur kernels", buffer_key.c_str());
+      return FLOAT_E_INVALID;
+    }
+    double r[4] = {0, 0, 0, 0}, S = 0, amax = 0;
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) {
+        r[i] += kb->data[i * 4 + j];
+        S += kb->data[i * 4 + j];
+        amax = std::max(amax, (double)fabsf(kb->data[i * 4 + j]));
+      }
+    if (!(S > 1e-12)) {
+      fh_set_error("'%s' does not have a positive sum", buffer_key.c_str());
+      return FLOAT_E_INVALID;
+    }
+    double a[4];
+    for (int i = 0; i < 4; ++i) a[i] = r[i] / sqrt(S);  // K = a (x) a  =>  row sums = a_i * sum(a), S = sum(a)^2
+    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j)
+        if (fabs(kb->data[i * 4 + j] - a[i] * a[j]) > 1e-5 * amax) {
+          fh_set_error("'%s' is not an outer product k (x) k (make_kernel's form); other blur kernels are not implemented", buffer_key.c_str());
+          return FLOAT_E_INVALID;
+        }
+    for (int b = 0; b < 4; ++b) fir[b] = (float)a[3 - b];
+    return FLOAT_OK;
+  }
+  if (wk) {
+    double sum = 0;
+    for (int b = 0; b < 4; ++b) sum += wk->data[b];
+    if (!(fabs(sum) > 1e-12)) {
+      fh_set_error("blur_kernel sums to zero");
+      return FLOAT_E_INVALID;
+    }
+    for (int b = 0; b < 4; ++b) fir[b] = (float)(2.0 * wk->data[3 - b] / sum);
+  }
+  return FLOAT_OK;
+}
+
+// The Upsample of ToRGB / ToFlow (styledecoder.py:373,394) is built with its default [1,3,3,1] whatever the loader's widget says
+// (:489-491) and dec_flow_kernel has that FIR in its code: a checkpoint whose `upsample.kernel` buffer differs is refused.
+int check_default_upsample(const TensorTable& tt, const std::string& key) {
+  const float_tensor_t* kb = tt.find(key);
+  if (!kb) return FLOAT_OK;
+  const float k1[4] = {1.f, 3.f, 3.f, 1.f};
+  bool ok = TensorTable::numel(kb) == 16;
+  for (int i = 0; ok && i < 4; ++i)
+    for (int j = 0; j < 4; ++j) ok = ok && fabsf(kb->data[i * 4 + j] - k1[i] * k1[j] / 16.f) <= 1e-6f;
+  if (!ok) {
+    fh_set_error("'%s' is not the [1,3,3,1] up-sampling kernel; other ToRGB / ToFlow up-sampling kernels are not implemented", key.c_str());
+    return FLOAT_E_INVALID;
+  }
+  return FLOAT_OK;
+}
+
 template <class T>
 int pack_styled(DevicePool* pool, const TensorTable& tt, const std::string& p, int cin, int cout, bool up, Styled* s,
                 std::vector<float>* WmT_host, std::vector<float>* bm_host, int style_dim) {
@@ -151,6 +221,10 @@ int pack_styled(DevicePool* pool, const TensorTable& tt, const std::string& p, i
   const float_tensor_t* mb = need(tt, p + ".conv.modulation.bias", cin);
   const float_tensor_t* ab = need(tt, p + ".activate.bias", cout);
   if (!w || !mw || !mb || !ab) return FLOAT_E_MISSING;
+  if (up) {
+    int rc = blur_taps(tt, p + ".conv.blur.kernel", s->fir);
+    if (rc) return rc;
+  }
   const float scale = 1.0f / sqrtf((float)(cin * 9));  // styledecoder.py:223-224
   std::vector<float> packed((size_t)9 * cout * cin);
   auto W = [&](int o, int i, int ky, int kx) { return w->data[(((size_t)o * cin + i) * 3 + ky) * 3 + kx] * scale; };
@@ -265,6 +339,7 @@ int create_impl(float_dec* h, const TensorTable& tt) {
     const float_tensor_t* rb1 = need(tt, pr + ".conv.1.bias", 3);
     const float_tensor_t* rb2 = need(tt, pr + ".bias", 3);
     if (!fw || !fmw || !fmb || !fb || !rw || !rb1 || !rb2) return FLOAT_E_MISSING;
+    if ((rc = check_default_upsample(tt, pf + ".upsample.kernel")) || (rc = check_default_upsample(tt, pr + ".upsample.kernel"))) return rc;
     const float sc = 1.0f / sqrtf((float)L.C);  // 1x1: fan_in = C (styledecoder.py:134,223)
     std::vector<float> a(3 * L.C), b(3 * L.C);
     for (int i = 0; i < 3 * L.C; ++i) {
@@ -555,6 +630,8 @@ int launch_upconv(float_dec* h, const Styled& up, int Ri, int n, const void* x_i
     z.OH = z.OW = R;
     z.ldd = ldd;
     z.sat = sat;
+    for (int b = 0; b < 4; ++b) z.fir[b] = up.fir[b];
+    z.fir_sym = (up.fir[0] == 0.25f && up.fir[1] == 0.75f && up.fir[2] == 0.75f && up.fir[3] == 0.25f) ? 1 : 0;
     z.tiles_x = z.tiles_y = (R + 27) / 28;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     const bool prof = fh_prof_pair(1, &e0, &e1);
@@ -607,7 +684,7 @@ int launch_upconv(float_dec* h, const Styled& up, int Ri, int n, const void* x_i
   // FIR blur + bias + lrelu, scaled by the consumer's style
   const size_t tot = (size_t)n * (R / 2) * (R / 4) * (up.cout / 8);
   hipLaunchKernelGGL((dec_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const E*>(Zb),
-                     reinterpret_cast<E*>(U), n, R, up.cout, up.abias, snext, lds, sat);
+                     reinterpret_cast<E*>(U), n, R, up.cout, up.abias, snext, lds, sat, up.fir[0], up.fir[1], up.fir[2], up.fir[3]);
   *U_out = U;
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;

@@ -639,6 +639,11 @@ struct ConvArgs {
   // (ncb == 0: the output-channel block is blockIdx.y)
   unsigned ncb, ngroups;
   unsigned long long* sat;          // saturation counter of this layer's output stores
+  // dec_zblur_kernel: 1-D taps of the Blur (weight of z[X - 1 + b] in output X; {.25, .75, .75, .25} for blur_kernel [1,3,3,1]);
+  // fir_sym: fir is exactly {.25, .75, .75, .25} - the vertical pass with literal taps, mirrored rows added first (the code
+  // every released checkpoint runs); else four FMAs with the taps from here
+  float fir[4];
+  int fir_sym;
 };
 
 // (tile group, output-channel block) of compute workgroup `bid`.  A layer with more than 32 output channels runs ncb workgroups
@@ -1485,20 +1490,11 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArg
   __syncthreads();
   DEC_PH(3);
   // ---- FIR + bias + lrelu*sqrt2 + next style.  Output row Yl (tile-local) takes z rows Yl + 1 .. Yl + 4, output column X
-  // takes z columns X + 1 .. X + 4, weights (1, 3, 3, 1) / 4 per axis (the up-sampling gain 4 included).
+  // takes z columns X + 1 .. X + 4, weights g.fir per axis ((1, 3, 3, 1) / 4 for the released checkpoints: the up-sampling gain
+  // 4 included).  The horizontal taps are MFMA operands, i.e. rounded to the operand type (exact for (1, 3, 3, 1) / 4).
   {
     const int j2 = w & 1, half = w >> 1;
-    P8 bx[2];  // Bx[zc = 8q + k][X = 16 xt + r16]
-#pragma unroll
-    for (int xt = 0; xt < 2; ++xt) {
-      bx[xt] = T::zero8();
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int t = 8 * q + k - (16 * xt + r16) - 1;
-        const float kv = (16 * xt + r16 < 28) ? ((t == 0 || t == 3) ? 0.25f : ((t == 1 || t == 2) ? 0.75f : 0.f)) : 0.f;
-        T::set(bx[xt], k, kv);
-      }
-    }
+    const float f0 = g.fir[0], f1 = g.fir[1], f2 = g.fir[2], f3 = g.fir[3];
     // b4, s4: this wave's bias / next style (channels n0 + j2*16 + q*4 .. +3), loaded under the last chunk's MFMAs.  The asm
     // makes the compiler wait for them HERE: left to the first use inside the row loop it put an `s_waitcnt vmcnt(0)` in front
     // of every row's arithmetic, which on gfx9 also waits for the previous row's STORES - 28 store round trips in series, 8.9
@@ -1516,56 +1512,77 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArg
     unsigned ystep[2];  // bytes between output rows; 0 for a lane that stores into the sink
 #pragma unroll
     for (int xt = 0; xt < 2; ++xt) {
+#ifdef DEC_ZB_NOSTORE
+      const bool ok = false;
+#else
       const bool ok = 16 * xt + r16 < 28 && tx * 28 + 16 * xt + r16 < g.OW;
+#endif
       yp[xt] = ok ? yt + (size_t)((16 * xt + r16) * g.Cout + j2 * 16 + q * 4) * EB : sink;
       ystep[xt] = ok ? (unsigned)(g.OW * g.Cout * EB) : 0u;
     }
     // FULL: all 28 output rows of the tile exist (every tile but the last row of tiles): no per-row test
-    auto filter = [&](auto full_rows) {
-      constexpr bool FULL = decltype(full_rows)::value;
-      v2f h0[2][2], h1[2][2], h2[2][2];
+    auto filter = [&](auto full_rows, auto symmetric) {
+      constexpr bool FULL = decltype(full_rows)::value, SYM = decltype(symmetric)::value;
+      P8 bx[2];  // Bx[zc = 8q + k][X = 16 xt + r16] = tap (zc - X - 1), zero outside the band and past the tile's 28 columns
 #pragma unroll
-      for (int xt = 0; xt < 2; ++xt)
+      for (int xt = 0; xt < 2; ++xt) {
+        bx[xt] = T::zero8();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) h0[xt][i] = h1[xt][i] = h2[xt][i] = v2f{0.f, 0.f};
+        for (int k = 0; k < 8; ++k) {
+          const int t = 8 * q + k - (16 * xt + r16) - 1;
+          float kv;
+          if constexpr (SYM) kv = (t == 0 || t == 3) ? 0.25f : ((t == 1 || t == 2) ? 0.75f : 0.f);
+          else kv = t == 0 ? f0 : (t == 1 ? f1 : (t == 2 ? f2 : (t == 3 ? f3 : 0.f)));
+          T::set(bx[xt], k, (16 * xt + r16 < 28) ? kv : 0.f);
+        }
+      }
+      // all 17 z rows of the wave requested at once, then the 34 independent MFMAs back to back, then the vertical pass: written
+      // row by row (read -> 2 MFMAs -> arithmetic -> store) the compiler kept that order and every row paid an LDS round trip
+      // and an MFMA drain with 2 waves per SIMD to hide them (in-kernel stamps: 4.8 us of a 13-us tile at 512 px)
+      P8 za[17];
 #pragma unroll
-      for (int r = 0; r < 17; ++r) {
-        const P8 a = *reinterpret_cast<const P8*>(sZ + zrd + r * 32 * RB);
-        v2f h[2][2];
+      for (int r = 0; r < 17; ++r) za[r] = *reinterpret_cast<const P8*>(sZ + zrd + r * 32 * RB);
+      f32x4 hd[17][2];  // D[channel 4q + reg][X = 16 xt + r16] of z row r
+#pragma unroll
+      for (int r = 0; r < 17; ++r)
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) hd[r][xt] = T::mfma(za[r], bx[xt], f32x4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+      for (int r = 3; r < 17; ++r) {
+        const int yl = half * 14 + r - 3;
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt) {
-          const f32x4 d = T::mfma(a, bx[xt], f32x4{0.f, 0.f, 0.f, 0.f});  // D[channel 4q + reg][X = 16 xt + r16]
-          h[xt][0] = v2f{d[0], d[1]};
-          h[xt][1] = v2f{d[2], d[3]};
-        }
-        if (r >= 3) {
-          const int yl = half * 14 + r - 3;
-#pragma unroll
-          for (int xt = 0; xt < 2; ++xt) {
-            v2f v[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-              v2f t = 0.25f * (h0[xt][i] + h[xt][i]) + bs[i];
-              t = 0.75f * (h1[xt][i] + h2[xt][i]) + t;
-              const v2f lo = 0.2f * t;
-              v[i] = v2f{__builtin_amdgcn_fmed3f(t.x, lo.x, __builtin_inff()), __builtin_amdgcn_fmed3f(t.y, lo.y, __builtin_inff())} * sn[i];  // leaky_relu(0.2)
-            }
-            unsigned char* const dst = (FULL || ty * 28 + yl < g.OH) ? yp[xt] + (unsigned)yl * ystep[xt] : sink;
-            dec_store4<T>(reinterpret_cast<E*>(dst), v[0].x, v[0].y, v[1].x, v[1].y, sm);
-          }
-        }
-#pragma unroll
-        for (int xt = 0; xt < 2; ++xt)
+          v2f v[2];
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
-            h0[xt][i] = h1[xt][i];
-            h1[xt][i] = h2[xt][i];
-            h2[xt][i] = h[xt][i];
+            const v2f h0 = v2f{hd[r - 3][xt][2 * i], hd[r - 3][xt][2 * i + 1]}, h1 = v2f{hd[r - 2][xt][2 * i], hd[r - 2][xt][2 * i + 1]};
+            const v2f h2 = v2f{hd[r - 1][xt][2 * i], hd[r - 1][xt][2 * i + 1]}, h = v2f{hd[r][xt][2 * i], hd[r][xt][2 * i + 1]};
+            v2f t;
+            if constexpr (SYM) {  // (1, 3, 3, 1) / 4 as literals: what every released checkpoint runs
+              t = 0.25f * (h0 + h) + bs[i];
+              t = 0.75f * (h1 + h2) + t;
+            } else {
+              t = f0 * h0 + bs[i];
+              t = f3 * h + t;
+              t = f1 * h1 + t;
+              t = f2 * h2 + t;
+            }
+            const v2f lo = 0.2f * t;
+            v[i] = v2f{__builtin_amdgcn_fmed3f(t.x, lo.x, __builtin_inff()), __builtin_amdgcn_fmed3f(t.y, lo.y, __builtin_inff())} * sn[i];  // leaky_relu(0.2)
           }
+          unsigned char* const dst = (FULL || ty * 28 + yl < g.OH) ? yp[xt] + (unsigned)yl * ystep[xt] : sink;
+          dec_store4<T>(reinterpret_cast<E*>(dst), v[0].x, v[0].y, v[1].x, v[1].y, sm);
+        }
       }
       };
-    if (ty * 28 + 28 <= g.OH) filter(std::true_type{});
-    else filter(std::false_type{});
+    const bool full = ty * 28 + 28 <= g.OH;
+    if (g.fir_sym) {
+      if (full) filter(std::true_type{}, std::true_type{});
+      else filter(std::false_type{}, std::true_type{});
+    } else {
+      if (full) filter(std::true_type{}, std::false_type{});
+      else filter(std::false_type{}, std::false_type{});
+    }
   }
   dec_sat_flush<T>(g.sat, sm);
   DEC_PH(4);
@@ -1573,7 +1590,7 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArg
   DEC_PH_END(0);
 }
 
-// Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4) over the
+// Second half of the up-sampling StyledConv: 4x4 FIR (pad 1,1; [1,3,3,1]^2/64 * 4 unless the checkpoint's loader says otherwise) over the
 // transposed-conv output z (R+1 x R+1), then + bias, leaky-relu*sqrt2, and the style of the next
 // conv (styledecoder.py:209-213,255-258 then 320-325).  A thread makes a 2 (rows) x 4 (pixels) x 8
 // (channels) block: 5 rows x 7 columns of z are read once (4.4 loads per output instead of 16), each
@@ -1581,7 +1598,8 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_zblur_kernel(ConvArg
 template <class T>
 __global__ __launch_bounds__(256) void dec_blur_kernel(const typename T::elem* __restrict__ z, typename T::elem* __restrict__ out,
                                                        int F, int R, int C, const float* __restrict__ bias,
-                                                       const float* __restrict__ snext, int lds, unsigned long long* sat) {
+                                                       const float* __restrict__ snext, int lds, unsigned long long* sat,
+                                                       float fir0, float fir1, float fir2, float fir3) {
   typedef typename T::pack8 P8;
   const int c8 = C >> 3, xq = R >> 2, yh = R >> 1;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -1593,7 +1611,7 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const typename T::elem* _
   const int Y0 = (int)(p % yh) * 2;
   const int f = (int)(p / yh);
   const int Z = R + 1;
-  const float k1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+  const float k1[4] = {fir0, fir1, fir2, fir3};  // weight of z[X - 1 + t] in output X ((1, 3, 3, 1) / 4 for blur_kernel [1,3,3,1])
   float acc[2][4][8];
 #pragma unroll
   for (int y = 0; y < 2; ++y)

@@ -130,6 +130,21 @@ int create_impl(float_enc* h, const TensorTable& tt) {
   const float_enc_cfg_t& c = h->cfg;
   int rc;
   const std::string p = "net_app.convs.";
+  // The Blur of every down-sampling ConvLayer is a registered buffer (encoder.py:59-75) that the reference's strict load takes
+  // from the checkpoint; enc_blur_kernel has make_kernel([1,3,3,1]) in its code, so a checkpoint that holds anything else is
+  // refused instead of being filtered with the wrong FIR.
+  for (const auto& kv : tt.m) {
+    const std::string& k = kv.first;
+    if (k.size() < 7 || k.compare(k.size() - 7, 7, ".kernel") != 0 || k.compare(0, p.size(), p) != 0) continue;
+    const float k1[4] = {1.f, 3.f, 3.f, 1.f};
+    bool ok = TensorTable::numel(kv.second) == 16;
+    for (int i = 0; ok && i < 4; ++i)
+      for (int j = 0; j < 4; ++j) ok = ok && fabsf(kv.second->data[i * 4 + j] - k1[i] * k1[j] / 64.f) <= 1e-6f;
+    if (!ok) {
+      fh_set_error("'%s' is not the [1,3,3,1] blur kernel; other encoder blur kernels are not implemented", k.c_str());
+      return FLOAT_E_INVALID;
+    }
+  }
   {  // convs.0: (C0, 3, 1, 1) + FusedLeakyReLU bias (1, C0, 1, 1)
     const float_tensor_t* w = tt.find(p + "0.0.weight");
     const float_tensor_t* b = tt.find(p + "0.1.bias");

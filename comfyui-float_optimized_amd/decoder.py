@@ -7,8 +7,23 @@ import torch
 from . import native
 
 
+def blur_taps(blur_kernel):
+    """The loader's `blur_kernel` as the operator's optional `blur_kernel` tensor: None for the default [1,3,3,1], else a
+    (4,) fp32 tensor.  Other lengths change the Blur's padding (styledecoder.py:209-213) and are not implemented."""
+    if blur_kernel is None:
+        return None
+    k = torch.as_tensor(blur_kernel, dtype=torch.float32).reshape(-1)
+    if k.numel() != 4:
+        raise ValueError("the HIP decoder implements 4-tap blur kernels (got %d taps: %s)" % (k.numel(), list(blur_kernel)))
+    if abs(float(k.sum())) < 1e-12:
+        raise ValueError("blur_kernel sums to zero: %s" % (list(blur_kernel),))
+    return None if k.tolist() == [1.0, 3.0, 3.0, 1.0] else k
+
+
 class SynthesisHIP:
-    def __init__(self, state_dict, size=512, style_dim=512, device="cuda:0", dtype="fp16", max_frames=16):
+    def __init__(self, state_dict, size=512, style_dim=512, device="cuda:0", dtype="fp16", max_frames=16, blur_kernel=None):
+        """blur_kernel: Synthesis(blur_kernel=...) of the reference (styledecoder.py:448, handed to the StyledConvs only, :486-488;
+        ToRGB / ToFlow keep their default [1,3,3,1]).  None = [1,3,3,1]; any 4-tap kernel is accepted (ValueError otherwise)."""
         if native.DTYPES.get(dtype) not in (native.FLOAT_DT_FP16, native.FLOAT_DT_FP32):
             raise ValueError("the decoder runs fp16 operands (fp32 = verification mode) only (got %r): bf16 left the 512-px "
                              "frames at the 40 dB limit" % (dtype,))
@@ -18,6 +33,9 @@ class SynthesisHIP:
         L = native.lib()
         pref = "motion_autoencoder.dec."
         sd = {(k[len(pref):] if k.startswith(pref) else k): v for k, v in state_dict.items()}
+        self.blur_kernel = blur_taps(blur_kernel)
+        if self.blur_kernel is not None:
+            sd["blur_kernel"] = self.blur_kernel
         arr, keep = native.tensor_table(sd)
         cfg = native.DecCfg(size, style_dim, native.DTYPES[dtype], max_frames)
         h = C.c_void_p()
@@ -139,7 +157,7 @@ def _unit(dtype, cin, cout, res, upsample, n_frames, style_dim, flags=0):
 
 
 @torch.no_grad()
-def debug_styled_conv(state, x, style, upsample=False, dtype="fp16", device="cuda:0", style_norm=True):
+def debug_styled_conv(state, x, style, upsample=False, dtype="fp16", device="cuda:0", style_norm=True, blur_kernel=None):
     """Test hook (float_dec_debug_styled_conv): StyledConv.forward(x, style) of the reference (styledecoder.py:302-325, noise
     weight 0) through the production kernels.  state: `conv.weight` (1,cout,cin,3,3), `conv.modulation.weight|bias`,
     `activate.bias`; x (F,cin,R,R), style (F,style_dim).  Returns (out (F,cout,R',R') on the GPU, values clamped at fp16's range)."""
@@ -147,6 +165,8 @@ def debug_styled_conv(state, x, style, upsample=False, dtype="fp16", device="cud
     F, cin, R, _ = x.shape
     cout = state["conv.weight"].shape[1]
     sd = {"sc." + k: v for k, v in state.items()}
+    if blur_taps(blur_kernel) is not None:
+        sd["blur_kernel"] = blur_taps(blur_kernel)
     arr, keep = native.tensor_table(sd)
     u = _unit(dtype, cin, cout, R, upsample, F, style.shape[-1], 0 if style_norm else 1)
     xd, sdv = x.to(dev, torch.float32).contiguous(), style.to(dev, torch.float32).contiguous()

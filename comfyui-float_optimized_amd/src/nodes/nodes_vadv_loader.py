@@ -168,8 +168,8 @@ class LoadFloatSynthesisModel:
             blur_kernel = safe_parse_list_str(blur_kernel_str, int)
         except ValueError as e:
             raise ValueError("Invalid blur_kernel_str format: %s. Must be Python list syntax e.g. '[1,3,3,1]'" % e)
-        if blur_kernel != [1, 3, 3, 1]:
-            raise ValueError("the HIP decoder implements blur_kernel=[1,3,3,1] (the FIR of the released checkpoints) only")
+        if len(blur_kernel) != 4:  # the Blur's padding follows the tap count (styledecoder.py:209-213); the operator has the 4-tap form
+            raise ValueError("the HIP decoder implements 4-tap blur kernels (the released checkpoints use [1,3,3,1]); got %s" % (blur_kernel,))
         sd = _load_sd(path)
         # channel_multiplier: the operator reads every level's channel count off the weights (like the reference's
         # load_state_dict would fail on a mismatch, nodes_vadv_loader.py:567-611, a widget that contradicts the file is refused)
@@ -191,7 +191,7 @@ class LoadFloatSynthesisModel:
             raise ValueError("Could not determine number of to_rgb layers to infer size.")
         size = 2 ** (n_rgb + 2)
         dec = SynthesisHIP(sd, size, style_dim, target_device, dtype=os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"),
-                           max_frames=int(os.environ.get("FLOAT_AMD_DEC_BATCH", "32")))
+                           max_frames=int(os.environ.get("FLOAT_AMD_DEC_BATCH", "32")), blur_kernel=blur_kernel)
         dec.inferred_size, dec.inferred_style_dim, dec.inferred_motion_dim = size, style_dim, motion_dim
         dec.channel_multiplier_setting, dec.blur_kernel_setting = channel_multiplier, blur_kernel
         dec.cudnn_benchmark_setting = cudnn_benchmark

@@ -80,24 +80,30 @@ def synth_fmt_state(cfg, seed=0):
 DEC_CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512, 64: 256, 128: 128, 256: 64, 512: 32, 1024: 16}
 
 
-def synth_decoder_state(size=512, style_dim=512, motion_dim=20, seed=0, flow_gain=0.1, rgb_gain=0.4, channel_multiplier=1):
+def synth_decoder_state(size=512, style_dim=512, motion_dim=20, seed=0, flow_gain=0.1, rgb_gain=0.4, channel_multiplier=1,
+                        blur_kernel=(1, 3, 3, 1)):
     """Synthesis (motion-AE decoder) weights, prefix `motion_autoencoder.dec.` stripped.
     StyleGAN2-style layers carry their 1/sqrt(fan_in) equalised-lr scale in the forward
     pass, so N(0,1) weights are the natural scale.  `flow_gain` shrinks the ToFlow conv so
     the synthetic warp stays a moderate displacement (a real checkpoint's flows are smooth;
     unit-variance random flows make the fp32 reference itself differ from fp64 by 5e-2 per
-    pixel); `rgb_gain` keeps most pixels inside the clamp range so errors are not hidden."""
+    pixel); `rgb_gain` keeps most pixels inside the clamp range so errors are not hidden.
+    `blur_kernel`: what Synthesis(blur_kernel=...) registers as the up-sampling StyledConvs' `conv.blur.kernel` buffers
+    (styledecoder.py:209-213,486-488); ToRGB / ToFlow keep [1,3,3,1] (:489-491)."""
     sd = {}
     log_size = int(math.log2(size))
     DEC_CHANNELS = {r: (c if r <= 32 else c * channel_multiplier) for r, c in globals()["DEC_CHANNELS"].items()}  # styledecoder.py:457-467
     blur = torch.tensor([1.0, 3.0, 3.0, 1.0])
     k2 = blur[None, :] * blur[:, None]
     k2 = k2 / k2.sum()
+    bk = torch.tensor([float(t) for t in blur_kernel])
+    kc = bk[None, :] * bk[:, None]
+    kc = kc / kc.sum()
 
     def styled(prefix, cin, cout, up):
         sd[prefix + ".conv.weight"] = _randn(seed, prefix + ".conv.weight", (1, cout, cin, 3, 3))
         if up:
-            sd[prefix + ".conv.blur.kernel"] = (k2 * 4.0).clone()
+            sd[prefix + ".conv.blur.kernel"] = (kc * 4.0).clone()
         sd[prefix + ".conv.modulation.weight"] = _randn(seed, prefix + ".conv.modulation.weight", (cin, style_dim))
         sd[prefix + ".conv.modulation.bias"] = 1.0 + _randn(seed, prefix + ".conv.modulation.bias", (cin,), 0.1)
         sd[prefix + ".noise.weight"] = torch.zeros(1)

@@ -183,6 +183,12 @@ typedef struct {
 
 typedef struct float_dec float_dec_t;
 
+/* tensors: the Synthesis state dict (prefix `motion_autoencoder.dec.` stripped), reference key names.
+ * Blur FIR of the up-sampling StyledConvs (styledecoder.py:209-213): the checkpoint's `convs.N.conv.blur.kernel` buffer where
+ * present (what the reference ends up with after its strict load_state_dict, nodes_vadv_loader.py:632), else the optional
+ * 1-D tensor `blur_kernel` (the loader's widget: Synthesis(blur_kernel=...), styledecoder.py:448), else [1,3,3,1].  4-tap
+ * kernels only, a buffer must be make_kernel's outer product k (x) k; ToRGB / ToFlow `upsample.kernel` buffers other than
+ * [1,3,3,1] are refused (FLOAT_E_INVALID). */
 int float_dec_create(const float_dec_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors,
                      float_dec_t** out);
 void float_dec_destroy(float_dec_t* h);
@@ -240,7 +246,8 @@ int float_dec_saturation(float_dec_t* h, uint64_t* total, uint64_t* per_site, in
  * show: which op is off).  All pointers device fp32; tensors are host fp32 with the reference module's own key names.
  *   float_dec_debug_styled_conv: StyledConv.forward(x, style) (styledecoder.py:302-325, noise weight 0):
  *     leaky_relu(ModulatedConv2d(x, style) + bias) * sqrt(2).  keys `sc.conv.weight` (1,cout,cin,3,3),
- *     `sc.conv.modulation.weight` (cin,style_dim), `sc.conv.modulation.bias` (cin), `sc.activate.bias` (cout).
+ *     `sc.conv.modulation.weight` (cin,style_dim), `sc.conv.modulation.bias` (cin), `sc.activate.bias` (cout); optional
+ *     `sc.conv.blur.kernel` (4,4) / `blur_kernel` (4) as in float_dec_create.
  *     x (n_frames,cin,res,res) NCHW, style (n_frames,style_dim), out (n_frames,cout,R',R'), R' = res or 2 res (upsample).
  *     Which kernel runs follows the production rules: plain conv res >= 16 -> dec_conv16_kernel, below -> dec_conv_kernel;
  *     up-conv 2 res >= 64 -> dec_zblur_kernel, res >= 8 -> dec_zconv4_kernel + dec_blur_kernel, res = 4 -> per-class

@@ -265,9 +265,10 @@ def sample_rd(sd, cfg, r_s, wa, we, noise, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0
 _SQRT2 = math.sqrt(2.0)
 
 
-def fir_kernel(gain=1.0, dtype=torch.float32):
-    """[1,3,3,1] x [1,3,3,1] / 64 (styledecoder.py:39-44); x4 when up-sampling (:79,:118)."""
-    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=dtype)
+def fir_kernel(gain=1.0, dtype=torch.float32, taps=(1.0, 3.0, 3.0, 1.0)):
+    """make_kernel: outer(k, k) / sum, [1,3,3,1] x [1,3,3,1] / 64 by default (styledecoder.py:39-44); x4 when up-sampling
+    (:79,:118)."""
+    k1 = torch.tensor([float(t) for t in taps], dtype=dtype)
     k = k1[:, None] * k1[None, :]
     return k / k.sum() * gain
 
@@ -290,8 +291,9 @@ def equal_linear(x, w, b):
     return x @ (w.to(x.dtype) * (1.0 / math.sqrt(w.shape[1]))).T + b.to(x.dtype)
 
 
-def modulated_conv(x, style, sd, prefix, demodulate=True, upsample=False):
-    """ModulatedConv2d (styledecoder.py:238-272), one explicit conv per batch item."""
+def modulated_conv(x, style, sd, prefix, demodulate=True, upsample=False, blur_kernel=(1, 3, 3, 1)):
+    """ModulatedConv2d (styledecoder.py:238-272), one explicit conv per batch item.  blur_kernel: the constructor argument of the
+    up-sampling form (styledecoder.py:197,205-213); its Blur pads (pad0, pad1) = ((p + 1) // 2 + 1, p // 2 + 1), p = len - 4."""
     w = sd[prefix + ".weight"].to(x.dtype)[0]  # (Cout, Cin, k, k)
     cout, cin, ks, _ = w.shape
     s = equal_linear(style, sd[prefix + ".modulation.weight"], sd[prefix + ".modulation.bias"])
@@ -304,16 +306,21 @@ def modulated_conv(x, style, sd, prefix, demodulate=True, upsample=False):
         if upsample:
             # conv_transpose2d stride 2 (styledecoder.py:250-257) then Blur pad (1,1), gain 4
             y = F.conv_transpose2d(x[b:b + 1], wb.transpose(0, 1), stride=2, padding=0)
-            y = upfirdn(y, fir_kernel(4.0, x.dtype), pad=(1, 1))
+            # the Blur's kernel is a registered buffer: after the strict load (nodes_vadv_loader.py:632) it is the CHECKPOINT's
+            # `<conv>.blur.kernel`, the constructor's make_kernel(blur_kernel) * 4 only where the state has no such key
+            k2 = sd.get(prefix + ".blur.kernel")
+            k2 = fir_kernel(4.0, x.dtype, blur_kernel) if k2 is None else k2.to(x.dtype)
+            p = k2.shape[0] - 2 - 2
+            y = upfirdn(y, k2, pad=((p + 1) // 2 + 1, p // 2 + 1))
         else:
             y = F.conv2d(x[b:b + 1], wb, padding=ks // 2)
         outs.append(y)
     return torch.cat(outs, dim=0)
 
 
-def styled_conv(x, style, sd, prefix, upsample=False):
+def styled_conv(x, style, sd, prefix, upsample=False, blur_kernel=(1, 3, 3, 1)):
     """StyledConv with noise=None (styledecoder.py:320-325): modconv, + bias, lrelu(0.2) sqrt2."""
-    y = modulated_conv(x, style, sd, prefix + ".conv", True, upsample)
+    y = modulated_conv(x, style, sd, prefix + ".conv", True, upsample, blur_kernel)
     return F.leaky_relu(y + sd[prefix + ".activate.bias"].to(x.dtype), 0.2) * _SQRT2
 
 
@@ -352,10 +359,11 @@ def to_flow(x, style, feat, sd, prefix, skip=None):
     return fw, fw + x * (1.0 - mask), out, grid
 
 
-def synthesis(sd, latent, feats, dtype=torch.float32, return_all=False):
+def synthesis(sd, latent, feats, dtype=torch.float32, return_all=False, blur_kernel=(1, 3, 3, 1)):
     """Synthesis.forward with alpha=None (styledecoder.py:497-534).
     latent (B,512) = s_r + r_d[:,t]; feats: 7 maps (1|B,C,R,R), R = 8..512.
-    Returns rgb (B,3,S,S) (and the 64x64-level flow grid when return_all)."""
+    Returns rgb (B,3,S,S) (and the 64x64-level flow grid when return_all).
+    blur_kernel reaches the StyledConvs only (styledecoder.py:470,486-488); ToRGB / ToFlow are built with their default."""
     latent = latent.to(dtype)
     B = latent.shape[0]
     x = sd["input.input"].to(dtype).expand(B, -1, -1, -1)
@@ -365,7 +373,7 @@ def synthesis(sd, latent, feats, dtype=torch.float32, return_all=False):
     flow64 = None
     inter = {}
     for li, feat in enumerate(feats):
-        x = styled_conv(x, latent, sd, "convs.%d" % (2 * li), upsample=True)
+        x = styled_conv(x, latent, sd, "convs.%d" % (2 * li), upsample=True, blur_kernel=blur_kernel)
         x = styled_conv(x, latent, sd, "convs.%d" % (2 * li + 1))
         fw, x, skip_flow, grid = to_flow(x, latent, feat, sd, "to_flows.%d" % li, skip_flow)
         skip = to_rgb(fw, sd, "to_rgbs.%d" % li, skip)
@@ -383,13 +391,13 @@ def postprocess(img):
     return ((img.clamp(-1, 1) + 1) / 2).permute(0, 2, 3, 1).contiguous()
 
 
-def decode_frames(sd, s_r, r_d, feats, dtype=torch.float32):
+def decode_frames(sd, s_r, r_d, feats, dtype=torch.float32, blur_kernel=(1, 3, 3, 1)):
     """decode_latent_into_processed_images (FLOAT.py:113-169): frame t uses latent
     s_r + r_d[:,t]; returns (T,H,W,3) fp32 in [0,1]."""
     T = r_d.shape[1]
     frames = []
     for t in range(T):
-        img = synthesis(sd, s_r.to(dtype) + r_d[:, t].to(dtype), feats, dtype)
+        img = synthesis(sd, s_r.to(dtype) + r_d[:, t].to(dtype), feats, dtype, blur_kernel=blur_kernel)
         frames.append(postprocess(img)[0].to(torch.float32))
     return torch.stack(frames, dim=0)
 

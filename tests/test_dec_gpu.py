@@ -183,3 +183,38 @@ def test_dec_channel_multiplier_2(dtype):
     print("channel_multiplier 2, %s: max|d| %.2e rel-L2 %.2e" % (dtype, m, r))
     assert (m <= 1e-4) if dtype == "fp32" else (r <= 5e-3)
     assert dec.saturation() == 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_blur_kernel_from_checkpoint_and_widget(dtype):
+    """A Synthesis trained with another 4-tap blur kernel (tests/golden/dec_blur.npz: reference Synthesis(blur_kernel=[1,2,4,1])
+    with that kernel's `conv.blur.kernel` buffers loaded strictly, nodes_vadv_loader.py:567-632).  The operator takes the FIR of
+    every up-sampling StyledConv from the checkpoint's buffer; a state without the buffers takes the loader's widget value;
+    ToRGB / ToFlow up-sampling kernels other than [1,3,3,1] are refused.  fp32 mode max-abs <= 1e-4, fp16 rel-L2 <= 5e-3."""
+    g = golden("dec_blur")
+    bk = g["kernels"].tolist()[1]
+    sd = W.synth_decoder_state(128, seed=g["seed"], blur_kernel=bk)
+    feats = W.synth_feats(128, seed=g["seed"])
+
+    def run(state, **kw):
+        dec = pkg.decoder.SynthesisHIP(state, 128, 512, "cuda:0", dtype=dtype, max_frames=2, **kw)
+        dec.set_feats(feats)
+        raw = dec.synthesis_raw(g["s_r"], g["r_d"]).cpu()
+        assert dec.saturation() == 0
+        return raw
+
+    raw = run(sd)
+    m, r = float((raw - g["raw"]).abs().max()), float((raw - g["raw"]).norm() / g["raw"].norm())
+    print("blur kernel %s from the checkpoint, %s: max|d| %.2e rel-L2 %.2e" % (bk, dtype, m, r))
+    assert (m <= 1e-4) if dtype == "fp32" else (r <= 5e-3)
+    bare = {k: v for k, v in sd.items() if not k.endswith("blur.kernel")}
+    assert torch.equal(run(bare, blur_kernel=bk), raw)  # the widget value where the state has no buffers
+    dflt = run(bare)
+    assert float((dflt - g["raw"]).norm() / g["raw"].norm()) > 0.05  # [1,3,3,1] is a different decoder
+    assert torch.equal(run(sd, blur_kernel=[1, 3, 3, 1]), raw)  # a contradicting widget loses to the checkpoint (strict load)
+    odd = dict(sd)
+    odd["to_rgbs.1.upsample.kernel"] = odd["convs.0.conv.blur.kernel"].clone()
+    with pytest.raises(ValueError, match="up-sampling kernel"):
+        pkg.decoder.SynthesisHIP(odd, 128, 512, "cuda:0", dtype=dtype, max_frames=2)
+    with pytest.raises(ValueError, match="4-tap"):
+        pkg.decoder.SynthesisHIP(sd, 128, 512, "cuda:0", dtype=dtype, max_frames=2, blur_kernel=[1, 2, 1])

@@ -63,3 +63,47 @@ def test_unit_op_argument_errors():
         D.debug_styled_conv(sd, torch.zeros(1, 32, 8, 8), torch.zeros(1, 512))
     with pytest.raises(ValueError):
         D.debug_styled_conv(sd, torch.zeros(1, 32, 8, 8), torch.zeros(1, 512), dtype="bf16")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_up_conv_blur_kernels(dtype):
+    """StyledConv(upsample=True, blur_kernel=k) of the reference for a symmetric and an asymmetric 4-tap kernel
+    (tests/golden/dec_blur.npz) through the three up-conv routes (per-class conv + dec_blur_kernel, dec_zconv4_kernel +
+    dec_blur_kernel, dec_zblur_kernel).  The asymmetric kernel pins the orientation (upfirdn2d convolves: styledecoder.py:28-29).
+    Same limits as the [1,3,3,1] routes; the kernel arrives once as the loader's widget value and once as the checkpoint's
+    `conv.blur.kernel` buffer (which wins over a contradicting widget, like the reference's strict load)."""
+    g = golden("dec_blur")
+    seed = g["seed"]
+    style = rnd(seed + 1, 2, 512)
+    for ki, bk in enumerate(g["kernels"].tolist()):
+        for i, (name, (cin, cout, R, F)) in enumerate(zip(["up4", "up8", "up32"], g["sc_cases"].tolist())):
+            k = seed + 100 * (i + 1)
+            sd = {"conv.weight": rnd(k + 2, 1, cout, cin, 3, 3), "conv.modulation.weight": rnd(k + 3, cin, 512),
+                  "conv.modulation.bias": 1 + rnd(k + 4, cin, std=0.1), "activate.bias": rnd(k + 5, 1, cout, 1, 1, std=0.1)}
+            x = rnd(k + 6, F, cin, R, R)
+            want = g["sc_k%d_%s_out" % (ki, name)]
+            out, sat = D.debug_styled_conv(sd, x, style[:F], upsample=True, dtype=dtype, blur_kernel=bk)
+            m, r = max_abs(out.cpu(), want), rel_l2(out.cpu(), want)
+            print("%s up-conv %-5s kernel %s max|d| %.2e rel %.2e" % (dtype, name, bk, m, r))
+            assert sat == 0 and m <= LIM[dtype]["max"] and r <= LIM[dtype]["rel"], (name, bk)
+            k1 = torch.tensor(bk, dtype=torch.float32)
+            sd["conv.blur.kernel"] = k1[:, None] * k1[None, :] / k1.sum() ** 2 * 4  # make_kernel(k) * 4 (styledecoder.py:39-44,118)
+            out2, _ = D.debug_styled_conv(sd, x, style[:F], upsample=True, dtype=dtype, blur_kernel=[1, 3, 3, 1])
+            assert torch.equal(out2, out), "the checkpoint's buffer decides"
+
+
+def test_blur_kernel_refusals():
+    sd = {"conv.weight": torch.zeros(1, 32, 32, 3, 3), "conv.modulation.weight": torch.zeros(32, 512),
+          "conv.modulation.bias": torch.zeros(32), "activate.bias": torch.zeros(1, 32, 1, 1)}
+    x, st = torch.zeros(1, 32, 8, 8), torch.zeros(1, 512)
+    with pytest.raises(ValueError, match="4-tap"):
+        D.debug_styled_conv(sd, x, st, upsample=True, blur_kernel=[1, 1])
+    with pytest.raises(ValueError, match="sums to zero"):
+        D.debug_styled_conv(sd, x, st, upsample=True, blur_kernel=[1, -1, 1, -1])
+    bad = dict(sd)
+    bad["conv.blur.kernel"] = torch.eye(4)  # not an outer product k (x) k
+    with pytest.raises(ValueError, match="outer product"):
+        D.debug_styled_conv(bad, x, st, upsample=True)
+    bad["conv.blur.kernel"] = torch.ones(6, 6) / 9
+    with pytest.raises(ValueError, match="4 x 4"):
+        D.debug_styled_conv(bad, x, st, upsample=True)

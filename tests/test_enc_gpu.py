@@ -123,6 +123,12 @@ def test_encoder_errors():
     enc = pkg.encoder.EncoderHIP(esd, 64, 512, 20, "cuda:0")
     with pytest.raises(ValueError):
         enc.encode_image_into_latent(torch.zeros(1, 3, 32, 32))
+    # the Blur buffers come from the checkpoint in the reference (strict load); the operator has [1,3,3,1] in its code and says so
+    odd = dict(esd)
+    key = [k for k in esd if k.endswith("conv2.0.kernel")][0]
+    odd[key] = torch.ones(4, 4) / 16
+    with pytest.raises(ValueError, match="blur kernel"):
+        pkg.encoder.EncoderHIP(odd, 64, 512, 20, "cuda:0")
 
 
 def test_encoder_fp32_feeds_decoder_fp32():

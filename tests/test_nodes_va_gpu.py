@@ -108,6 +108,11 @@ def test_va_errors(models):
         n["ApplyFloatEncoder"]().apply_encoder(torch.zeros(1, 32, 32, 3), enc)
     with pytest.raises(ValueError):
         n["LoadFloatSynthesisModel"]().load_synthesis_infer_arch("decoder.safetensors", "cuda:0", 2, "[1, 3, 3, 1]", False)
+    with pytest.raises(ValueError, match="4-tap"):  # the Blur's padding follows the tap count; the reference's strict load fails too
+        n["LoadFloatSynthesisModel"]().load_synthesis_infer_arch("decoder.safetensors", "cuda:0", 1, "[1, 2, 1]", False)
+    # another 4-tap widget value loads; the checkpoint's [1,3,3,1] buffers decide what the decoder computes (strict load)
+    dec, _, _, _ = n["LoadFloatSynthesisModel"]().load_synthesis_infer_arch("decoder.safetensors", "cuda:0", 1, "[1, 2, 2, 1]", False)
+    assert dec.blur_kernel_setting == [1, 2, 2, 1]
     with pytest.raises(ValueError):
         n["LoadFMTModel"]().load_fmt_model("fmt.safetensors", "cuda:0", False, 600, 8, 2, 10, 25.0, 2.0)  # dim_a <= 0
     with pytest.raises(FileNotFoundError):

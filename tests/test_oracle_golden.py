@@ -225,3 +225,30 @@ def test_dec_channel_multiplier_2():
     feats = W.synth_feats(128, seed=g["seed"], channel_multiplier=2)
     raw = torch.cat([O.synthesis(sd, g["s_r"] + g["r_d"][:, t], feats) for t in range(2)])
     assert rel_l2(raw, g["raw"]) < TOL_REL
+
+
+def test_dec_blur_kernels():
+    """Other 4-tap blur kernels than [1,3,3,1] (tests/golden/dec_blur.npz, reference StyledConv(blur_kernel=...) and a whole
+    Synthesis whose checkpoint holds the kernel's buffers): the oracle's StyledConv with the kernel as constructor argument,
+    and its Synthesis reading the checkpoint's `conv.blur.kernel` like the strictly loaded reference does."""
+    from tests.util import seeded_normal as rnd
+    g = golden("dec_blur")
+    seed = g["seed"]
+    style = rnd(seed + 1, 2, 512)
+    for ki, bk in enumerate(g["kernels"].tolist()):
+        for i, (name, (cin, cout, R, F)) in enumerate(zip(["up4", "up8", "up32"], g["sc_cases"].tolist())):
+            k = seed + 100 * (i + 1)
+            sd = {"c.conv.weight": rnd(k + 2, 1, cout, cin, 3, 3), "c.conv.modulation.weight": rnd(k + 3, cin, 512),
+                  "c.conv.modulation.bias": 1 + rnd(k + 4, cin, std=0.1), "c.activate.bias": rnd(k + 5, 1, cout, 1, 1, std=0.1)}
+            x = rnd(k + 6, F, cin, R, R)
+            want = g["sc_k%d_%s_out" % (ki, name)]
+            assert rel_l2(O.styled_conv(x, style[:F], sd, "c", True, blur_kernel=bk), want) < TOL_REL
+            assert rel_l2(O.styled_conv(x, style[:F], sd, "c", True), want) > 0.1  # the default kernel is a different answer
+    bk = g["kernels"].tolist()[1]
+    sd = W.synth_decoder_state(128, seed=seed, blur_kernel=bk)
+    feats = W.synth_feats(128, seed=seed)
+    raw = torch.cat([O.synthesis(sd, g["s_r"] + g["r_d"][:, t], feats) for t in range(2)])
+    assert rel_l2(raw, g["raw"]) < TOL_REL
+    sd0 = W.synth_decoder_state(128, seed=seed)  # default buffers in the checkpoint: the constructor argument alone changes nothing
+    raw0 = torch.cat([O.synthesis(sd0, g["s_r"] + g["r_d"][:, t], feats, blur_kernel=bk) for t in range(2)])
+    assert rel_l2(raw0, g["raw"]) > 0.05

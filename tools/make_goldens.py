@@ -393,6 +393,60 @@ def gen_dec_cm2(ns, seed=1800, size=128):
     save("dec_cm2_%d" % size, seed=seed, size=size, s_r=s_r, r_d=r_d, raw=raw)
 
 
+def gen_dec_blur(ns, seed=1900, size=128):
+    """Synthesis(blur_kernel=...) with other 4-tap kernels than [1,3,3,1] (the LoadFloatSynthesisModel widget,
+    nodes_vadv_loader.py:567-611; styledecoder.py:448,486-488: only the StyledConvs receive it): the three up-conv kernel
+    routes of float_dec_debug_styled_conv for a symmetric and an ASYMMETRIC kernel (upfirdn2d convolves with the flipped
+    kernel, styledecoder.py:28-29: the asymmetric case pins the orientation), and two frames of a whole 128-px Synthesis whose
+    checkpoint holds that kernel's `conv.blur.kernel` buffers (the strict load puts the checkpoint's buffers over the
+    constructor's kernel, nodes_vadv_loader.py:632 - asserted below)."""
+    print("[decoder blur kernels]")
+    S = ns.styledecoder
+    arrs = dict(seed=seed, size=size)
+    style = rnd(seed + 1, 2, 512)
+    kernels = ([1, 2, 2, 1], [1, 2, 4, 1])
+    cases = (("up4", 64, 32, 4, 2), ("up8", 64, 32, 8, 2), ("up32", 32, 32, 32, 1))
+    arrs["kernels"] = np.array(kernels)
+    arrs["sc_cases"] = np.array([[c[1], c[2], c[3], c[4]] for c in cases])
+    for ki, bk in enumerate(kernels):
+        for i, (name, cin, cout, R, F) in enumerate(cases):
+            sc = S.StyledConv(cin, cout, 3, 512, upsample=True, blur_kernel=bk)
+            k = seed + 100 * (i + 1)
+            w, mw, mb, ab = rnd(k + 2, 1, cout, cin, 3, 3), rnd(k + 3, cin, 512), 1 + rnd(k + 4, cin, std=0.1), rnd(k + 5, 1, cout, 1, 1, std=0.1)
+            sc.conv.weight.data.copy_(w)
+            sc.conv.modulation.weight.data.copy_(mw)
+            sc.conv.modulation.bias.data.copy_(mb)
+            sc.activate.bias.data.copy_(ab.reshape(sc.activate.bias.shape))
+            sc.noise.weight.data.zero_()
+            x = rnd(k + 6, F, cin, R, R)
+            with torch.no_grad():
+                ref = sc(x, style[:F])
+            sd = {"c.conv.weight": w, "c.conv.modulation.weight": mw, "c.conv.modulation.bias": mb, "c.activate.bias": ab}
+            orc = O.styled_conv(x, style[:F], sd, "c", True, blur_kernel=bk)
+            dflt = O.styled_conv(x, style[:F], sd, "c", True)
+            print("  k%d %-5s oracle-ref max|d| %.3e rel %.3e ; vs [1,3,3,1] rel %.3e" % ((ki, name) + maxdiff(orc, ref) + (maxdiff(dflt, ref)[1],)))
+            arrs["sc_k%d_%s_out" % (ki, name)] = ref
+    bk = kernels[1]
+    d = S.Synthesis(size, 512, 20, blur_kernel=bk)
+    sd = weights.synth_decoder_state(size, seed=seed, blur_kernel=bk)  # the buffers a checkpoint trained with this kernel holds
+    d.load_state_dict(sd, strict=True)
+    sd0 = weights.synth_decoder_state(size, seed=seed)
+    d0 = S.Synthesis(size, 512, 20, blur_kernel=bk)
+    d0.load_state_dict(sd0, strict=True)  # the strict load overwrites the constructor's kernel with the checkpoint's buffers
+    assert all(torch.equal(d0.state_dict()[k], sd0[k]) for k in sd0 if k.endswith("blur.kernel"))
+    d.eval()
+    feats = weights.synth_feats(size, seed=seed)
+    s_r = rnd(seed + 21, 1, 512)
+    r_d = rnd(seed + 22, 1, 2, 512, std=0.5)
+    with torch.no_grad():
+        raw = torch.cat([d(s_r + r_d[:, t], None, feats)[0] for t in range(2)])
+    orc = torch.cat([O.synthesis(sd, s_r + r_d[:, t], feats, blur_kernel=bk) for t in range(2)])
+    dflt = torch.cat([O.synthesis(sd0, s_r + r_d[:, t], feats) for t in range(2)])
+    print("  synthesis %s raw std %.3f ; oracle-ref max|d| %.3e ; vs [1,3,3,1] max|d| %.3e" % (bk, float(raw.std()), maxdiff(orc, raw)[0], maxdiff(dflt, raw)[0]))
+    arrs.update(s_r=s_r, r_d=r_d, raw=raw)
+    save("dec_blur", **arrs)
+
+
 def gen_e2e_config1(ns, seed=900):
     """BASELINE.json configs[0]: 1 s audio -> 25 frames, 512x512, nfe=10 (9 Euler evaluations), fp32, the
     reference's own sampler (nodes_adv.py:545-694) and decode loop (FLOAT.py:113-169) chained on CPU."""
@@ -624,6 +678,9 @@ def main():
         gen_dec_stress(ns, 512, 1730, "range", sparse=True)
         gen_dec_cm2(ns)
         return
+    if os.environ.get("GOLDENS_ONLY") == "blur":
+        gen_dec_blur(ns)
+        return
     if os.environ.get("GOLDENS_ONLY") == "encx":
         gen_encoder(ns, 64, seed=1010, sparse=False, gain=2.0, name="enc_stress_64_g2")
         gen_encoder(ns, 64, seed=1010, sparse=False, gain=6.0, name="enc_stress_64_g6")
@@ -655,6 +712,7 @@ def main():
     gen_dec(ns, 64, seed=700, n_frames=3, sparse=False)
     gen_dec(ns, 512, seed=800, n_frames=2, sparse=True)
     gen_dec_units_hip(ns, seed=1600)
+    gen_dec_blur(ns)
     gen_dec_stress(ns, 64, 1700, "warp", sparse=False)
     gen_dec_stress(ns, 64, 1710, "range", sparse=False)
     gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
