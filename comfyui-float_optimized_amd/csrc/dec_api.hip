@@ -842,8 +842,16 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
                     ((uintptr_t)host_dev % 16 == 0) && ((uintptr_t)out % 16 == 0);
   h->ride.left16 = 0;
   h->ride.wleft = 0.0;
-  for (int s0 = 0; s0 < n_frames; s0 += kStyleCap) {
-    const int ns = std::min(kStyleCap, n_frames - s0);
+  // Ragged clips put their SHORT piece first at every level (style chunk, low group, high batch): the last batch of the call is
+  // then a full one.  A short last batch carried the previous full batch's copy in launches too short for it (its launches took
+  // as long as a full batch's) and the short first batch carries nothing.  FLOAT_DEC_SHORT_FIRST=0: remainder last.
+  static const bool short_first = env_int("FLOAT_DEC_SHORT_FIRST", 1, 0, 1) != 0;
+  auto piece = [](int done, int total, int cap) {
+    const int r = total % cap;
+    return (short_first && done == 0 && r) ? r : std::min(cap, total - done);
+  };
+  for (int s0 = 0, ns = 0; s0 < n_frames; s0 += ns) {
+    ns = piece(s0, n_frames, kStyleCap);
     // every style modulation (22 EqualLinears) and every demod factor for `ns` frames: 2 launches
     {
       constexpr int FB = 8;
@@ -873,15 +881,15 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
       dim3 g2((maxc + 255) / 256, (ns + FB - 1) / FB, (unsigned)h->convs.size());
       hipLaunchKernelGGL((dec_demod_all_kernel<FB>), g2, dim3(256), FB * maxcin * sizeof(float), st, d);
     }
-    for (int a0 = 0; a0 < ns; a0 += FL) {
-      const int na = std::min(FL, ns - a0);
+    for (int a0 = 0, na = 0; a0 < ns; a0 += na) {
+      na = piece(a0, ns, FL);
       const float* st_a = h->styles + (size_t)a0 * h->Stot;
       const float* dm_a = h->demod + (size_t)a0 * h->Dtot;
       int skip_idx = 0;
       int rc = run_low<T>(h, na, st_a, dm_a, &skip_idx, st);
       if (rc) return rc;
       for (int b0 = 0, nb = 0; b0 < na; b0 += nb) {
-        nb = std::min(FH, na - b0);
+        nb = piece(b0, na, FH);
         // ride-along hand-over: the very last batch of the call has no successor to carry its copy.  Cutting it in two so that
         // only FLOAT_DEC_RIDE_TAIL frames' copy stays exposed was measured and is off: 30.1 ms per 250 frames without, 31.0-31.8
         // with a tail of 4..16 frames (the smaller launches lose more than the shorter copy gains)
