@@ -9,6 +9,7 @@ from . import native
 from .config import AudioConfig
 
 
+@native.rebuildable
 class AudioEncoderHIP:
     """state_dict keys: `wav2vec2.*`, `audio_projection.{0,1}.*` (an `audio_encoder.` prefix is stripped) - the
     reference's AudioEncoder.state_dict()."""
@@ -45,6 +46,7 @@ class AudioEncoderHIP:
         with torch.cuda.device(self.device):
             native.check(native.lib().float_aud_create(C.byref(ncfg), arr, len(sd), C.byref(h)))
         self._h = h
+        self._reserved = (0, 0)  # a new handle has no workspace yet (also after a rebuild: native.rebuildable)
         del keep
 
     def saturation(self, reset=False):
@@ -91,6 +93,7 @@ class AudioEncoderHIP:
         return out
 
 
+@native.rebuildable
 class Audio2EmotionHIP(AudioEncoderHIP):
     """Speech-to-emotion (reference Audio2Emotion, FLOAT.py:378-401, on Wav2Vec2ForSpeechClassification,
     wav2vec2_ser.py:41-118): the wav2vec2-large variant of the same operator with the classification head.

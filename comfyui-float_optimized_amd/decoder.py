@@ -20,6 +20,7 @@ def blur_taps(blur_kernel):
     return None if k.tolist() == [1.0, 3.0, 3.0, 1.0] else k
 
 
+@native.rebuildable
 class SynthesisHIP:
     def __init__(self, state_dict, size=512, style_dim=512, device="cuda:0", dtype="fp16", max_frames=16, blur_kernel=None):
         """blur_kernel: Synthesis(blur_kernel=...) of the reference (styledecoder.py:448, handed to the StyledConvs only, :486-488;

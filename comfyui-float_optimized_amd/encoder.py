@@ -9,6 +9,7 @@ import torch
 from . import native
 
 
+@native.rebuildable
 class EncoderHIP:
     """Encoder(size, dim, dim_motion) (encoder.py:234-281).  `state_dict` uses the reference keys
     (`net_app.convs.*`, `fc.*`; a `motion_autoencoder.enc.` prefix is stripped); pass the decoder's
@@ -20,8 +21,8 @@ class EncoderHIP:
         self.dtype = dtype
         self.n_feats = int(math.log2(size)) - 2
         pref = "motion_autoencoder.enc."
-        sd = {(k[len(pref):] if k.startswith(pref) else k): v for k, v in state_dict.items()
-              if not k.endswith(".kernel")}  # Blur buffers are the fixed [1,3,3,1] FIR (encoder.py:59-71)
+        # the Blur buffers (`*.kernel`, encoder.py:59-71) travel too: the operator has [1,3,3,1] in its code and refuses others
+        sd = {(k[len(pref):] if k.startswith(pref) else k): v for k, v in state_dict.items()}
         if direction_weight is not None:
             sd["direction.weight"] = direction_weight
         self.has_direction = "direction.weight" in sd

@@ -10,6 +10,7 @@ from . import native
 from .config import FmtConfig
 
 
+@native.rebuildable
 class FlowMatchingTransformerHIP:
     """Holds packed weights + workspace on one GPU.  `sample` stacks up to `max_batch` clips per launch chain
     (float_fmt_sample_batch); the single-evaluation / single-window calls loop batch items on the host, like the

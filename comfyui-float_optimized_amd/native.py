@@ -196,3 +196,34 @@ def profile_ms(which):
     n = C.c_int64(0)
     ms = lib().float_profile_ms(which, C.byref(n))
     return ms, n.value
+
+
+def rebuildable(cls):
+    """Class decorator for the operator mirrors (one C handle in `_h`, released by `close()`): the object remembers its
+    constructor arguments - the host state dict among them - so that a released handle can be re-created.
+      op.offload()    frees every device allocation of the handle (packed weights, workspaces, graphs);
+      op.to_target()  re-creates it where it was (packing is deterministic: the rebuilt operator is bitwise the first);
+      op.resident     whether the handle exists.
+    The counterpart of the reference's `with model_to_target(logger, model)` around every node call (nodes.py:173-175,
+    nodes_vadv.py:107,192,275,347,437,520,697,807): weights on the target device inside, on the host after."""
+    init = cls.__init__
+
+    def __init__(self, *a, **k):
+        if "_ctor" not in self.__dict__:  # the outermost class of an inheritance chain records; re-creation keeps the record
+            self._ctor = (a, k)
+        init(self, *a, **k)
+
+    def offload(self):
+        self.close()
+
+    def to_target(self):
+        if not self.__dict__.get("_h"):
+            a, k = self._ctor
+            type(self).__init__(self, *a, **k)
+        return self
+
+    cls.__init__ = __init__
+    cls.offload = offload
+    cls.to_target = to_target
+    cls.resident = property(lambda self: bool(self.__dict__.get("_h")))
+    return cls

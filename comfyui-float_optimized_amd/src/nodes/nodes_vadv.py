@@ -3,7 +3,9 @@ Apply FLOAT Encoder, FLOAT Get Identity Reference, Sample Motion Sequence RD, Ap
 pair (feature extract + projection), which this build runs as ONE fused operator (float_aud_*).  Same class
 attributes, widget names/defaults and return tuples as the reference; tensors between nodes are CPU tensors like there.
 The emotion nodes run the speech-emotion operator (float_aud_classify)."""
+import contextlib
 import math
+import os
 
 import torch
 
@@ -16,6 +18,23 @@ from .nodes_vadv_loader import BASE_CATEGORY, build_audio_encoder
 from .options.base_options import BaseOptions
 
 SUFFIX = "(VA)"
+
+
+@contextlib.contextmanager
+def model_to_target(*ops):
+    """The reference wraps every VA node's model call in `with model_to_target(logger, model)` (nodes_vadv.py:107,192,275,347,
+    437,520,697,807): on the target device inside, back on the host after.  Here the operators stay resident by default (288 GB
+    of HBM; a rebuild costs seconds of host-side packing); FLOAT_AMD_OFFLOAD=always releases every handle after the call and
+    the next call rebuilds it from the host weights the loader object keeps (native.rebuildable) - bitwise the same results."""
+    for op in ops:
+        op.to_target()
+    try:
+        yield
+    finally:
+        if os.environ.get("FLOAT_AMD_OFFLOAD", "never").lower() == "always":
+            for op in ops:
+                torch.cuda.current_stream(op.device).synchronize()
+                op.offload()
 
 
 class ApplyFloatEncoder:
@@ -45,15 +64,17 @@ class ApplyFloatEncoder:
             raise ValueError("Image channels %d does not match expected input_nc %d." % (ch, nc))
         s = ref_image.permute(0, 3, 1, 2).contiguous() * 2.0 - 1.0  # nodes_vadv.py:345-347
         s_r, lam, feats = [], [], None
-        for b in range(s.shape[0]):  # the operator's batch is 1 (include/float_hip.h)
-            sb, lb, fb, _ = float_encoder.encode_image_into_latent(s[b])
-            s_r.append(sb)
-            lam.append(lb)
-            feats = [[f] for f in fb] if feats is None else [acc + [f] for acc, f in zip(feats, fb)]
-        pipe = {"h_source": torch.cat(s_r).cpu(), "feats": [torch.cat(f).cpu() for f in feats]}  # .cpu() synchronises
-        if float_encoder.dtype == "fp16":
-            report_range({"encoder": float_encoder.saturation(reset=True)}, "ApplyFloatEncoder")
-        return (pipe, torch.cat(lam).cpu(), float_encoder)
+        with model_to_target(float_encoder):
+            for b in range(s.shape[0]):  # the operator's batch is 1 (include/float_hip.h)
+                sb, lb, fb, _ = float_encoder.encode_image_into_latent(s[b])
+                s_r.append(sb)
+                lam.append(lb)
+                feats = [[f] for f in fb] if feats is None else [acc + [f] for acc, f in zip(feats, fb)]
+            pipe = {"h_source": torch.cat(s_r).cpu(), "feats": [torch.cat(f).cpu() for f in feats]}  # .cpu() synchronises
+            lam = torch.cat(lam).cpu()
+            if float_encoder.dtype == "fp16":
+                report_range({"encoder": float_encoder.saturation(reset=True)}, "ApplyFloatEncoder")
+        return (pipe, lam, float_encoder)
 
 
 class FloatGetIdentityReferenceVA:
@@ -77,7 +98,9 @@ class FloatGetIdentityReferenceVA:
         if r_s_lambda_latent.shape[1] != float_synthesis.inferred_motion_dim:
             raise ValueError("Dimension 1 of 'r_s_lambda_latent' should be (%d), got %d."
                              % (float_synthesis.inferred_motion_dim, r_s_lambda_latent.shape[1]))
-        return (float_synthesis, float_synthesis.direction(r_s_lambda_latent).cpu())
+        with model_to_target(float_synthesis):
+            r_s = float_synthesis.direction(r_s_lambda_latent).cpu()
+        return (float_synthesis, r_s)
 
 
 class FloatSampleMotionSequenceRD_VA:
@@ -130,7 +153,6 @@ class FloatSampleMotionSequenceRD_VA:
         # dropout probabilities are inert at inference (FMT.py:271-275 with train=False); atol/rtol do not act on a
         # fixed-grid solver: accepted for graph compatibility
         fmt, cfg = float_fmt_model, float_fmt_model.cfg
-        fmt.set_method(torchdiffeq_ode_method)
         T = wa_latent.shape[1]
         n_chunks = int(math.ceil(T / cfg.num_frames_for_clip))
         dev = fmt.device
@@ -140,10 +162,12 @@ class FloatSampleMotionSequenceRD_VA:
             noise = draw_noise(n_chunks, B, cfg, seed, device=dev)
         else:
             noise = torch.stack([torch.randn(B, cfg.num_frames_for_clip, cfg.dim_w, device=dev) for _ in range(n_chunks)])
-        r_d = fmt.sample(r_s_latent, wa_latent, we_latent, noise, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg)
-        r_d_cpu = r_d.cpu()  # synchronises
-        if fmt.dtype == "fp16":
-            report_range({"fmt": fmt.saturation(reset=True)}, "FloatSampleMotionSequenceRD_VA")
+        with model_to_target(fmt):
+            fmt.set_method(torchdiffeq_ode_method)  # a rebuilt handle starts from the default solver
+            r_d = fmt.sample(r_s_latent, wa_latent, we_latent, noise, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale, include_r_cfg)
+            r_d_cpu = r_d.cpu()  # synchronises
+            if fmt.dtype == "fp16":
+                report_range({"fmt": fmt.saturation(reset=True)}, "FloatSampleMotionSequenceRD_VA")
         return (r_d_cpu, fmt)
 
 
@@ -182,12 +206,14 @@ class ApplyFloatSynthesis:
         T = r_d_latents.shape[1]
         host = torch.empty((B * T, size, size, BaseOptions().input_nc), dtype=torch.float32, pin_memory=True)
         staging = None
-        for b in range(B):
-            float_synthesis.set_feats([f[b:b + 1] for f in feats])
-            staging = float_synthesis.decode_into_host(s_r[b:b + 1], r_d_latents[b], host[b * T:(b + 1) * T], staging)
-        torch.cuda.current_stream(float_synthesis.device).synchronize()
-        if float_synthesis.dtype == "fp16":  # an fp16 decoder that left its range must not hand over black regions silently
-            report_range({"decoder": float_synthesis.saturation(reset=True)}, "ApplyFloatSynthesis")
+        with model_to_target(float_synthesis):
+            for b in range(B):
+                float_synthesis.set_feats([f[b:b + 1] for f in feats])
+                staging = float_synthesis.decode_into_host(s_r[b:b + 1], r_d_latents[b], host[b * T:(b + 1) * T], staging)
+            torch.cuda.current_stream(float_synthesis.device).synchronize()
+            if float_synthesis.dtype == "fp16":  # an fp16 decoder that left its range must not hand over black regions silently
+                report_range({"decoder": float_synthesis.saturation(reset=True)}, "ApplyFloatSynthesis")
+        del staging
         return (host, float_synthesis)
 
 
@@ -269,8 +295,10 @@ class FloatApplyAudioProjection:
         if key not in cache:
             cache[key] = build_audio_encoder(wav2vec_features.pipe, projection_layer, wav2vec_features.only_last)
         enc = cache[key]
-        enc.fps = wav2vec_features.fps
-        return (enc.inference(wav2vec_features.audio, wav2vec_features.n_frames).cpu(),)
+        with model_to_target(enc):
+            enc.fps = wav2vec_features.fps
+            wa = enc.inference(wav2vec_features.audio, wav2vec_features.n_frames).cpu()
+        return (wa,)
 
 
 class FloatExtractEmotionWithCustomModel:
@@ -308,7 +336,8 @@ class FloatExtractEmotionWithCustomModel:
         if name != "none" and idx is None:  # nodes_vadv.py:265-271: unknown name -> predict from the audio
             logger.warning("Specified emotion '%s' not found in the emotion model's label2id map. Predicting from audio instead.", name)
         if idx is None:
-            we = model.predict_emotion(processed_audio_features).unsqueeze(1)
+            with model_to_target(model):
+                we = model.predict_emotion(processed_audio_features).unsqueeze(1).cpu()
         else:
             we = torch.nn.functional.one_hot(torch.tensor(idx), num_classes=n).float()[None, None].repeat(B, 1, 1)
         return (we.cpu(), emotion_model_pipe)
@@ -351,13 +380,14 @@ class FloatExtractEmotionWithCustomModelDyn:
             raise ValueError("Chunk duration is too small for the sample rate.")
         n_chunks = math.ceil(total / chunk)
         seq = []
-        for b in range(B):  # nodes_vadv.py:812-826: every chunk is normalised on its own, then classified
-            for i in range(n_chunks):
-                piece = normalise(w[b, :, i * chunk:(i + 1) * chunk], sr, want)
-                if piece.shape[1] < 400:  # shorter than the feature extractor's receptive field: pad by replication
-                    piece = torch.nn.functional.pad(piece[:, None], (0, 400 - piece.shape[1]), mode="replicate")[:, 0]
-                seq.append(model.predict_emotion(piece))
-        seq = torch.cat(seq, dim=0).view(B, n_chunks, info["num_labels"]).cpu()
+        with model_to_target(model):
+            for b in range(B):  # nodes_vadv.py:812-826: every chunk is normalised on its own, then classified
+                for i in range(n_chunks):
+                    piece = normalise(w[b, :, i * chunk:(i + 1) * chunk], sr, want)
+                    if piece.shape[1] < 400:  # shorter than the feature extractor's receptive field: pad by replication
+                        piece = torch.nn.functional.pad(piece[:, None], (0, 400 - piece.shape[1]), mode="replicate")[:, 0]
+                    seq.append(model.predict_emotion(piece))
+            seq = torch.cat(seq, dim=0).view(B, n_chunks, info["num_labels"]).cpu()
         T = math.ceil(total / sr * target_fps)
         if n_chunks > 1:  # nearest-neighbour up-sampling (nodes_vadv.py:835-838)
             we = torch.nn.functional.interpolate(seq.transpose(1, 2), size=T, mode="nearest").transpose(1, 2)

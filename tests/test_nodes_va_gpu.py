@@ -141,3 +141,54 @@ def test_va_emotion_nodes(models):
     assert float((seq[0, 0] - O.audio2emotion_predict(models["sds"]["emo"], models["ecfg"], chunk0)[0]).abs().max()) < 2e-3
     with pytest.raises(ValueError):
         n["FloatExtractEmotionWithCustomModelDyn"]().extract_dynamic_emotion({"waveform": wav, "sample_rate": 8000}, pipe, 25.0, 2.0)
+
+
+def test_va_offload_after_every_node(models, monkeypatch):
+    """FLOAT_AMD_OFFLOAD=always: every VA node releases its operator's handle after the call - the reference's
+    `with model_to_target(logger, model)` around every node body (nodes_vadv.py:107,192,275,347,437,520,697,807) - and the next
+    call rebuilds it from the host weights the loader object keeps.  Same graph, resident vs released: bitwise the same tensors;
+    after a released run no handle is left and the device memory the operators held is free again."""
+    n = pkg.NODE_CLASS_MAPPINGS
+    dev = "cuda:0"
+    _, _, _, enc = n["LoadFloatEncoderModel"]().load_encoder_infer_arch("encoder.safetensors", dev, False)
+    dec, _, _, _ = n["LoadFloatSynthesisModel"]().load_synthesis_infer_arch("decoder.safetensors", dev, 1, "[1, 3, 3, 1]", False)
+    fmt, _, _, _ = n["LoadFMTModel"]().load_fmt_model("fmt.safetensors", dev, False, 7, 8, 2, 10, 25.0, 2.0)
+    _, pipe = n["LoadWav2VecModel"]().load_float_wav2vec_model("wav2vec2-base-960h", dev)
+    proj, _, _ = n["LoadAudioProjectionLayer"]().load_projection_layer("projection.safetensors", dev)
+    emo, _ = n["LoadEmotionRecognitionModel"]().load_emotion_model("wav2vec-english-speech-emotion-recognition", dev)
+    img = torch.from_numpy(np.random.RandomState(6).rand(1, SIZE, SIZE, 3).astype(np.float32))
+    wav = W.synth_waveform(1.0, seed=8)[:, None]
+
+    def graph():
+        pipe_app, lam, _ = n["ApplyFloatEncoder"]().apply_encoder(img, enc)
+        _, r_s = n["FloatGetIdentityReferenceVA"]().get_identity_reference_batch(lam, dec)
+        feats, T, a_norm, _, _, _ = n["FloatAudioPreprocessAndFeatureExtract"]().extract_features_with_custom_model(
+            {"waveform": wav, "sample_rate": 16000}, pipe, 25.0, False)
+        (wa,) = n["FloatApplyAudioProjection"]().apply_projection(feats, proj)
+        we, _ = n["FloatExtractEmotionWithCustomModel"]().extract_emotion_from_features(a_norm, emo, "none")
+        r_d, _ = n["FloatSampleMotionSequenceRD_VA"]().sample_rd_sequence_va(
+            r_s_latent=r_s, wa_latent=wa, we_latent=we, audio_num_frames=T, float_fmt_model=fmt, a_cfg_scale=2.0, r_cfg_scale=1.0,
+            e_cfg_scale=1.0, include_r_cfg=False, nfe=3, torchdiffeq_ode_method="midpoint", ode_atol=1e-5, ode_rtol=1e-5,
+            audio_dropout_prob=0.1, ref_dropout_prob=0.1, emotion_dropout_prob=0.1, fix_noise_seed=True, seed=15)
+        frames, _ = n["ApplyFloatSynthesis"]().apply_synthesis(pipe_app, dec, r_d[:, :3] * 0.3)
+        return [pipe_app["h_source"], r_s, wa, we, r_d, frames.clone()]
+
+    ops = lambda: [enc, dec, fmt, emo[0]] + list(proj.get("_encoders", {}).values())  # noqa: E731
+    resident = graph()
+    assert all(op.resident for op in ops())
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    held = torch.cuda.mem_get_info()[0]
+    monkeypatch.setenv("FLOAT_AMD_OFFLOAD", "always")
+    released = graph()
+    assert not any(op.resident for op in ops())
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    freed = torch.cuda.mem_get_info()[0] - held
+    print("VA operators released: %.2f GB of device memory came back" % (freed / 2**30))
+    assert freed > 0.5 * 2**30  # the small FMT / decoder / encoder / two wav2vec2 models of this fixture
+    for a, b in zip(resident, released):
+        assert torch.equal(a, b)
+    again = graph()  # rebuilt from the released state
+    for a, b in zip(resident, again):
+        assert torch.equal(a, b)
