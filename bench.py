@@ -416,6 +416,20 @@ def main():
         if mf:
             gemm_roof["mfma_util_pmc"] = mf.get("fmt_gemm", {}).get("mfma_util")
             conv_roof["mfma_util_pmc"] = mf.get("dec_conv", {}).get("mfma_util")
+        # Peaks MEASURED on this box beside the spec-sheet ones: streaming read bandwidth and the dense fp16
+        # MFMA rate of register-operand loops (float_probe_peaks).  `peak` / `frac` stay the guide's figures.
+        try:
+            peaks = pkg.native.probe_peaks(dev)
+            props = torch.cuda.get_device_properties(dev)
+            extra["device"] = dict(peaks, name=props.name, arch=getattr(props, "gcnArchName", None),
+                                   hbm_GiB=round(props.total_memory / 2**30, 1))
+            mfma_meas = max(peaks["mfma_f16_16x16x32_TFLOPs"], peaks["mfma_f16_32x32x16_TFLOPs"])
+            for r_, pk in ((gemm_roof, peaks["hbm_read_GBps"]), (conv_roof, mfma_meas), (mod_roof, mfma_meas)):
+                if r_ is not None and pk > 0:
+                    r_["peak_measured"] = pk
+                    r_["frac_measured"] = round(r_["achieved"] / pk, 4)
+        except Exception as e:  # the probe needs 4 GiB of scratch; the line is valid without it
+            warnings.append("float_probe_peaks failed: %s" % e)
         roofs = sorted([(gemm_total_ms, gemm_roof), (conv_total_ms, conv_roof)] + ([(mod_total_ms, mod_roof)] if mod_roof else []),
                        key=lambda x: -x[0])
         roof = [r for _, r in roofs]

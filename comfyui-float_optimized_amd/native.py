@@ -13,7 +13,7 @@ ODE_METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "heun2": 3, "heun3": 4}
 DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16,
           "fp32": FLOAT_DT_FP32, "float32": FLOAT_DT_FP32}  # fp32: the verification mode of the FMT and decoder operators
 DEC_SAT_SITES = 40
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class NativeLibraryError(RuntimeError):
@@ -54,6 +54,7 @@ _SIGNATURES = {
     "float_hip_abi_version": (C.c_int, []),
     "float_last_error": (C.c_char_p, []),
     "float_set_profiling": (C.c_int, [C.c_int32]),
+    "float_probe_peaks": (C.c_int, [C.POINTER(C.c_float)] * 4 + [C.POINTER(C.c_int32)]),
     "float_profile_ms": (C.c_double, [C.c_int32, C.POINTER(C.c_int64)]),
     "float_stream_create_cu_range": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]),
     "float_stream_destroy": (C.c_int, [C.c_void_p]),
@@ -227,3 +228,15 @@ def rebuildable(cls):
     cls.to_target = to_target
     cls.resident = property(lambda self: bool(self.__dict__.get("_h")))
     return cls
+
+
+def probe_peaks(device=None):
+    """float_probe_peaks: {hbm_read_GBps, hbm_copy_GBps, mfma_f16_16x16x32_TFLOPs, mfma_f16_32x32x16_TFLOPs, compute_units} measured
+    on `device` right now (4 GiB of scratch, ~0.1 s)."""
+    v = [C.c_float(0) for _ in range(4)]
+    n = C.c_int32(0)
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        torch.cuda.synchronize()
+        check(lib().float_probe_peaks(C.byref(v[0]), C.byref(v[1]), C.byref(v[2]), C.byref(v[3]), C.byref(n)))
+    return {"hbm_read_GBps": round(v[0].value, 1), "hbm_copy_GBps": round(v[1].value, 1), "mfma_f16_16x16x32_TFLOPs": round(v[2].value, 1),
+            "mfma_f16_32x32x16_TFLOPs": round(v[3].value, 1), "compute_units": n.value}

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FLOAT_HIP_ABI_VERSION 4
+#define FLOAT_HIP_ABI_VERSION 5
 
 enum {
   FLOAT_OK = 0,
@@ -382,6 +382,11 @@ int float_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream
 int float_stream_destroy(void* stream);
 int float_set_profiling(int32_t on);
 double float_profile_ms(int32_t which, int64_t* n_launches);
+/* Measured peaks of the current device, printed by bench.py beside the spec-sheet peaks of its roofline objects: streaming
+ * read and copy (read + write) bandwidth over 2-GiB buffers in GB/s, dense fp16 MFMA rate with register operands
+ * (v_mfma_f32_16x16x32_f16 / _32x32x16_f16) in TFLOP/s, compute-unit count.  Allocates and frees 4 GiB; ~0.1 s; synchronises
+ * the NULL stream.  Every pointer optional. */
+int float_probe_peaks(float* hbm_read_gbps, float* hbm_copy_gbps, float* mfma16_tflops, float* mfma32_tflops, int32_t* n_cu);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,12 @@ def test_single_gpu_line_has_the_contract_fields():
     assert abs(r["value"] - 50 * r["steps"] / (r["ms_per_step"] * r["steps"] * 1e-3)) < 0.01 * r["value"]
     ro = r["roofline"]
     assert ro["bound"] in ("hbm", "mfma") and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-3 and "traffic" in ro
+    # the peaks measured on this box travel with the spec-sheet ones: a streaming read of an MI355X sits between 2 and
+    # 8 TB/s, a register-operand fp16 MFMA loop between 1 and 2.6 PFLOP/s; the spec-sheet figures stay `peak`
+    d = r["device"]
+    assert 2000 < d["hbm_read_GBps"] <= 8000 and 2000 < d["hbm_copy_GBps"] <= 8000 and d["compute_units"] >= 64
+    assert 1000 < max(d["mfma_f16_16x16x32_TFLOPs"], d["mfma_f16_32x32x16_TFLOPs"]) <= 2600
+    assert ro["peak"] in (8000.0, 2500.0) and ro["peak_measured"] > 0 and abs(ro["frac_measured"] - ro["achieved"] / ro["peak_measured"]) < 1e-3
 
 
 @pytest.mark.parametrize("mode", ["replicas", "window", "shard"])
