@@ -4,6 +4,7 @@
 
 #include "fmt_gemm.hpp"
 #include "fmt_kernels.hpp"
+#include "fmt_rb_kernels.hpp"
 
 namespace {
 
@@ -287,6 +288,80 @@ int launch_gemm(const GemmArgs& g, int mtw, int nt, int nw, bool prime, hipStrea
   return FLOAT_E_INVALID;
 }
 
+// ---- stacked clips (>= kRbMinRows rows): the row-blocked LDS-DMA tile (fmt_rb_kernels.hpp) for qkv / proj / fc1 / fc2
+template <class T, int MI, int NJ, int KPS, int NS, int EPI>
+int launch_rbs_t(GemmArgs g, bool prime, hipStream_t s) {
+  constexpr int smem = fmt_rb_smem(MI, NJ, KPS, NS), ROWS = 32 * MI, BN = 32 * NJ;
+  auto kern = fmt_gemm_rbs_kernel<T, MI, NJ, KPS, NS, EPI>;
+  if (prime) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      (void)hipGetLastError();
+    return FLOAT_OK;
+  }
+  if (EPI != EPI_PARTIAL || g.ksplit < 1) g.ksplit = 1;
+  FH_REQUIRE(g.N % BN == 0 && (g.K / 32) % (g.ksplit * KPS) == 0 && g.K / 32 / g.ksplit / KPS >= 1,
+             "row-blocked GEMM: N=%d K=%d not tileable by %d columns / %d K slices of %d-k-block stages", g.N, g.K, BN, g.ksplit, KPS);
+  g.mblk = (g.M + ROWS - 1) / ROWS;
+  g.touch.W = nullptr;
+  const dim3 grid((unsigned)((g.N / BN) * g.mblk * g.ksplit));
+  hipEvent_t e0, e1;
+  if (fh_prof_pair(3, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(512), smem, s, e0, e1, 0, g);
+  else hipLaunchKernelGGL(kern, grid, dim3(512), smem, s, g);
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+// tile shapes built: 0 = 96 x 64 (two workgroups per CU), 1 = 96 x 128, 2 = 192 x 128 (ring of 3)
+template <class T, int EPI>
+int launch_rbs(const GemmArgs& g, int shape, bool prime, hipStream_t s) {
+  if constexpr (T::is32) {
+    fh_set_error("the fp32 verification mode has no row-blocked tiling");
+    return FLOAT_E_INVALID;
+  } else {
+  if (prime) {
+    (void)launch_rbs_t<T, 3, 2, 2, 4, EPI>(g, true, s);
+    (void)launch_rbs_t<T, 3, 4, 2, 4, EPI>(g, true, s);
+    (void)launch_rbs_t<T, 6, 4, 2, 3, EPI>(g, true, s);
+    return FLOAT_OK;
+  }
+  switch (shape) {
+    case 0: return launch_rbs_t<T, 3, 2, 2, 4, EPI>(g, false, s);
+    case 1: return launch_rbs_t<T, 3, 4, 2, 4, EPI>(g, false, s);
+    default: return launch_rbs_t<T, 6, 4, 2, 3, EPI>(g, false, s);
+  }
+  }
+}
+// Which tile, per layer and row count (tools/probes/gemm_lab.hip on MI355X, us per launch incl. the launch boundary, weights
+// rotating over 8 buffers; 48 x 64 tiling -> best row-blocked tile):
+//   rows    qkv (3072 x 1024)     proj (1024 x 1024)      fc1 (4096 x 1024)      fc2 (1024 x 4096, 4 K slices)
+//    360     9.7 ->  6.7 (96x64)   5.1 (kept)             10.9 ->  8.0 (96x64)   10.9 ->  8.3 (96x64)
+//    720    14.4 ->  9.9 (96x128)  6.6 ->  6.4 (96x64 /2) 18.8 -> 13.2 (96x128)  19.0 -> 12.8 (96x128)
+//   1440    24.4 -> 16.4 (96x64)  11.6 ->  9.8 (96x64 /2) 33.1 -> 22.5 (192x128) 34.1 -> 20.9 (192x128)
+//   2880    53.7 -> 31.7 (192x128) 22.2 -> 15.7 (192x128 /2) 74.5 -> 43.3 (192x128) 71.8 -> 39.1 (192x128)
+// FLOAT_FMT_RB=0 keeps the 48 x 64 tiling (the A/B switch); FLOAT_FMT_RB_QKV / _PROJ / _FC1 / _FC2 = "shape[,ksplit]" override.
+constexpr int kRbMinRows = 300;
+int g_fmt_rb = 1;
+struct RbPlan {
+  int shape = -1, ksplit = 1;  // shape < 0: the weight-streaming tiling
+};
+enum { RB_QKV = 0, RB_PROJ, RB_FC1, RB_FC2 };
+RbPlan pick_rb(int layer, int M) {
+  static const char* const envs[4] = {"FLOAT_FMT_RB_QKV", "FLOAT_FMT_RB_PROJ", "FLOAT_FMT_RB_FC1", "FLOAT_FMT_RB_FC2"};
+  RbPlan p;
+  if (!g_fmt_rb || M < kRbMinRows) return p;
+  const int tier = M < 540 ? 0 : (M < 1100 ? 1 : (M < 2200 ? 2 : 3));
+  static const int shapes[4][4] = {/* qkv */ {0, 1, 0, 2}, /* proj */ {-1, 0, 0, 2}, /* fc1 */ {0, 1, 2, 2}, /* fc2 */ {0, 1, 2, 2}};
+  p.shape = shapes[layer][tier];
+  p.ksplit = layer == RB_PROJ ? 2 : (layer == RB_FC2 ? 4 : 1);
+  if (const char* e = getenv(envs[layer])) {
+    int sh = p.shape, ks = p.ksplit;
+    if (sscanf(e, "%d,%d", &sh, &ks) >= 1) {
+      p.shape = sh;
+      if (layer == RB_PROJ || layer == RB_FC2) p.ksplit = (ks == 1 || ks == 2 || ks == 4 || ks == 8) ? ks : p.ksplit;
+    }
+  }
+  return p;
+}
+
 template <class T, int EPI>
 void prime_epi() {
   GemmArgs g;
@@ -324,6 +399,9 @@ void prime_kernels() {
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     (void)launch_wide<T>(g, true, nullptr);
+    (void)launch_rbs<T, EPI_T16>(g, 0, true, nullptr);
+    (void)launch_rbs<T, EPI_GELU_P16>(g, 0, true, nullptr);
+    (void)launch_rbs<T, EPI_PARTIAL>(g, 0, true, nullptr);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(fmt_mega_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 48 * 64 * 4) != hipSuccess)
       (void)hipGetLastError();
   }
@@ -846,11 +924,17 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
     if ((rc = run_gemm<T, EPI_XEMBED>(g, s))) return rc;
   }
   PendingRed pend;  // residual update left to the next LayerNorm launch
+  // stacked clips: the row-blocked LDS-DMA tile (fmt_rb_kernels.hpp); its launches carry no touch descriptors and the
+  // LayerNorm / attention launches before them pull nothing (their descriptors follow the 48 x 64 tiling's block decode)
+  RbPlan rb_qkv, rb_proj, rb_fc1, rb_fc2;
+  if constexpr (!T::is32) {
+    rb_qkv = pick_rb(RB_QKV, M), rb_proj = pick_rb(RB_PROJ, M), rb_fc1 = pick_rb(RB_FC1, M), rb_fc2 = pick_rb(RB_FC2, M);
+  }
   auto split_ok = [&](int ks, const Lin& L) { return (ks == 1 || ks == 2 || ks == 4) && L.K % (128 * ks) == 0; };
   for (int b = 0; b < c.depth; ++b) {
     const float* mod = modbuf + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, &B.qkv, nullptr, 0, 128))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, rb_qkv.shape >= 0 ? nullptr : &B.qkv, nullptr, 0, 128))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.qkv, M);
       g.sat = h->sat;
@@ -859,9 +943,21 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       if ((g_fmt_touch & 8) && attnproj_hpw(h)) g.touch = make_touch(B.proj, M, c.heads / attnproj_hpw(h), gemm_lanes_per_xcd(M, g.N, g.K), 2, 8 / attnproj_hpw(h));  // k-slices <-> XCDs as the fused launch decodes them
       else if ((g_fmt_touch & 8) && !split_ok(g_fmt_proj_split, B.proj)) g.touch = make_touch(B.proj, M, 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       static const LayerPlan plan("FLOAT_FMT_PLAN_QKV");
-      if ((rc = run_gemm<T, EPI_T16>(g, s, false, &plan))) return rc;
+      if (rb_qkv.shape >= 0) rc = launch_rbs<T, EPI_T16>(g, rb_qkv.shape, false, s);
+      else rc = run_gemm<T, EPI_T16>(g, s, false, &plan);
+      if (rc) return rc;
     }
-    if (attnproj_hpw(h)) {
+    if (rb_proj.shape >= 0) {
+      launch_attn<T>(h, M, nullptr, s);
+      GemmArgs gp = base_args(h->att16, B.proj, M);
+      gp.ksplit = rb_proj.ksplit;
+      gp.out_f32 = h->slab;
+      gp.ldo = gp.N;
+      gp.slab_stride = (size_t)h->Mpad * gp.N;
+      if ((rc = launch_rbs<T, EPI_PARTIAL>(gp, rb_proj.shape, false, s))) return rc;
+      pend.ks = rb_proj.ksplit;
+      pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
+    } else if (attnproj_hpw(h)) {
       if ((rc = launch_attnproj<T>(h, M, B.proj, s))) return rc;
       pend.ks = c.heads / attnproj_hpw(h);
       pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.proj.b, mod + 2 * D};
@@ -883,18 +979,29 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       static const LayerPlan plan("FLOAT_FMT_PLAN_PROJ");
       if ((rc = run_gemm<T, EPI_GATE_RES>(g, s, false, &plan))) return rc;
     }
-    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, &B.fc1, nullptr, 0, 64))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, rb_fc1.shape >= 0 ? nullptr : &B.fc1, nullptr, 0, 64))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.fc1, M);
       g.sat = h->sat;
       g.out16 = h->hid16;
       g.ldo16 = B.fc2.K / 32;  // packed for fc2
-      if (g_fmt_touch & 4)
+      if ((g_fmt_touch & 4) && rb_fc2.shape < 0)
         g.touch = make_touch(B.fc2, M, split_ok(g_fmt_fc2_split, B.fc2) ? g_fmt_fc2_split : 0, gemm_lanes_per_xcd(M, g.N, g.K), 2);
       static const LayerPlan plan("FLOAT_FMT_PLAN_FC1");
-      if ((rc = run_gemm<T, EPI_GELU_P16>(g, s, false, &plan))) return rc;
+      if (rb_fc1.shape >= 0) rc = launch_rbs<T, EPI_GELU_P16>(g, rb_fc1.shape, false, s);
+      else rc = run_gemm<T, EPI_GELU_P16>(g, s, false, &plan);
+      if (rc) return rc;
     }
-    if (split_ok(g_fmt_fc2_split, B.fc2)) {
+    if (rb_fc2.shape >= 0) {
+      GemmArgs g = base_args(h->hid16, B.fc2, M);
+      g.ksplit = rb_fc2.ksplit;
+      g.out_f32 = h->slab;
+      g.ldo = g.N;
+      g.slab_stride = (size_t)h->Mpad * g.N;
+      if ((rc = launch_rbs<T, EPI_PARTIAL>(g, rb_fc2.shape, false, s))) return rc;
+      pend.ks = rb_fc2.ksplit;
+      pend.red = LnRed{h->slab, (size_t)h->Mpad * D, B.fc2.b, mod + 5 * D};
+    } else if (split_ok(g_fmt_fc2_split, B.fc2)) {
       GemmArgs g = base_args(h->hid16, B.fc2, M);
       g.sat = h->sat;
       if (g_fmt_touch & 32) {
@@ -1393,6 +1500,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (const char* v = getenv("FLOAT_FMT_FULL_NW")) g_fmt_full_nw = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
+  if (const char* v = getenv("FLOAT_FMT_RB")) g_fmt_rb = atoi(v) != 0;
   h->attnproj = getenv("FLOAT_FMT_ATTNPROJ") ? atoi(getenv("FLOAT_FMT_ATTNPROJ")) : 0;
   h->mega_on = getenv("FLOAT_FMT_MEGA") ? atoi(getenv("FLOAT_FMT_MEGA")) : 0;
   {

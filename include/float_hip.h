@@ -373,13 +373,14 @@ int float_aud_classify(float_aud_t* h, const float* a, int32_t n_samples, float*
 /* ---------------------------------------------------------------- misc ------------ */
 int float_hip_abi_version(void);
 const char* float_last_error(void);
-/* Average device time (ms) of the kernels launched by the last timed call, by class, measured
- * with hipEvents on the caller's stream when profiling is on.  which: 0 = FMT GEMMs of the step chain,
- * 1 = decoder convs, 2 = the once-per-window adaLN modulation GEMM of the FMT.  Returns <0 when profiling is off. */
 /* A HIP stream restricted to CUs [cu_begin, cu_end) (hipExtStreamCreateWithCUMask).  Used to run the FMT
  * chain and the decoder concurrently on disjoint CU sets (pipeline.generate(overlap="cu")). */
 int float_stream_create_cu_range(int32_t cu_begin, int32_t cu_end, void** stream_out);
 int float_stream_destroy(void* stream);
+/* Average device time (ms) of the kernels launched by the last timed call, by class, measured
+ * with hipEvents on the caller's stream when profiling is on.  which: 0 = FMT GEMMs of the step chain (weight-streaming
+ * tiling), 1 = decoder convs, 2 = the once-per-window adaLN modulation GEMM of the FMT, 3 = FMT GEMMs of a stacked-clip
+ * step chain (row-blocked LDS-DMA tiling, float_fmt_sample_batch).  Returns <0 when profiling is off. */
 int float_set_profiling(int32_t on);
 double float_profile_ms(int32_t which, int64_t* n_launches);
 /* Measured peaks of the current device, printed by bench.py beside the spec-sheet peaks of its roofline objects: streaming

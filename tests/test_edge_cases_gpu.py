@@ -117,7 +117,7 @@ def test_other_temporal_structures(n_prev, n_cur, window):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-@pytest.mark.parametrize("B,dynamic,rcfg", [(2, False, False), (4, True, False), (3, False, True)])
+@pytest.mark.parametrize("B,dynamic,rcfg", [(2, False, False), (4, True, False), (3, False, True), (4, False, False), (8, False, False)])
 def test_batched_sampling_equals_per_clip(B, dynamic, rcfg, dtype):
     """float_fmt_sample_batch: B clips stacked along the rows of ONE launch chain (nodes_vadv.py:618-735 takes batches).  Each
     clip must be what the one-clip chain gives for it - within rounding, the GEMM tilings depend on the row count - and
@@ -133,6 +133,9 @@ def test_batched_sampling_equals_per_clip(B, dynamic, rcfg, dtype):
     a, r, e = (1.0, 1.0, 3.0) if dynamic else ((2.0, 1.5, 1.2) if rcfg else (2.0, 1.0, 1.0))
     got = many.sample(cat("r_s"), cat("wa"), cat("we"), noise, 5, a, r, e, include_r_cfg=rcfg).cpu()
     assert got.shape == (B, T, 512)
+    # the stacked chain (row-blocked LDS-DMA GEMM tiles from 300 rows on) sums in a fixed order: bitwise run to run
+    assert torch.equal(got, many.sample(cat("r_s"), cat("wa"), cat("we"), noise, 5, a, r, e, include_r_cfg=rcfg).cpu())
+    assert many.saturation() == 0
     tol = 2e-2 if dtype == "bf16" else 4e-3
     for q in range(B):
         alone = one.sample(cs[q]["r_s"], cs[q]["wa"], cs[q]["we"], noise[:, q:q + 1], 5, a, r, e, include_r_cfg=rcfg).cpu()
