@@ -66,7 +66,8 @@ def parse():
     ap.add_argument("--no-bf16", action="store_true", help="skip the second measurement with bf16 FMT operands")
     ap.add_argument("--no-s2e", action="store_true", help="skip the measurement with the speech-emotion model in the step "
                     "(emotion='none', the reference's default widget: wav2vec2-large classifier on the clip's audio)")
-    ap.add_argument("--no-variants", action="store_true", help="skip the literal nfe=50 run and the run from host inputs")
+    ap.add_argument("--no-variants", action="store_true", help="skip the literal nfe=50 run, the run from host inputs and the batches")
+    ap.add_argument("--batches", default="4,8,16", help="stacked-clip throughput runs (value_batchB), comma separated; empty = none")
     return ap.parse_args()
 
 
@@ -79,6 +80,17 @@ def free_port():
     return p
 
 
+def rank_threads(world):
+    """Intra-op host threads of one rank: the cores this process may use, divided by the ranks of the node (at least 1).  Eight
+    ranks each bringing torch's default pool (one thread per core) oversubscribe the host 8x while they synthesise and pack
+    600 M parameters and draw noise per clip."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    return max(1, cores // max(1, world))
+
+
 def launch_ranks(n):
     """Start n fresh rank processes (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this process
     makes any GPU call, wait for all of them, relay rank 0's output.  Exit code != 0 if any rank failed or fewer than n
@@ -86,6 +98,10 @@ def launch_ranks(n):
     env = dict(os.environ)
     env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(n))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # host threads per rank: the ranks share the host's cores (rank_threads); no NUMA pinning - the step's host work is a noise
+    # draw and a few hundred launches, the inputs cross PCIe once
+    for var in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+        env.setdefault(var, str(rank_threads(n)))
     procs = []
     for r in range(n):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
@@ -193,6 +209,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    host_threads = rank_threads(world)
+    if world > 1:  # also under torchrun, which sets OMP_NUM_THREADS=1 by itself: the pool follows the policy, not the launcher
+        torch.set_num_threads(host_threads)
     backend = os.environ.get("FLOAT_BENCH_BACKEND", "nccl")  # "gloo": ranks may share one GPU (smoke test of the N>1 path)
     n_dev = max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local_rank % n_dev)
@@ -294,6 +313,7 @@ def main():
             last["host"] = agent.infer_device(img, wav, a_cfg, 1.0, e_cfg, emo=emo_of_step[0], seed=15)
             return
         s_r, r_s, wa = conditioning()
+        noise = agent._noise_to_device(hp.n_chunks(T_total), 15)  # the clip's draw, into the pinned buffer, as infer_device does
         if args.mode == "window" and world > 1:
             r_loc, _, rep = pkg.distributed.sample_window_parallel(hp.fmt, cfg, r_s, wa, we, noise, args.nfe, a_cfg, 1.0, e_cfg,
                                                                    iters=args.window_iters, resolve_chunks=args.window_resolve)
@@ -463,6 +483,7 @@ def main():
         return time.perf_counter() - t0
 
     variants = {}
+    batch_done = 0
     if rank == 0 and world == 1 and product:
         k = max(3, min(20, args.steps))
         if with_s2e:
@@ -503,23 +524,68 @@ def main():
             # THROUGHPUT form of the same product path: B clips of equal length through ONE stacked FMT chain
             # (InferenceAgent.infer_device_batch -> float_fmt_sample_batch; what FLOAT Process runs for a batch of portraits,
             # BASELINE configs[3] on one GPU): every weight is read once per evaluation for all of them
-            nb = 4
-            items = [(torch.roll(img, i, dims=-1), wav) for i in range(nb)]
+            def batch_run(nb, reps):
+                items = [(torch.roll(img, i, dims=-1), wav) for i in range(nb)]
 
-            def batch_step():
-                last.pop("host", None)
-                last["hosts"] = agent.infer_device_batch(items, a_cfg, 1.0, e_cfg, "neutral", [15 + i for i in range(nb)])
-            batch_step()
-            barrier()
-            kb = max(2, k // 4)
-            t0 = time.perf_counter()
-            for _ in range(kb):
+                def batch_step():
+                    last.pop("hosts", None)
+                    last["hosts"] = agent.infer_device_batch(items, a_cfg, 1.0, e_cfg, "neutral", [15 + i for i in range(nb)])
                 batch_step()
-            barrier()
-            el = time.perf_counter() - t0
-            last.pop("hosts", None)
-            variants.update({"value_batch4": round(nb * T * kb / el, 3), "ms_per_step_batch4": round(el / kb * 1e3, 3),
-                             "batch4_what": "4 clips of 10 s stacked in one FMT chain, decoded one after the other, 1000 frames per step"})
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    batch_step()
+                barrier()
+                el = time.perf_counter() - t0
+                last.pop("hosts", None)
+                return el
+
+            last.pop("host", None)
+            for nb in [int(b) for b in args.batches.split(",") if b]:
+                try:
+                    reps = max(2, k // nb)
+                    el = batch_run(nb, reps)
+                    variants.update({"value_batch%d" % nb: round(nb * T * reps / el, 3), "ms_per_step_batch%d" % nb: round(el / reps * 1e3, 3)})
+                    batch_done = nb
+                except Exception as e:  # noqa: BLE001  (host or device memory for the largest batches)
+                    warnings.append("batch of %d clips failed: %s" % (nb, str(e).splitlines()[0][:200]))
+                    break
+            variants["batch_what"] = ("value_batchB: B clips of %.0f s stacked in ONE FMT chain (InferenceAgent.infer_device_batch -> "
+                                      "float_fmt_sample_batch), decoded back to back, B x %d frames per step" % (args.seconds, T))
+            # the stacked chain's GEMMs under hipEvents (class 3: the row-blocked LDS-DMA tile) at the largest batch that ran
+            if batch_done and not args.no_roofline:
+                fmtb = hp.batched_fmt(batch_done)
+                cs = [conditioning() for _ in range(batch_done)]
+                r_sb = torch.cat([c[1].reshape(1, -1) for c in cs])
+                wab = torch.cat([c[2].reshape(1, T_total, -1) for c in cs])
+                web = torch.cat([we.reshape(1, 1, -1)] * batch_done)
+                nz = agent._noise_batch_to_device(hp.n_chunks(T_total), [15 + i for i in range(batch_done)])
+                fmtb.sample(r_sb, wab, web, nz, args.nfe, a_cfg, 1.0, e_cfg)
+                torch.cuda.synchronize()
+                pkg.native.set_profiling(True)
+                t0 = time.perf_counter()
+                fmtb.sample(r_sb, wab, web, nz, args.nfe, a_cfg, 1.0, e_cfg)
+                torch.cuda.synchronize()
+                b_ms, b_n = pkg.native.profile_ms(3)
+                bm_ms, bm_n = pkg.native.profile_ms(2)
+                pkg.native.set_profiling(False)
+                n_eval = hp.n_chunks(T_total) * (args.nfe - 1)
+                rows = batch_done * 3 * cfg.n_tokens
+                blk_flop = 2.0 * rows * 1024 * (3072 + 1024 + 4096 + 4096) * 8 * n_eval  # qkv + proj + fc1 + fc2 of the 8 blocks
+                if b_n > 0:
+                    rb = {"kernel": "fmt_gemm_rbs_kernel (qkv / proj / fc1 / fc2 of a stacked-clip step chain)", "batch": batch_done,
+                          "rows": rows, "bound": "mfma", "achieved": round(blk_flop / (b_ms * b_n * 1e-3) / 1e12, 2),
+                          "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "launches": b_n, "avg_launch_us": round(b_ms * 1e3, 2),
+                          "algorithmic_flop_per_launch": round(blk_flop / b_n), "traffic": None,
+                          "note": "one tile per CU fetches its operands once by LDS-DMA: fetch-rate-bound below ~2 900 rows "
+                                  "(DESIGN.md section 6), hence far from the MFMA peak it is priced against"}
+                    rb["frac"] = round(rb["achieved"] / MFMA_PEAK_TFLOPS, 4)
+                    if bm_n > 0:
+                        mflop = 2.0 * rows * 51200 * 1024 * n_eval
+                        rb["adaln_gemm"] = {"launches": bm_n, "avg_launch_us": round(bm_ms * 1e3, 2),
+                                            "achieved": round(mflop / (bm_ms * bm_n * 1e-3) / 1e12, 2), "unit": "TFLOP/s"}
+                        rb["adaln_gemm"]["frac"] = round(rb["adaln_gemm"]["achieved"] / MFMA_PEAK_TFLOPS, 4)
+                    variants["roofline_batch"] = rb
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -550,6 +616,7 @@ def main():
                        "decode_batch": args.max_frames, "hip_graph": not args.no_graph, "parallelism": par},
         }
         out.update(extra)
+        out["host_threads_per_rank"] = host_threads if world > 1 else torch.get_num_threads()
         out["rccl_ranks"] = rccl_ranks  # ranks as counted by an RCCL all_reduce of ones (None: no RCCL communicator in this run)
         out["fp16_range_hits"] = sum(range_hits.values())
         if rccl_note:

@@ -17,7 +17,7 @@ class AudioEncoderHIP:
     def __init__(self, state_dict, cfg: AudioConfig = None, device="cuda:0", dtype="fp16", sampling_rate=16000, fps=25.0):
         self.cfg = cfg or AudioConfig()
         self.device = torch.device(device)
-        self.dtype = dtype
+        self.dtype = dtype = native.canon_dtype(dtype)
         self.sampling_rate, self.fps = sampling_rate, fps
         sd = {}
         for k, v in state_dict.items():

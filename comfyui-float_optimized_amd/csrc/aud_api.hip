@@ -560,7 +560,10 @@ int float_aud_saturation(float_aud_t* h, uint64_t* total, int32_t reset, void* s
   unsigned long long v = 0;
   FH_CHECK_HIP(hipMemcpy(&v, h->sat, sizeof(v), hipMemcpyDeviceToHost));
   *total = v;
-  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(v)));
+  if (reset) {  // on the caller's stream: ordered against the launches that add to the counter there (not the NULL stream's memset)
+    FH_CHECK_HIP(hipMemsetAsync(h->sat, 0, sizeof(v), (hipStream_t)stream));
+    FH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
   return FLOAT_OK;
 }
 

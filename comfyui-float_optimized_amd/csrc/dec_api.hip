@@ -1255,7 +1255,10 @@ int float_dec_saturation(float_dec_t* h, uint64_t* total, uint64_t* per_site, in
     if (per_site) per_site[i] = host[i];
   }
   *total = sum;
-  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(host)));
+  if (reset) {  // on the caller's stream: ordered against the launches that add to the counters there
+    FH_CHECK_HIP(hipMemsetAsync(h->sat, 0, sizeof(host), st));
+    FH_CHECK_HIP(hipStreamSynchronize(st));
+  }
   return FLOAT_OK;
 }
 

@@ -429,7 +429,10 @@ int float_enc_saturation(float_enc_t* h, uint64_t* total, int32_t reset, void* s
   unsigned long long v = 0;
   FH_CHECK_HIP(hipMemcpy(&v, h->sat, sizeof(v), hipMemcpyDeviceToHost));
   *total = v;
-  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(v)));
+  if (reset) {  // on the caller's stream: ordered against the launches that add to the counter there (not the NULL stream's memset)
+    FH_CHECK_HIP(hipMemsetAsync(h->sat, 0, sizeof(v), (hipStream_t)stream));
+    FH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  }
   return FLOAT_OK;
 }
 
@@ -442,6 +445,20 @@ int float_enc_feats16(float_enc_t* h, const void** feats16, int32_t* channels, i
     if (channels) channels[i] = h->resC[nb - 1 - i];
   }
   *n_out = n;
+  return FLOAT_OK;
+}
+
+int float_enc_export_feats16(float_enc_t* h, void* const* dst, int32_t n_feats, void* stream) {
+  FH_REQUIRE(h && dst, "null argument to float_enc_export_feats16");
+  const int nb = (int)h->blocks.size();
+  FH_REQUIRE(n_feats >= 1 && n_feats <= nb, "float_enc_export_feats16: %d maps asked, the encoder keeps %d", n_feats, nb);
+  const size_t eb = h->cfg.dtype == FLOAT_DT_FP32 ? 4 : 2;
+  for (int i = 0; i < n_feats; ++i) {
+    FH_REQUIRE(dst[i] != nullptr, "float_enc_export_feats16: dst[%d] is null", i);
+    const int l = nb - 1 - i;
+    int rc = fh_copy_d2d(dst[i], h->res[l], (size_t)h->resR[l] * h->resR[l] * h->resC[l] * eb, (hipStream_t)stream);
+    if (rc) return rc;
+  }
   return FLOAT_OK;
 }
 

@@ -45,6 +45,7 @@ struct float_fmt {
     MegaCtx ctx{};
   } mega[5];               // by CFG rows (1, 3, 4)
   unsigned* mega_sync = nullptr;  // [8 x 32 | 32 | 8 x 32 | seq | err] words
+  unsigned* mega_err_host = nullptr;  // host-mapped twin of the err word (hipHostMalloc): read by mega_poll without a copy
   u16* mega_ws = nullptr;         // write-once A operands of the persistent kernel: per block h16 x 2, att16, hid16; + the head's
   float* kbuf = nullptr;   // [4][kMaxTok][dim_w] stage velocities of the Runge-Kutta solvers
   // Modulations of up to kScSteps evaluations of a window, [step][Mmod][Ntot] fp32: c = t_emb + c_embedder(wr, wa, we) does not
@@ -733,7 +734,25 @@ constexpr int kMegaWgs = 256, kMegaSmem = 8 * 48 * 64 * 4;
 MegaSync mega_sync_of(const float_fmt* h) {
   unsigned* m = h->mega_sync;
   static const int wg = getenv("FLOAT_FMT_MEGA_STAMP_WG") ? atoi(getenv("FLOAT_FMT_MEGA_STAMP_WG")) : 0;
-  return MegaSync{m, m + 8 * 32, m + 9 * 32, m + 17 * 32, m + 18 * 32, reinterpret_cast<unsigned long long*>(m + 20 * 32), (unsigned)wg};
+  return MegaSync{m, m + 8 * 32, m + 9 * 32, m + 17 * 32, m + 18 * 32, h->mega_err_host, reinterpret_cast<unsigned long long*>(m + 20 * 32), (unsigned)wg};
+}
+// The persistent kernel's barrier watchdog, looked at by EVERY FMT call of the handle before it queues new work (the flag is
+// host-mapped: no copy, no synchronisation when it is clear): a timeout in an earlier call means that call's results are
+// invalid.  This call fails with the message; the device is drained, the cached window graphs (they hold the persistent
+// kernel) are destroyed, the barrier words are cleared (their generation counters are out of step for good otherwise) and the
+// handle runs the launch chain from here on.
+int mega_poll(float_fmt* h) {
+  if (!h->mega_err_host || *reinterpret_cast<volatile unsigned*>(h->mega_err_host) == 0u) return FLOAT_OK;
+  FH_CHECK_HIP(hipDeviceSynchronize());  // graphs may be queued on other streams than the caller's
+  for (auto& gr : h->graphs) (void)hipGraphExecDestroy(gr.exec);
+  h->graphs.clear();
+  if (h->mega_sync) FH_CHECK_HIP(hipMemset(h->mega_sync, 0, (size_t)(32 * 20) * sizeof(unsigned)));
+  *reinterpret_cast<volatile unsigned*>(h->mega_err_host) = 0u;
+  h->mega_on = 0;
+  h->job.active = false;
+  fh_set_error("fmt_mega_kernel: a grid barrier timed out in an earlier call (not all %d workgroups were resident) - the results of "
+               "that call are invalid; the handle falls back to the launch chain (FLOAT_FMT_MEGA=0 selects it from the start)", 256);
+  return FLOAT_E_HIP;
 }
 // The chain's shapes this kernel is built for: one clip, 3 CFG rows of 60 tokens (M = 180), dim_h 1024, the default launch
 // options - i.e. exactly the tilings run_blocks would pick.  Anything else keeps the launch chain.
@@ -754,6 +773,18 @@ template <class T>
 int build_mega(float_fmt* h, int bc) {
   float_fmt::MegaPlan& P = h->mega[bc];
   P.tried = 1;
+  {
+    // every one of the 256 workgroups must be resident at once (a plain launch: nothing else checks it)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fmt_mega_kernel<T>), 512, kMegaSmem) != hipSuccess) {
+      (void)hipGetLastError();
+      per_cu = 0;
+    }
+    if (per_cu * h->n_cu < kMegaWgs) {
+      h->mega_on = 0;  // the launch chain
+      return FLOAT_OK;
+    }
+  }
   const float_fmt_cfg_t& c = h->cfg;
   const int D = h->D, ntok = h->ntok, M = bc * ntok;
   std::vector<MegaStage> st;
@@ -879,6 +910,10 @@ int build_mega(float_fmt* h, int bc) {
   for (const MegaStage& m : st) FH_REQUIRE(m.nblk <= (unsigned)kMegaWgs, "persistent kernel: a stage needs %u workgroups", m.nblk);
   int rc;
   if (!h->mega_sync && (rc = h->pool.alloc(&h->mega_sync, 32 * 20 + 2 * 3 * 64, true))) return rc;  // + stamps of <= 64 stages
+  if (!h->mega_err_host) {
+    FH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->mega_err_host), 64, hipHostMallocMapped));
+    memset(h->mega_err_host, 0, 64);
+  }
   if ((rc = h->pool.alloc(&P.dev, st.size(), false))) return rc;
   FH_CHECK_HIP(hipMemcpy(P.dev, st.data(), st.size() * sizeof(MegaStage), hipMemcpyHostToDevice));
   P.nstage = (int)st.size();
@@ -1593,6 +1628,7 @@ void float_fmt_destroy(float_fmt_t* h) {
   if (!h) return;
   for (auto& g : h->graphs) (void)hipGraphExecDestroy(g.exec);
   if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+  if (h->mega_err_host) (void)hipHostFree(h->mega_err_host);
   h->pool.release();
   delete h;
 }
@@ -1602,6 +1638,7 @@ int float_fmt_eval(float_fmt_t* h, float t, const float* x, const float* wa, con
                    float r_cfg, float e_cfg, int32_t include_r_cfg, float* out, void* stream) {
   int rc = check_common(h, we, we_len, prev_we);
   if (rc) return rc;
+  if ((rc = mega_poll(h))) return rc;
   FH_REQUIRE(x && wa && wr && we && prev_x && prev_wa && out, "null tensor argument to float_fmt_eval");
   hipStream_t s = (hipStream_t)stream;
   return h->cfg.dtype == FLOAT_DT_BF16
@@ -1616,6 +1653,7 @@ int float_fmt_sample_chunk(float_fmt_t* h, const float* x0, const float* wa, con
                            float a_cfg, float r_cfg, float e_cfg, int32_t include_r_cfg, float* out, void* stream) {
   int rc = check_common(h, we, we_len, prev_we);
   if (rc) return rc;
+  if ((rc = mega_poll(h))) return rc;
   FH_REQUIRE(x0 && wa && wr && we && prev_x && prev_wa && out, "null tensor argument to float_fmt_sample_chunk");
   FH_REQUIRE(nfe >= 1 && n_evals(h->method, nfe) < kMaxSteps, "nfe=%d: too many evaluations (max %d)", nfe, kMaxSteps);
   hipStream_t s = (hipStream_t)stream;
@@ -1662,20 +1700,11 @@ int float_fmt_saturation(float_fmt_t* h, uint64_t* total, int32_t reset, void* s
   unsigned long long v = 0;
   FH_CHECK_HIP(hipMemcpy(&v, h->sat, sizeof(v), hipMemcpyDeviceToHost));
   *total = v;
-  if (reset) FH_CHECK_HIP(hipMemset(h->sat, 0, sizeof(v)));
-  if (h->mega_sync) {  // the persistent kernel's barrier watchdog
-    unsigned err = 0;
-    FH_CHECK_HIP(hipMemcpy(&err, h->mega_sync + 18 * 32, sizeof(err), hipMemcpyDeviceToHost));
-    if (err) {
-      FH_CHECK_HIP(hipMemset(h->mega_sync + 18 * 32, 0, sizeof(err)));
-      h->mega_on = 0;  // the launch chain from here on: captured window graphs hold the persistent kernel, drop them
-      for (auto& gr : h->graphs) (void)hipGraphExecDestroy(gr.exec);
-      h->graphs.clear();
-      fh_set_error("fmt_mega_kernel: a grid barrier timed out (not all %d workgroups were resident) - the results of this call are "
-                   "invalid; the handle falls back to the launch chain (FLOAT_FMT_MEGA=0 selects it from the start)", 256);
-      return FLOAT_E_HIP;
-    }
+  if (reset) {  // on the caller's stream: ordered against the launches that add to the counter there (not the NULL stream's memset)
+    FH_CHECK_HIP(hipMemsetAsync(h->sat, 0, sizeof(v), (hipStream_t)stream));
+    FH_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
   }
+  if (int rc = mega_poll(h)) return rc;  // the persistent kernel's barrier watchdog (also polled by every other call)
   return FLOAT_OK;
 }
 
@@ -1743,6 +1772,7 @@ int float_fmt_sample_begin_range(float_fmt_t* h, const float* wr, const float* w
 
 int float_fmt_sample_next(float_fmt_t* h, void* stream, int32_t* window_done, int32_t* windows_left) {
   FH_REQUIRE(h != nullptr && h->job.active, "float_fmt_sample_next without float_fmt_sample_begin");
+  if (int prc = mega_poll(h)) return prc;
   auto& J = h->job;
   hipStream_t s = (hipStream_t)stream;
   const int k = J.next;

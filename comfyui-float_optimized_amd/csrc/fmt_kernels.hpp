@@ -1152,8 +1152,9 @@ __global__ __launch_bounds__(512) void fmt_attnproj_kernel(const u16* __restrict
 // waiters poll - three dependent memory round trips instead of 256 serialized atomics on one line.  Counters only ever count
 // up: generation = launches so far (a device word read at kernel start, bumped by workgroup 0 at the end) x barriers per
 // launch + stage, so a hipGraph can replay the same launch.  A waiter that does not see its release within ~0.3 s (a CU was
-// not available, so not all workgroups are resident) sets the error word and leaves; the host reports it
-// (float_fmt_saturation / the next call) instead of hanging the GPU.
+// not available, so not all workgroups are resident) sets the error word (and its host-mapped twin) and leaves; the host
+// reports it at the next FMT call on the handle, whatever its dtype (mega_poll in fmt_api.hip: that call fails, the barrier
+// words are cleared and the handle falls back to the launch chain) instead of hanging the GPU.
 enum { MS_XEMBED = 0, MS_LN, MS_QKV, MS_ATTN, MS_PROJ, MS_FC1, MS_FC2, MS_HEAD };
 struct MegaStage {
   int kind;
@@ -1188,6 +1189,7 @@ struct MegaSync {
   unsigned* rel;   // [8] x 32 words
   unsigned* seq;   // launches so far
   unsigned* err;   // != 0: a barrier timed out
+  unsigned* err_host;  // the same flag in host-mapped memory: the host reads it at its next call without a device copy
   unsigned long long* stamps;  // diagnostic builds (-DMEGA_STAMPS): [stage][3] s_memrealtime of workgroup `stamp_wg`
   unsigned stamp_wg;
 };
@@ -1209,6 +1211,7 @@ __device__ __forceinline__ bool fmt_grid_barrier(const MegaSync& sy, unsigned ge
   while ((int)(__hip_atomic_load((gu32*)(sy.rel + g * 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen) < 0) {
     if (++spins > (1u << 18) || ((spins & 63u) == 0u && __hip_atomic_load((gu32*)sy.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
       __hip_atomic_store((gu32*)sy.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (sy.err_host) __hip_atomic_store((gu32*)sy.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       return false;
     }
     __builtin_amdgcn_s_sleep(1);

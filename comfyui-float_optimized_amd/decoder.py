@@ -30,7 +30,7 @@ class SynthesisHIP:
                              "frames at the 40 dB limit" % (dtype,))
         self.size, self.style_dim = size, style_dim
         self.device = torch.device(device)
-        self.dtype = dtype
+        self.dtype = dtype = native.canon_dtype(dtype)
         L = native.lib()
         pref = "motion_autoencoder.dec."
         sd = {(k[len(pref):] if k.startswith(pref) else k): v for k, v in state_dict.items()}
@@ -78,6 +78,13 @@ class SynthesisHIP:
         with torch.cuda.device(self.device):
             native.check(native.lib().float_dec_set_feats(self._h, ptrs, len(fs), native.stream_ptr(self.device)))
         self._feats = fs  # keep alive until the async repack has run
+
+    def set_feats16(self, bufs, dtype=None):
+        """Skip features as flat NHWC device buffers of the decoder's element type (EncoderHIP.export_feats16)."""
+        ptrs = (C.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_dec_set_feats16(self._h, ptrs, len(bufs), native.DTYPES[dtype or self.dtype],
+                                                            native.stream_ptr(self.device)))
 
     def _run(self, fn, s_r, r_d, shape):
         s_r = s_r.to(self.device, torch.float32).reshape(-1).contiguous()

@@ -44,7 +44,10 @@ def sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg,
     """The AR window loop (FLOAT.py:209-253) over windows [w0, w1) starting from `hist`
     (prev_x, prev_wa, prev_we) - zeros when None, as for window 0.  `fmt` needs
     sample_chunk(x0, wa, wr, we, prev_x, prev_wa, prev_we, nfe=, a_cfg_scale=, r_cfg_scale=, e_cfg_scale=).
-    Returns (samples (B,(w1-w0)*L,dim_w), tail = (prev_x, prev_wa, prev_we) after the last window)."""
+    ONE contract for both implementations (the host loop below and the operator's own window loop, picked for a HIP handle
+    with one clip): returns (samples (B, min(T, w1 L) - w0 L, dim_w) - the range's rows TRIMMED to the clip - and
+    tail = (prev_x, prev_wa, prev_we), the history window w1 would start from.  When window w1 - 1 is the clip's last, trimmed
+    window nobody samples after it and prev_x is zeros (prev_wa / prev_we are the tails of the replicate-padded window)."""
     L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
     B = wa.shape[0]
     dev, dt = wa.device, wa.dtype
@@ -66,7 +69,11 @@ def sample_range(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg,
         prev_x, prev_wa = xs[:, -P:], wa_c[:, -P:]
         if dynamic:
             prev_we = we_c[:, -P:]
-    return torch.cat(out, dim=1), (prev_x, prev_wa, prev_we)
+    T = wa.shape[1]
+    xs = torch.cat(out, dim=1)[:, :min(T, w1 * L) - w0 * L]
+    if w1 * L > T:  # the clip's last, trimmed window: same tail as the native loop gives (nobody samples after it)
+        prev_x = torch.zeros_like(prev_x)
+    return xs, (prev_x, prev_wa, prev_we)
 
 
 def _sample_range_native(fmt, cfg, r_s, wa, we, noise, w0, w1, nfe, a_cfg, r_cfg, e_cfg, hist):

@@ -18,7 +18,7 @@ class EncoderHIP:
     def __init__(self, state_dict, size=512, dim=512, dim_motion=20, device="cuda:0", dtype="fp16", direction_weight=None):
         self.size, self.dim, self.dim_motion = size, dim, dim_motion
         self.device = torch.device(device)
-        self.dtype = dtype
+        self.dtype = dtype = native.canon_dtype(dtype)
         self.n_feats = int(math.log2(size)) - 2
         pref = "motion_autoencoder.enc."
         # the Blur buffers (`*.kernel`, encoder.py:59-71) travel too: the operator has [1,3,3,1] in its code and refuses others
@@ -79,6 +79,18 @@ class EncoderHIP:
         return s_r, None, feats
 
     __call__ = forward
+
+    def export_feats16(self, bufs=None):
+        """Copies of the NHWC skip features of the last forward in the operator's element type (float_enc_export_feats16), one
+        flat device tensor per map - what `SynthesisHIP.set_feats16` takes back.  A batch of portraits keeps one set per item,
+        so that item i can be decoded after item j was encoded without a second encoder pass."""
+        eb = 4 if self.dtype == "fp32" else 2
+        if bufs is None:
+            bufs = [torch.empty(c * r * r * eb, dtype=torch.uint8, device=self.device) for c, r, _ in self.feat_shapes()]
+        ptrs = (C.c_void_p * len(bufs))(*[b.data_ptr() for b in bufs])
+        with torch.cuda.device(self.device):
+            native.check(native.lib().float_enc_export_feats16(self._h, ptrs, len(bufs), native.stream_ptr(self.device)))
+        return bufs
 
     def hand_feats_to(self, dec):
         """Give the NHWC 16-bit skip features of the last forward to a SynthesisHIP of the same dtype

@@ -21,7 +21,7 @@ class FlowMatchingTransformerHIP:
         into groups of that size.  Sizes the workspace (3.1 GB of modulation slab per clip at the default shape)."""
         self.cfg = cfg or FmtConfig()
         self.device = torch.device(device)
-        self.dtype = dtype
+        self.dtype = dtype = native.canon_dtype(dtype)
         self.max_batch = max(1, int(max_batch))
         L = native.lib()
         c = self.cfg

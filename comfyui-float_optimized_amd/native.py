@@ -12,8 +12,18 @@ FLOAT_DT_BF16, FLOAT_DT_FP16, FLOAT_DT_FP32 = 0, 1, 2
 ODE_METHODS = {"euler": 0, "midpoint": 1, "rk4": 2, "heun2": 3, "heun3": 4}
 DTYPES = {"bf16": FLOAT_DT_BF16, "bfloat16": FLOAT_DT_BF16, "fp16": FLOAT_DT_FP16, "float16": FLOAT_DT_FP16,
           "fp32": FLOAT_DT_FP32, "float32": FLOAT_DT_FP32}  # fp32: the verification mode of the FMT and decoder operators
+DTYPE_NAMES = {FLOAT_DT_BF16: "bf16", FLOAT_DT_FP16: "fp16", FLOAT_DT_FP32: "fp32"}
 DEC_SAT_SITES = 40
-ABI_VERSION = 5
+ABI_VERSION = 6
+
+
+def canon_dtype(dtype):
+    """'float16' / 'bfloat16' / 'float32' -> 'fp16' / 'bf16' / 'fp32': the operator mirrors keep the canonical name, so
+    that every `op.dtype == "fp16"` test (range checks, watchdogs) sees an fp16 handle however it was asked for."""
+    try:
+        return DTYPE_NAMES[DTYPES[str(dtype)]]
+    except KeyError:
+        raise ValueError("unknown dtype %r (one of %s)" % (dtype, ", ".join(sorted(DTYPES)))) from None
 
 
 class NativeLibraryError(RuntimeError):
@@ -99,6 +109,7 @@ _SIGNATURES = {
     "float_aud_classify": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_aud_inference": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "float_enc_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32, C.POINTER(C.c_int32)]),
+    "float_enc_export_feats16": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_void_p]),
     "float_fmt_saturation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p]),
     "float_enc_saturation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p]),
     "float_aud_saturation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.c_int32, C.c_void_p]),

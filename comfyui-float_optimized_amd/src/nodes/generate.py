@@ -46,10 +46,12 @@ class InferenceAgent:
         # the host copy of the weights stays with the agent (the reference's offload device, nodes.py:139): offload() frees
         # every device allocation, to_target() rebuilds the operators from here
         self._parts = parts
+        from ... import native as _native
+        canon = _native.canon_dtype  # 'float16' and 'fp16' are one type to every later `== "fp16"` test
         self._build = dict(max_frames=max_frames, use_graph=use_graph,
-                           fmt_dtype=fmt_dtype or os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16"),
-                           dec_dtype=dec_dtype or os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16"),
-                           aud_dtype=aud_dtype or os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16"))
+                           fmt_dtype=canon(fmt_dtype or os.environ.get("FLOAT_AMD_FMT_DTYPE", "fp16")),
+                           dec_dtype=canon(dec_dtype or os.environ.get("FLOAT_AMD_DEC_DTYPE", "fp16")),
+                           aud_dtype=canon(aud_dtype or os.environ.get("FLOAT_AMD_AUD_DTYPE", "fp16")))
         self.G = None
         self.to_target()
 
@@ -94,6 +96,8 @@ class InferenceAgent:
         self.G = self.enc = self.audio_encoder = self.emotion_encoder = None
         self.__dict__.pop("_we_cache", None)
         self.__dict__.pop("_noise_pin", None)
+        self.__dict__.pop("_noise_pin_b", None)
+        self.__dict__.pop("_feat_slots", None)
         with torch.cuda.device(self.rank):
             torch.cuda.empty_cache()
 
@@ -150,6 +154,21 @@ class InferenceAgent:
         if idx not in cache:
             cache[idx] = host_models.emotion_one_hot(emo, "cpu").to(self.rank)
         return cache[idx]
+
+    def _noise_batch_to_device(self, n_chunks, seeds):
+        """(n_chunks, B, L, W): item i draws its own sequential stream from seeds[i] (what infer_device draws for it alone),
+        written straight into one pinned buffer and sent by ONE non-blocking copy."""
+        c = self.cfg
+        shape = (n_chunks, len(seeds), c.num_frames_for_clip, c.dim_w)
+        buf = self.__dict__.get("_noise_pin_b")
+        if buf is None or tuple(buf.shape) != shape:
+            buf = self._noise_pin_b = torch.empty(shape, dtype=torch.float32, pin_memory=True)
+        for i, sd in enumerate(seeds):
+            g = torch.Generator("cpu")
+            g.manual_seed(int(sd))
+            for k in range(n_chunks):
+                torch.randn(1, c.num_frames_for_clip, c.dim_w, generator=g, out=buf[k, i:i + 1])
+        return buf.to(self.rank, non_blocking=True)
 
     def _noise_to_device(self, n_chunks, seed):
         """The reference's sequential CPU draws (fmt.draw_noise; FLOAT.py:203-215) written straight into a pinned buffer and sent
@@ -288,23 +307,30 @@ class InferenceAgent:
         self.to_target()
         B = len(items)
         seeds = list(seeds) if seeds is not None else [self.opt.seed] * B
-        conds = [self.conditions_device(s, a, emo) for s, a in items]
+        # once-per-clip producers of every item; the encoder's skip maps of item i are copied aside (33 MB, a D2D copy) so
+        # that no item needs a second encoder pass when its turn to decode comes
+        conds, feats = [], []
+        slots = self.__dict__.setdefault("_feat_slots", [])
+        for i, (s, a) in enumerate(items):
+            conds.append(self.conditions_device(s, a, emo))
+            if i >= len(slots):
+                slots.append(None)
+            slots[i] = self.enc.export_feats16(slots[i])
+            feats.append(slots[i])
         T = conds[0]["T"]
         if any(c["T"] != T for c in conds):
             raise ValueError("infer_device_batch needs clips of equal length")
         n_chunks = int(math.ceil(T / self.cfg.num_frames_for_clip))
-        from ...fmt import draw_noise
-        noise = torch.cat([draw_noise(n_chunks, 1, self.cfg, sd) for sd in seeds], dim=1).to(self.rank, non_blocking=True)
+        noise = self._noise_batch_to_device(n_chunks, seeds)
         r_s = torch.cat([c["r_s"].reshape(1, -1) for c in conds])
         wa = torch.cat([c["wa"].reshape(1, T, -1) for c in conds])
         we = torch.cat([c["we"].reshape(1, 1, -1) for c in conds])
         r_d = self.G.batched_fmt(B).sample(r_s, wa, we, noise, self.opt.nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale)
         out = []
-        for i, (s, _) in enumerate(items):
-            # the encoder's skip maps of item i (its buffers hold the last encoded image): one more 1-ms encoder pass
-            s_r, _, _, _ = self.enc.encode_image_into_latent(s, want_feats=False)
-            self.enc.hand_feats_to(self.G.dec)
-            out.append(self.G.decode_to_host(s_r, r_d[i]))
+        for i in range(B):
+            # decodes queue back to back: the last frames of item i cross PCIe inside the launches of item i + 1
+            self.G.dec.set_feats16(feats[i], self.enc.dtype)
+            out.append(self.G.decode_to_host(conds[i]["s_r"], r_d[i]))
         torch.cuda.current_stream(self.rank).synchronize()
         self.check_range("InferenceAgent.infer_device_batch")
         return out

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define FLOAT_HIP_ABI_VERSION 5
+#define FLOAT_HIP_ABI_VERSION 6
 
 enum {
   FLOAT_OK = 0,
@@ -314,6 +314,10 @@ int float_enc_forward(float_enc_t* h, const float* img, float* s_r, float* lam, 
 int float_enc_saturation(float_enc_t* h, uint64_t* total, int32_t reset, void* stream); /* see float_fmt_saturation */
 int float_enc_feats16(float_enc_t* h, const void** feats16, int32_t* channels, int32_t max_feats,
                       int32_t* n_out);
+/* Stream-ordered copies of those maps into caller buffers (dst[i]: R_i x R_i x C_i elements of the operator's type, reference
+ * order): a batch of portraits (nodes.py:189-209) keeps one set per item and hands it to float_dec_set_feats16 when the item
+ * is decoded, instead of encoding the item a second time. */
+int float_enc_export_feats16(float_enc_t* h, void* const* dst, int32_t n_feats, void* stream);
 
 /* ---------------------------------------------------------------- audio encoder --- */
 /* Audio conditioning, once per clip: AudioEncoder.inference (reference

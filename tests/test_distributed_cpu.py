@@ -51,8 +51,13 @@ def test_sample_range_equals_oracle_loop():
     for dynamic in (False, True):
         cfg, sd, T, wa, r_s, we, noise = _problem(dynamic)
         ref = O.sample_rd(sd, cfg, r_s, wa, we, noise, 4, 2.0, 1.0, 1.0)
-        xs, _ = D.sample_range(OracleFmt(sd, cfg), cfg, r_s, wa, we, noise, 0, 4, 4, 2.0, 1.0, 1.0)
-        assert torch.allclose(xs[:, :T], ref, atol=1e-6)
+        xs, tail = D.sample_range(OracleFmt(sd, cfg), cfg, r_s, wa, we, noise, 0, 4, 4, 2.0, 1.0, 1.0)
+        # the contract of both implementations: rows trimmed to the clip; behind the clip's trimmed last window prev_x is zeros
+        assert xs.shape[1] == T and torch.allclose(xs, ref, atol=1e-6)
+        assert float(tail[0].abs().max()) == 0.0 and tail[0].shape == (1, cfg.num_prev_frames, cfg.dim_w)
+        mid, tail = D.sample_range(OracleFmt(sd, cfg), cfg, r_s, wa, we, noise, 0, 2, 4, 2.0, 1.0, 1.0)
+        L, P = cfg.num_frames_for_clip, cfg.num_prev_frames
+        assert mid.shape[1] == 2 * L and torch.allclose(tail[0], ref[:, 2 * L - P:2 * L], atol=1e-6)
 
 
 def _free_port():

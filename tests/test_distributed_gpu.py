@@ -11,7 +11,7 @@ import sys
 import pytest
 import torch
 
-from tests.util import ROOT, load_pkg, sample_inputs
+from tests.util import ROOT, load_pkg, rel_l2, sample_inputs
 
 pkg = load_pkg()
 D = pkg.distributed
@@ -40,6 +40,16 @@ def test_native_window_range_is_the_sequential_chain(dynamic):
     assert torch.equal(mid, ref[:, 2 * L:4 * L]) and torch.equal(tail[0], ref[:, 4 * L - P:4 * L])
     with pytest.raises(ValueError, match="window range"):
         pkg.fmt.WindowSampler(fmt, r_s, wa, we, noise, 6, 2.0, 1.0, 1.0, windows=(3, 9))
+
+    # the host loop (one sample_chunk call per window: what an object without a HIP handle gets) obeys the same contract on
+    # the clip's trimmed last window: same trimmed rows, zero prev_x, same conditioning tails
+    class HostLoop:
+        sample_chunk = staticmethod(fmt.sample_chunk)
+    h_part, h_tail = D.sample_range(HostLoop(), cfg, r_s, wa, we, noise, 2, 5, 6, 2.0, 1.0, 1.0, hist)
+    n_part, n_tail = D.sample_range(fmt, cfg, r_s, wa, we, noise, 2, 5, 6, 2.0, 1.0, 1.0, hist)
+    assert h_part.shape == n_part.shape and rel_l2(h_part, n_part) < 1e-3
+    assert all(a.shape == b.shape for a, b in zip(h_tail, n_tail))
+    assert float(h_tail[0].abs().max()) == 0.0 and float(n_tail[0].abs().max()) == 0.0 and torch.equal(h_tail[1], n_tail[1])
 
 
 _RCCL_SCRIPT = r'''

@@ -16,7 +16,7 @@ def test_library_exports_header_symbols():
     L = pkg.native.lib()
     for name in declared:
         assert hasattr(L, name)
-    assert L.float_hip_abi_version() == 5  # v5: float_probe_peaks, optional `blur_kernel` tensor; v4: float_{fmt,enc,aud}_saturation (v3: fp32 decoder, float_dec_saturation, float_dec_debug_* unit ops)
+    assert L.float_hip_abi_version() == 6  # v6: float_enc_export_feats16; v5: float_probe_peaks, optional `blur_kernel` tensor; v4: float_{fmt,enc,aud}_saturation (v3: fp32 decoder, float_dec_saturation, float_dec_debug_* unit ops)
 
 
 def test_product_does_not_import_oracle():
