@@ -164,11 +164,13 @@ def stress_decoder(size=512, seed=0, kind="warp", style_gain=100.0, act_gain=300
                   by 2.6e-3 at 64 px and by 2.4 (rel-L2 0.25) at 512 px, so it is only a test case at 64 px;
     kind "warp_smooth": unit-gain ToFlow convs on the smooth features of the tame goldens - the 512-px form (reference fp32
                   vs fp64: max 0.21, rel-L2 2.8e-3; the fixtures record that sensitivity and the tests scale their limits by it).
+    kind "warp_half": the same at flow gain 0.5 - between the tame goldens (0.1) and the chaotic unit gain: the second point of
+                  the 16-bit tolerance table (how fast the fp16 frame error grows with the amplitude of the warp).
     kind "range": modulation weights x style_gain (styles reach +-3 style_gain = 300: StyleGAN2's fp16 overflow case) and
                   ConstantInput / skip features x act_gain (activations 1e2..1e4); the ToFlow convs (whose own modulation is
                   left alone) are scaled back by 1 / act_gain so that the warp stays a warp instead of saturating tanh."""
-    if kind in ("warp", "warp_smooth"):
-        sd = synth_decoder_state(size, seed=seed, flow_gain=1.0)
+    if kind in ("warp", "warp_smooth", "warp_half"):
+        sd = synth_decoder_state(size, seed=seed, flow_gain=0.5 if kind == "warp_half" else 1.0)
         feats = synth_feats(size, seed=seed, smooth=1, hi=0.5) if kind == "warp" else synth_feats(size, seed=seed)
         return sd, feats
     if kind != "range":

@@ -71,3 +71,37 @@ def test_warp_stress_fp16_sensitivity_record(kind, size, limit):
         kind, size, r, m, g["ref_vs_f64_rel"], g["ref_vs_f64_max"], dec.saturation()))
     assert dec.saturation() == 0
     assert r <= limit
+
+
+def _frame_metrics(got_raw, want_raw):
+    """PSNR / share of samples beyond 2/255 / max on the post-processed frames (clamp(-1, 1), (x + 1) / 2: FLOAT.py:149-152)."""
+    a, b = got_raw.clamp(-1, 1) * 0.5 + 0.5, want_raw.clamp(-1, 1) * 0.5 + 0.5
+    d = (a - b).double()
+    psnr = -10 * math.log10(max(1e-20, float(d.pow(2).mean())))
+    return psnr, 100.0 * float((d.abs() > 2 / 255).double().mean()), float(d.abs().max())
+
+
+def test_fp16_tolerance_against_the_amplitude_of_the_warp():
+    """The 16-bit tolerance table as a SLOPE, not a point: the same smooth skip features and seeded weights at ToFlow gain 0.1
+    (the tame golden dec_512: 56 dB, tests/test_dec_gpu.py), 0.5 (dec_stress_warp_half_512) and 1.0 (dec_stress_warp_smooth_512),
+    fp16 decoder against the reference Synthesis on post-processed frames.  NOT a parity claim beyond gain 0.1: with random
+    weights the map amplifies a perturbation by the factor the reference's own fp32-vs-fp64 difference shows (gain 0.5: max
+    3.1e-2 from 6e-8 roundings = 5e5 x; gain 1.0: 0.21 = 3.5e6 x), and fp16 operands round 8192 x coarser than fp32 - the fp16
+    frames leave the tolerance somewhere between gain 0.1 and 0.5 (26.6 dB, 35 % of the samples beyond 2/255 at 0.5).  What IS
+    asserted: the fp32 verification mode of the same kernels stays within 10 x the reference's own sensitivity at gain 0.5
+    (the logic is right, the operand width is the limit), nothing overflows, the fp16 drift is where it was measured.  A checkpoint whose reference fp32-vs-fp64 sensitivity is near these cases needs dtype fp32."""
+    rows = []
+    for kind, gain in (("warp_half", 0.5), ("warp_smooth", 1.0)):
+        g, dec, got, want = _run(kind, 512)
+        assert dec.saturation() == 0
+        rows.append((gain,) + _frame_metrics(got, want) + (g["ref_vs_f64_max"],))
+    for gain, psnr, beyond, mx, ref64 in rows:
+        print("fp16 decoder at flow gain %.1f (512 px): PSNR %.1f dB, %.2f %% beyond 2/255, max %.3f (reference fp32 vs fp64 max %.3f)" % (
+            gain, psnr, beyond, mx, ref64))
+    g, dec, got, want = _run("warp_half", 512, dtype="fp32")
+    m32 = max_abs(got, want)
+    print("fp32 mode at flow gain 0.5: max|d| %.3e raw (reference fp32 vs fp64 %.3e)" % (m32, g["ref_vs_f64_max"]))
+    assert m32 <= 10 * g["ref_vs_f64_max"]
+    half = rows[0]
+    assert 22.0 <= half[1] <= 45.0, half            # the record: 26.6 dB at gain 0.5 ...
+    assert 22.0 <= rows[1][1] <= 45.0, rows[1]      # ... 29.7 dB at 1.0 (clamped frames: not monotone once everything drifts)

@@ -676,7 +676,11 @@ def main():
         gen_dec_stress(ns, 64, 1710, "range", sparse=False)
         gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
         gen_dec_stress(ns, 512, 1730, "range", sparse=True)
+        gen_dec_stress(ns, 512, 1740, "warp_half", sparse=True)
         gen_dec_cm2(ns)
+        return
+    if os.environ.get("GOLDENS_ONLY") == "warp_half":
+        gen_dec_stress(ns, 512, 1740, "warp_half", sparse=True)
         return
     if os.environ.get("GOLDENS_ONLY") == "blur":
         gen_dec_blur(ns)
@@ -717,6 +721,7 @@ def main():
     gen_dec_stress(ns, 64, 1710, "range", sparse=False)
     gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
     gen_dec_stress(ns, 512, 1730, "range", sparse=True)
+    gen_dec_stress(ns, 512, 1740, "warp_half", sparse=True)
     gen_dec_cm2(ns)
     gen_encoder(ns, 64, seed=1000, sparse=False)
     gen_encoder(ns, 512, seed=1100, sparse=True)
