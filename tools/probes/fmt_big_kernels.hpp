@@ -1,0 +1,242 @@
+// LAB ONLY (tools/probes/gemm_big_lab.hip) - a measured negative result of round 5, not part of the library.
+//
+// The FMT's large GEMM - the adaLN projection of every evaluation of a window (FMT.py:163-166, 187-190: M = evaluations x rows
+// = 9 000 per clip, N = 51 200, K = 1 024, fp32 modulations out) - as a PERSISTENT kernel on 192 x 256 tiles, written to take
+// what fmt_gemm_dma_kernel (192 x 320 tiles, one workgroup per tile, 0.36 of the dense MFMA peak) loses OUTSIDE its K loop:
+//   * rows DENSE over the evaluations (47 row blocks of 192 instead of 50 evaluations padded from 180 to 192 rows: -6 %);
+//   * one workgroup per CU walks its share of the tile list and the LDS-DMA ring never stops at a tile boundary: the first
+//     operands of tile t + 1 land while tile t is being stored (no ~1 us wait per tile);
+//   * the epilogue does not touch the ring: a wave passes its 96 x 64 accumulators 16 rows at a time through a PRIVATE 4-KB LDS
+//     slab (XOR-swizzled granules, conflict-free, no workgroup barrier) and stores whole 256-byte rows; the bias arrives by one
+//     register load per tile; stores and that load are counted by hand in the vmcnt waits (the kernel must compile without
+//     spills: scratch reloads are vector-memory operations);
+//   * tile order: an XCD's 32 workgroups hold 8 row blocks x 4 column blocks at any time (FETCH_SIZE: 1.55 GB of the 8.4 GB of
+//     tile fetches of a launch leave the L2s: 82 % hits).
+// MEASURED (MI355X): in the lab, on uniform random operands, 1 094-1 110 us per launch against 1 232-1 273 for
+// fmt_gemm_dma_kernel on the same box; IN THE PIPELINE (real SiLU operands: a higher clock for both) a tie - FMT sampling
+// 81.6 vs 81.3 ms per clip, 161.5 vs 160.3 ms per 4 clips, 469 vs 460 per 16.  Counters: MFMA pipe 41 % of the cycles, waves
+// 43 % issue-stalled, 29 % parked - with the stores removed still 0.37-0.41 of the peak: the K loop, not what surrounds it, is
+// the limit.  A step costs the sum of its LDS-DMA issue (28 pieces of 1 KiB per k-block, ~100 clocks of issue each, all waves
+// behind the same barrier) and its MFMAs; spreading the pieces over the step (wave w in front of its MFMA chunk w, BIG_SPREAD)
+// made it 10 % SLOWER, 256-row tiles (MI = 8) spill.  What would move it is a structure whose two waves per SIMD sit in
+// opposite phases (one multiplies while the other issues and reads): not built.
+#pragma once
+#include "fmt_rb_kernels.hpp"  // -I comfyui-float_optimized_amd/csrc
+
+#ifndef BIG_SPREAD
+#define BIG_SPREAD 1  // 1: a wave issues its LDS-DMA pieces in front of MFMA chunk `wave index` of the step; 0: all waves behind the barrier
+#endif
+struct BigArgs {
+  const u16* A;       // packed [row tiles][KB][64][8], rows dense, readable up to nrb row blocks
+  const u16* W;       // packed [N/16][KB][64][8]
+  const float* bias;  // [N]
+  float* out;         // [M][ldo] fp32
+  int M, N, K, ldo;
+  int nrb, ncb;       // row blocks (192 or 256 rows: the kernel's MI) / column blocks of 256 (ncb a multiple of 8)
+};
+
+template <class T, int MI /* row fragments per wave: 6 -> 192-row tiles, 8 -> 256-row tiles */, int NS>
+__global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
+  constexpr int NJ = 4, RT = 2 * MI, CT = 16, NF = RT + CT, STAGE = NF * 1024, ROWS = RT * 16;
+  constexpr int IMAX = (NF + 7) / 8, ILO = NF / 8, NHI = NF % 8;  // pieces per wave and stage: IMAX for waves < NHI
+  constexpr int NST = MI * 4 + 1;  // vector-memory operations of an epilogue: MI x 4 row stores + the next tile's bias load
+  static_assert(NS >= 3 && NS <= 4, "ring of 3 or 4 stages");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];  // [NS][32 fragments][1 KiB] ring | [8 waves][4 KiB] staging
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wr = w >> 2, wc = w & 3, r16 = lane & 15, q = lane >> 4;
+  const int KB = g.K >> 5;
+  const size_t tstride = (size_t)KB * 512;
+  // ---- this workgroup's tiles: entries slot, slot + nslot, ... of its XCD's list
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+  const int nc8 = g.ncb >> 3;                       // column blocks of this XCD: x + 8 c
+  const int per_grp = 4 * g.nrb, full = nc8 >> 2;   // entries of a full group of 4 column blocks
+  const int nent = nc8 * g.nrb;
+  const int ntl = slot < nent ? (nent - slot + nslot - 1) / nslot : 0;
+  if (ntl == 0) return;
+  auto tile_of = [&](int j, int& rb, int& cb) {
+    const int e = slot + j * nslot;
+    int grp = e / per_grp, rem = e - grp * per_grp, ncol = 4;
+    if (grp >= full) {
+      grp = full;
+      rem = e - full * per_grp;
+      ncol = nc8 - full * 4;
+    }
+    rb = rem / ncol;
+    cb = x + 8 * (grp * 4 + (rem - rb * ncol));
+  };
+  const int Stot = ntl * KB;  // stages of this workgroup
+
+  // pieces of a stage issued by this wave: fragments f = w + 8 i (f < RT: row tile f of A, else column tile f - RT of W)
+  const u16* src[IMAX];
+  int cur_issue_tile = -1;
+  auto set_tile_ptrs = [&](int j) {
+    int rb, cb;
+    tile_of(j, rb, cb);
+#pragma unroll
+    for (int i = 0; i < IMAX; ++i) {
+      const int f = min(w + 8 * i, NF - 1);
+      src[i] = f < RT ? g.A + (size_t)(rb * RT + f) * tstride : g.W + (size_t)(cb * CT + f - RT) * tstride;  // wave-uniform: scalar registers
+    }
+    cur_issue_tile = j;
+  };
+  auto issue = [&](int gs) {
+    const int j = gs / KB, kb = gs - j * KB;
+    if (j != cur_issue_tile) set_tile_ptrs(j);
+    unsigned char* dst = lds + (gs % NS) * STAGE + w * 1024;
+#pragma unroll
+    for (int i = 0; i < IMAX; ++i)
+      if (i < ILO || w < NHI)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kb * 512 + lane * 8),
+                                         (__attribute__((address_space(3))) void*)(dst + i * 8 * 1024), 16, 0, 0);
+  };
+  // bias of this wave's 64 columns, 4 per lane (lane % 16), by a register load the compiler does not see (no wait of its own)
+  auto load_bias = [&](int j) -> f32x4 {
+    int rb, cb;
+    tile_of(min(j, ntl - 1), rb, cb);
+    const float* p = g.bias + cb * 256 + wc * 64 + (lane & 15) * 4;
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  };
+
+  const unsigned abase = (unsigned)(lane * 16 + (wr * MI) * 1024), bbase = (unsigned)(lane * 16 + (RT + wc * NJ) * 1024);
+  f32x4 acc[MI][NJ];
+  u32x4 a0[MI], b0[NJ], a1[MI], b1[NJ];
+  auto read_frags = [&](int gs, u32x4(&ar)[MI], u32x4(&br)[NJ]) {
+    const unsigned so = (unsigned)((gs % NS) * STAGE);
+    fh_static_for<0, MI>([&](auto i) { ar[i.value] = fh_ds_read128<i.value * 1024>(abase + so); });
+    fh_static_for<0, NJ>([&](auto j) { br[j.value] = fh_ds_read128<j.value * 1024>(bbase + so); });
+  };
+  // wait until stage gs + 1 has landed: `extra` = 1 while the last epilogue's NST operations are younger than that stage
+#define BIG_WAIT(K, EXTRA)                                                  \
+  do {                                                                      \
+    if (NHI == 0 || w < NHI) {                                              \
+      if (EXTRA) fh_wait_vmcnt<(K)*IMAX + NST>();                           \
+      else fh_wait_vmcnt<(K)*IMAX>();                                       \
+    } else {                                                                \
+      if (EXTRA) fh_wait_vmcnt<(K)*ILO + NST>();                            \
+      else fh_wait_vmcnt<(K)*ILO>();                                        \
+    }                                                                       \
+  } while (0)
+#define BIG_WAIT_UPTO(K, EXTRA)                              \
+  do {                                                       \
+    const int k_ = (K);                                      \
+    if (NS == 4 && k_ >= 2) BIG_WAIT(2, EXTRA);              \
+    else if (k_ >= 1) BIG_WAIT(1, EXTRA);                    \
+    else BIG_WAIT(0, EXTRA);                                 \
+  } while (0)
+#define BIG_STEP(GS, SINCE, AC, BC, AN, BN_)                                                    \
+  do {                                                                                          \
+    const int s_ = (GS);                                                                        \
+    if (s_ + 1 < Stot) {                                                                        \
+      if ((SINCE) < NS - 1 && drained == 0) BIG_WAIT_UPTO(Stot - 2 - s_, true);                 \
+      else BIG_WAIT_UPTO(Stot - 2 - s_, false);                                                 \
+    }                                                                                           \
+    __builtin_amdgcn_s_barrier();                                                               \
+    if (BIG_SPREAD == 0 && s_ + NS < Stot) issue(s_ + NS);                                      \
+    if (s_ + 1 < Stot) read_frags(s_ + 1, AN, BN_);                                             \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                             \
+      /* wave w issues its pieces of stage s + NS in front of its chunk w: the CU's 28 pieces of a stage enter the address  */ \
+      /* path spread over the step instead of as one burst behind the barrier                                              */ \
+      if (BIG_SPREAD != 0 && c == w && s_ + NS < Stot) issue(s_ + NS);                          \
+      _Pragma("unroll") for (int m = c * (MI * NJ / 8); m < (c + 1) * (MI * NJ / 8); ++m)       \
+        acc[m / NJ][m % NJ] = T::mfma(BC[m % NJ], AC[m / NJ], acc[m / NJ][m % NJ]);             \
+      if (BIG_SPREAD != 0) __builtin_amdgcn_sched_barrier(0);                                   \
+    }                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
+    __builtin_amdgcn_sched_barrier(0);                                                          \
+  } while (0)
+
+  f32x4 bias_cur = load_bias(0);  // older than every DMA
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    if (s < Stot) issue(s);
+  if (Stot >= NS) BIG_WAIT(NS - 1, false);
+  else fh_wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, a0, b0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+
+  unsigned char* const stg = lds + NS * STAGE + w * 4096;  // this wave's private slab: [16 rows][16 granules of 16 B], granule ^ row
+  const unsigned stg_lds = (unsigned)(NS * STAGE + w * 4096);
+  int drained = 1;  // 1: nothing of an epilogue is outstanding (first tile, or an epilogue that ended with vmcnt(0))
+  for (int j = 0; j < ntl; ++j) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int gs0 = j * KB;
+    for (int kb = 0; kb < KB; kb += 2) {
+      BIG_STEP(gs0 + kb, kb, a0, b0, a1, b1);
+      BIG_STEP(gs0 + kb + 1, kb + 1, a1, b1, a0, b0);
+    }
+    // ---- epilogue of tile j from the accumulators; the ring keeps filling with tile j + 1 meanwhile
+    int rb, cb;
+    tile_of(j, rb, cb);
+    const int row0 = rb * ROWS + wr * (MI * 16), col0 = cb * 256 + wc * 64;
+    const f32x4 bias_next = load_bias(j + 1);  // 1 of the NST operations; used by the next epilogue
+    const bool whole = row0 + MI * 16 <= g.M;   // every store of this wave is issued: the hand count of NST holds
+    // running output address = scalar base (4 rows further per store) + this lane's 32-bit offset.  The base is kept opaque:
+    // the compiler would otherwise precompute one 64-bit address per store at kernel start and spill them - and scratch
+    // reloads are vector-memory operations that would break the hand count of NST.  The kernel must compile WITHOUT spills.
+    typedef __attribute__((address_space(1))) char gchar;  // global address space kept explicit: behind the opaque asm the
+    typedef __attribute__((address_space(1))) f32x4 gf32x4;  // compiler would emit FLAT stores (out of order, two counters)
+    gchar* obase = (gchar*)(g.out + (size_t)row0 * g.ldo + col0);  // wave-uniform, advanced per store
+    const unsigned ovoff = (unsigned)((q * g.ldo + (lane & 15) * 4) * 4);                      // this lane's byte offset in a 4-row group
+    const size_t ostep = (size_t)16 * g.ldo;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      // 16 rows x 64 columns through the slab: write in accumulator order (row r16, granule jj * 4 + q), read back by rows
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) {
+        const unsigned ad = stg_lds + (unsigned)(r16 * 256 + (((jj * 4 + q) ^ r16) << 4));
+        asm volatile("ds_write_b128 %0, %1" ::"v"(ad), "v"(acc[i][jj]) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      f32x4 v[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = p * 4 + q;  // lane -> row p * 4 + lane / 16, granule lane % 16
+        const unsigned ad = stg_lds + (unsigned)(r * 256 + (((lane & 15) ^ r) << 4));
+        asm volatile("ds_read_b128 %0, %1" : "=v"(v[p]) : "v"(ad) : "memory");
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int r = i * 16 + p * 4 + q;
+        if (whole || row0 + r < g.M) {
+          f32x4 o = v[p] + bias_cur;
+#if defined(BIG_NO_STORE)
+          asm volatile("" ::"v"(o));
+#elif defined(BIG_STORE_PLAIN)
+          *(gf32x4*)(obase + ovoff) = o;
+#elif defined(BIG_STORE_NT)
+          __builtin_nontemporal_store(o, (gf32x4*)(obase + ovoff));
+#else
+          // write-through and not kept in the XCD's L2 (sc1): the 1.8 GB of modulations of a launch would otherwise pass through
+          // the 4-MB L2s as dirty lines and push the operand tiles out
+          asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(ovoff), "v"(o), "s"(obase) : "memory");
+#endif
+        }
+        obase += ostep;
+        asm volatile("" : "+s"(obase));
+      }
+    }
+    bias_cur = bias_next;
+    if (!whole) {  // fewer than 32 stores may have been issued: start the count afresh
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      drained = 1;
+    } else {
+      drained = 0;
+    }
+    (void)stg;
+  }
+#undef BIG_STEP
+#undef BIG_WAIT_UPTO
+#undef BIG_WAIT
+}

@@ -1,0 +1,127 @@
+// Lab for fmt_gemm_big_kernel (persistent 256 x 256 tiles) against fmt_gemm_dma_kernel on the adaLN projection's shape
+// (M = evaluations x rows, N = 51 200, K = 1 024, fp32 out), checked on sampled outputs against fp32 dot products.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I comfyui-float_optimized_amd/csrc -I tools/probes tools/probes/gemm_big_lab.hip -o build_ab/gemm_big_lab
+// (see fmt_big_kernels.hpp for what was measured: a tie with fmt_gemm_dma_kernel in the pipeline)
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#ifndef BIG_MI
+#define BIG_MI 6
+#endif
+#include "fmt_big_kernels.hpp"
+
+void fh_set_error(const char*, ...) {}
+int g_fh_profiling = 0;
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+static float h2f(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
+
+int main(int argc, char** argv) {
+  const int steps = argc > 1 ? atoi(argv[1]) : 50, rows = argc > 2 ? atoi(argv[2]) : 180;
+  const int M = steps * rows, N = 51200, K = 1024, KB = K / 32;
+  constexpr int MI = BIG_MI, RB = MI * 32;
+  const int nrb = (M + RB - 1) / RB, Mp = nrb * RB;
+  std::mt19937 rng(1);
+  std::uniform_real_distribution<float> U(-1.f, 1.f);
+  std::vector<u16> hA((size_t)Mp * K), hW((size_t)N * K);
+  for (auto& v : hA) v = FP16::host_from_float(U(rng));
+  for (auto& v : hW) v = FP16::host_from_float(U(rng) * 0.05f);
+  std::vector<float> hb(N);
+  for (auto& v : hb) v = U(rng);
+  u16 *dA, *dW;
+  float *db, *dout;
+  CK(hipMalloc(&dA, hA.size() * 2));
+  CK(hipMalloc(&dW, hW.size() * 2));
+  CK(hipMalloc(&db, N * 4));
+  const size_t out_rows = std::max((size_t)Mp, (size_t)steps * 192 + 192);
+  CK(hipMalloc(&dout, out_rows * N * 4));
+  CK(hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+  CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
+  CK(hipMemset(dout, 0xff, out_rows * N * 4));
+  BigArgs g{dA, dW, db, dout, M, N, K, N, nrb, N / 256};
+  constexpr int NS = 4, smem = NS * (2 * MI + 16) * 1024 + 8 * 4096;
+  auto kern = fmt_gemm_big_kernel<FP16, MI, NS>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+  int ncu = 0;
+  CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+  const int grid = (ncu / 8) * 8;
+  auto launch = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, nullptr, g); };
+  launch();
+  CK(hipDeviceSynchronize());
+  // sampled check: 4000 random outputs + the corners of the last row block
+  std::vector<float> out((size_t)M * 0 + 1);
+  double num = 0, den = 0, mx = 0;
+  std::mt19937 r2(7);
+  int bad = 0;
+  for (int t = 0; t < 4000; ++t) {
+    int row = t < 3900 ? (int)(r2() % M) : (M - 1 - (int)(r2() % 16)), n = (int)(r2() % N);
+    float got;
+    CK(hipMemcpy(&got, dout + (size_t)row * N + n, 4, hipMemcpyDeviceToHost));
+    double ref = hb[n];
+    for (int k = 0; k < K; ++k) ref += (double)h2f(hA[fmt_pack_off(row, k, KB)]) * h2f(hW[fmt_pack_off(n, k, KB)]);
+    const double d = got - ref;
+    num += d * d, den += ref * ref, mx = std::max(mx, std::fabs(d));
+    if (std::fabs(d) > 1e-2) ++bad;
+  }
+  // rows >= M must be untouched (0xff pattern = NaN)
+  float tail;
+  CK(hipMemcpy(&tail, dout + (size_t)M * N + 5, 4, hipMemcpyDeviceToHost));
+  printf("big kernel check: rel-L2 %.2e max %.2e bad %d; row M untouched: %s\n", std::sqrt(num / den), mx, bad, std::isnan(tail) || Mp == M ? "yes" : "NO");
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < 5; ++i) launch();
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = ms * 1e3 / 5;
+    printf("fmt_gemm_big_kernel  M=%d: %8.1f us  %7.1f TFLOP/s (%.3f of 2.5 PFLOP/s)\n", M, us, 2.0 * M * N * K / us * 1e-6, 2.0 * M * N * K / us * 1e-6 / 2500);
+  }
+  // the 192 x 320 one-tile-per-workgroup kernel on the padded layout (steps x 192 rows)
+  {
+    const int Mpad = 192;
+    std::vector<u16> hA2((size_t)steps * Mpad * K + (size_t)12 * 16 * K, 0);
+    for (int z = 0; z < steps; ++z)
+      for (int r = 0; r < std::min(rows, Mpad); ++r)
+        for (int k = 0; k < K; ++k) hA2[(size_t)z * Mpad * K + fmt_pack_off(r, k, KB)] = hA[fmt_pack_off(z * rows + r, k, KB)];
+    u16* dA2;
+    CK(hipMalloc(&dA2, hA2.size() * 2));
+    CK(hipMemcpy(dA2, hA2.data(), hA2.size() * 2, hipMemcpyHostToDevice));
+    GemmArgs ga;
+    memset(&ga, 0, sizeof(ga));
+    ga.A = dA2, ga.W = dW, ga.bias = db, ga.K = K, ga.N = N, ga.M = std::min(rows, Mpad), ga.out_f32 = dout, ga.ldo = N;
+    ga.zcount = steps, ga.zgroup = 2, ga.a_zstride = (size_t)Mpad * K, ga.o_zstride = (size_t)Mpad * N, ga.mblk = 1;
+    constexpr int smem2 = 4 * 32 * 1024;
+    auto k2 = fmt_gemm_dma_kernel<FP16, 4, 4, 1>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+    if (rows <= 192) {
+      for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k2, dim3((N / 320) * steps), dim3(512), smem2, nullptr, ga);
+        CK(hipEventRecord(e1, nullptr));
+        CK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const double us = ms * 1e3 / 5;
+        printf("fmt_gemm_dma_kernel  M=%d: %8.1f us  %7.1f TFLOP/s\n", M, us, 2.0 * M * N * K / us * 1e-6);
+      }
+    }
+  }
+  return 0;
+}
