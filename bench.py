@@ -428,11 +428,11 @@ def main():
             mod_roof["frac"] = round(mod_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
         # HBM traffic per launch / MFMA pipe utilisation from the committed rocprofv3 --pmc passes (tools/profile_round.sh),
         # only when they were taken on these kernel sources
-        pmc = load_profile_json("r04_pmc_traffic.json", warnings)
+        pmc = load_profile_json("r05_pmc_traffic.json", warnings)
         if pmc:
             gemm_roof["traffic"] = pmc.get("fmt_gemm", {}).get("hbm_bytes_per_launch")
             conv_roof["traffic"] = pmc.get("dec_conv", {}).get("hbm_bytes_per_launch")
-        mf = load_profile_json("r04_pmc_mfma.json", warnings)
+        mf = load_profile_json("r05_pmc_mfma.json", warnings)
         if mf:
             gemm_roof["mfma_util_pmc"] = mf.get("fmt_gemm", {}).get("mfma_util")
             conv_roof["mfma_util_pmc"] = mf.get("dec_conv", {}).get("mfma_util")

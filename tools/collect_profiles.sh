@@ -7,7 +7,7 @@ if [ -s $S/bench_final.json ]; then cp $S/bench_final.json ${P}_bench.json; else
 cp $S/stats/bench_kernel_stats.csv ${P}_bench_kernel_stats.csv
 cp $S/pmc_mfma.json ${P}_pmc_mfma.json
 cp $S/pmc_traffic.json ${P}_pmc_traffic.json
-for w in fmt dec; do
+for w in fmt fmtb dec; do
   python3 tools/summarize_pmc.py $S/pmc_FETCH_SIZE_$w > ${P}_pmc_fetch_size_$w.csv
   python3 tools/summarize_pmc.py $S/pmc_WRITE_SIZE_$w > ${P}_pmc_write_size_$w.csv
   python3 tools/summarize_pmc.py $S/pmc_sq_$w > ${P}_pmc_sq_$w.csv

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3 counter passes (PMC passes serialise kernels, so the whole
 bench would take minutes): `--what dec` decodes 16 frames at 512x512 twice, `--what fmt` runs one
-50-frame window with 10 Euler evaluations (eager launches).
+50-frame window with 10 Euler evaluations (eager launches), `--what fmtb` the same window for 4 stacked clips (720 rows:
+the row-blocked LDS-DMA GEMM tiles).
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/profile_hotpath.py --what dec
 """
@@ -16,7 +17,7 @@ sys.path.insert(0, ROOT)
 from tests.util import load_pkg  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--what", default="dec", choices=["dec", "fmt"])
+ap.add_argument("--what", default="dec", choices=["dec", "fmt", "fmtb"])
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--reps", type=int, default=2)
 args = ap.parse_args()
@@ -33,6 +34,17 @@ if args.what == "dec":
         out = dec.decode_latent_into_processed_images(s_r, r_d)
     torch.cuda.synchronize()
     print("decoded", tuple(out.shape), float(out.mean()))
+elif args.what == "fmtb":
+    B = 4
+    sd = pkg.weights.synth_fmt_state(cfg, seed=1)
+    fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, dev, "fp16", use_graph=0, max_batch=B)
+    cs = [pkg.pipeline.synth_conditions(cfg, 50, seed=q) for q in range(B)]
+    cat = lambda k: torch.cat([c[k] for c in cs])  # noqa: E731
+    noise = pkg.fmt.draw_noise(1, B, cfg, 15)
+    for _ in range(args.reps):
+        r_d = fmt.sample(cat("r_s"), cat("wa"), cat("we"), noise, 11, 2.0, 1.0, 1.0)
+    torch.cuda.synchronize()
+    print("sampled", tuple(r_d.shape), float(r_d.abs().mean()))
 else:
     sd = pkg.weights.synth_fmt_state(cfg, seed=1)
     fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, dev, "fp16", use_graph=0)
