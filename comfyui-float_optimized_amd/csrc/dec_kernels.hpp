@@ -1107,10 +1107,26 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
 #pragma unroll
         for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) b[ty][j] = *reinterpret_cast<const P8*>(sB + fb + ((ty * TX + tx) * BN + j * 16) * RB);
+          for (int j = 0; j < NT; ++j) {
+#ifdef DEC_DIAG_READS36  // timing-only build (WRONG frames): two thirds of the fragment reads, every MFMA - the bound on a 32-pixel-wide M tile
+            if (ty == TY - 1 && TY == 3) {
+              b[ty][j] = b[0][j];
+              continue;
+            }
+#endif
+            b[ty][j] = *reinterpret_cast<const P8*>(sB + fb + ((ty * TX + tx) * BN + j * 16) * RB);
+          }
+#ifdef DEC_DIAG_READS36
+        P8 a_seen[3 + TY];
+#endif
 #pragma unroll
         for (int hr = 0; hr < 3 + TY; ++hr) {
+#ifdef DEC_DIAG_READS36
+          const P8 a = (hr >= 4 && TY == 3) ? a_seen[hr - 4] : *reinterpret_cast<const P8*>(sA + fa[tx] + hr * HW * RB);
+          a_seen[hr] = a;
+#else
           const P8 a = *reinterpret_cast<const P8*>(sA + fa[tx] + hr * HW * RB);
+#endif
 #pragma unroll
           for (int mt = 0; mt < 4; ++mt) {
             const int ty = hr - mt;

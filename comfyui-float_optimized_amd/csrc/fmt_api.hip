@@ -352,7 +352,9 @@ RbPlan pick_rb(int layer, int M) {
   const int tier = M < 540 ? 0 : (M < 1100 ? 1 : (M < 2200 ? 2 : 3));
   static const int shapes[4][4] = {/* qkv */ {0, 1, 0, 2}, /* proj */ {-1, 0, 0, 2}, /* fc1 */ {0, 1, 2, 2}, /* fc2 */ {0, 1, 2, 2}};
   p.shape = shapes[layer][tier];
-  p.ksplit = layer == RB_PROJ ? 2 : (layer == RB_FC2 ? 4 : 1);
+  // fc2: 4 K slices fill the CUs up to 1440 rows; from 2200 rows on 2 slices do (15 x 8 tiles x 2) and halve the fp32 slabs the
+  // next LayerNorm folds (16 clips: 415.7 vs 438.6 ms per 250 evaluations; 8 clips the other way round: 251.6 vs 241.9)
+  p.ksplit = layer == RB_PROJ ? 2 : (layer == RB_FC2 ? (tier == 3 ? 2 : 4) : 1);
   if (const char* e = getenv(envs[layer])) {
     int sh = p.shape, ks = p.ksplit;
     if (sscanf(e, "%d,%d", &sh, &ks) >= 1) {
@@ -569,6 +571,33 @@ TouchSpec make_touch(const Lin& L, int M, int ksplit, unsigned lanes, unsigned p
   return t;
 }
 
+// The same for a row-blocked GEMM (fmt_gemm_rbs_kernel, no K split): only the FIRST stages of every weight column tile - what
+// each of its workgroups waits for before it can start (1.5 of fc1's 10 us at 720 rows: every CU asks for cold lines at once).
+// Its block decode puts column block bx on XCD bx % 8, like the 48 x 64 tiling's.  FLOAT_FMT_RB_TOUCH = k-blocks to pull (0 = off).
+// Measured, ms per 250 evaluations of 4 / 16 clips: none 152.2 / 408.4, 4 k-blocks 151.8, 8: 151.4, 16: 150.6 / 404.6 (kept),
+// 32 (the whole K of every tile): 150.8 / 410.0.
+int g_fmt_rb_touch = 16;
+TouchSpec make_touch_rb(const Lin& L, int shape, unsigned lanes, unsigned per_lane) {
+  TouchSpec t{};
+  const int ct = shape == 0 ? 4 : 8;  // 16-column tiles per column block: 96 x 64 | 96 x 128, 192 x 128
+  const int kb = g_fmt_rb_touch;
+  if (kb <= 0 || (kb & (kb - 1)) || L.N % (ct * 16) || (L.N / (ct * 16)) % 8 || L.K / 32 < kb) return t;
+  const unsigned run_lines = (unsigned)kb * 8u;  // a k-block of a column tile is 1 KiB = 8 lines, consecutive k-blocks are consecutive
+  auto lg = [](unsigned v) {
+    int n = 0;
+    while ((1u << n) < v) ++n;
+    return n;
+  };
+  t.run_shift = (unsigned)lg(run_lines);
+  t.nt_shift = (unsigned)lg((unsigned)ct);
+  t.p_shift = 3;
+  t.tile_bytes = (unsigned)(L.K / 32) * 1024u;
+  t.total = (unsigned)(L.N / (ct * 16) / 8) * (unsigned)ct * run_lines;
+  if ((size_t)t.total > (size_t)lanes * per_lane) return t;
+  t.W = reinterpret_cast<const char*>(L.W);
+  return t;
+}
+
 // threads per XCD of the launch run_gemm makes for a plain (M, N, K) GEMM
 unsigned gemm_lanes_per_xcd(int M, int N, int K) {
   const Tiling t = pick_tiling(M, N, K, false);
@@ -578,7 +607,7 @@ unsigned gemm_lanes_per_xcd(int M, int N, int K) {
 
 template <class T>
 int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hipStream_t s, PendingRed* pend = nullptr,
-                 const Lin* next = nullptr, u16* out = nullptr, int perm = 0, int touch_bit = 1) {
+                 const Lin* next = nullptr, u16* out = nullptr, int perm = 0, int touch_bit = 1, int rb_shape = -1) {
   const int nv = h->D / 256;
   // one row (wave) per workgroup: 180 single-wave workgroups spread over 180 CUs (4 rows per workgroup: +0.4 %)
   static const int rpw = getenv("FLOAT_FMT_LN_ROWS") ? std::max(1, std::min(4, atoi(getenv("FLOAT_FMT_LN_ROWS")))) : 1;
@@ -589,7 +618,8 @@ int launch_lnmod(float_fmt* h, int M, const float* shift, const float* scale, hi
   LnRed red{};
   if (ks) red = pend->red;
   TouchSpec pf{};
-  if (next && (g_fmt_touch & (1 | touch_bit)) && rpw == 1 && !T::is32) pf = make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
+  if (next && (g_fmt_touch & (1 | touch_bit)) && rpw == 1 && !T::is32)
+    pf = rb_shape >= 0 ? make_touch_rb(*next, rb_shape, (grid.x / 8) * 64, 6) : make_touch(*next, M, 0, (grid.x / 8) * 64, 6);
 #define LN_LAUNCH(NV, KS)                                                                                                          \
   do {                                                                                                                             \
     if (pf.W && wt) hipLaunchKernelGGL((fmt_lnmod_kernel<T, NV, KS, true, true>), grid, block, 0, s, h->xres, M, shift, scale, h->Ntot, out ? out : h->h16, red, pf, h->ntok, perm, h->sat); \
@@ -959,8 +989,8 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
     if ((rc = run_gemm<T, EPI_XEMBED>(g, s))) return rc;
   }
   PendingRed pend;  // residual update left to the next LayerNorm launch
-  // stacked clips: the row-blocked LDS-DMA tile (fmt_rb_kernels.hpp); its launches carry no touch descriptors and the
-  // LayerNorm / attention launches before them pull nothing (their descriptors follow the 48 x 64 tiling's block decode)
+  // stacked clips: the row-blocked LDS-DMA tile (fmt_rb_kernels.hpp); its launches carry no touch descriptors; the LayerNorm in
+  // front of qkv / fc1 pulls the first stages of their weights into the XCDs' L2s (make_touch_rb)
   RbPlan rb_qkv, rb_proj, rb_fc1, rb_fc2;
   if constexpr (!T::is32) {
     rb_qkv = pick_rb(RB_QKV, M), rb_proj = pick_rb(RB_PROJ, M), rb_fc1 = pick_rb(RB_FC1, M), rb_fc2 = pick_rb(RB_FC2, M);
@@ -969,7 +999,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
   for (int b = 0; b < c.depth; ++b) {
     const float* mod = modbuf + (size_t)b * 6 * D;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
     const Blk& B = h->blk[b];
-    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, rb_qkv.shape >= 0 ? nullptr : &B.qkv, nullptr, 0, 128))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod, mod + D, s, &pend, &B.qkv, nullptr, 0, 128, rb_qkv.shape))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.qkv, M);
       g.sat = h->sat;
@@ -1014,7 +1044,7 @@ int run_blocks(float_fmt* h, int nclip, int bc, const float* modbuf, bool euler,
       static const LayerPlan plan("FLOAT_FMT_PLAN_PROJ");
       if ((rc = run_gemm<T, EPI_GATE_RES>(g, s, false, &plan))) return rc;
     }
-    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, rb_fc1.shape >= 0 ? nullptr : &B.fc1, nullptr, 0, 64))) return rc;
+    if ((rc = launch_lnmod<T>(h, M, mod + 3 * D, mod + 4 * D, s, &pend, &B.fc1, nullptr, 0, 64, rb_fc1.shape))) return rc;
     {
       GemmArgs g = base_args(h->h16, B.fc1, M);
       g.sat = h->sat;
@@ -1536,6 +1566,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   if (const char* v = getenv("FLOAT_FMT_WIDE_VARIANT")) g_fmt_wide_variant = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_PROJ_SPLIT")) g_fmt_proj_split = atoi(v);
   if (const char* v = getenv("FLOAT_FMT_RB")) g_fmt_rb = atoi(v) != 0;
+  if (const char* v = getenv("FLOAT_FMT_RB_TOUCH")) g_fmt_rb_touch = atoi(v);
   h->attnproj = getenv("FLOAT_FMT_ATTNPROJ") ? atoi(getenv("FLOAT_FMT_ATTNPROJ")) : 0;
   h->mega_on = getenv("FLOAT_FMT_MEGA") ? atoi(getenv("FLOAT_FMT_MEGA")) : 0;
   {

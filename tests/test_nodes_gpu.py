@@ -136,11 +136,14 @@ def test_float_process_batch_runs_stacked_chains(pipe, monkeypatch):
         out, aud, _ = node.floatprocess(imgs, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
         torch.cuda.synchronize()
         return out, aud, time.perf_counter() - t0
+    def best_of(n):  # wall clocks of single calls on a box that has run other tests for minutes: take the best of a few
+        res = [run() for _ in range(n)]
+        return min(res, key=lambda r: r[2])
     run()
-    batched, aud_b, t_b = run()
+    batched, aud_b, t_b = best_of(3)
     monkeypatch.setenv("FLOAT_AMD_BATCH_CLIPS", "0")
     run()
-    looped, aud_l, t_l = run()
+    looped, aud_l, t_l = best_of(3)
     assert batched.shape == looped.shape == (100, 512, 512, 3) and torch.equal(aud_b["waveform"], aud_l["waveform"])
     for i in range(4):
         mse = float(((batched[i * 25:(i + 1) * 25] - looped[i * 25:(i + 1) * 25]) ** 2).mean())
