@@ -18,7 +18,8 @@
 // 43 % issue-stalled, 29 % parked - with the stores removed still 0.37-0.41 of the peak: the K loop, not what surrounds it, is
 // the limit.  A step costs the sum of its LDS-DMA issue (28 pieces of 1 KiB per k-block, ~100 clocks of issue each, all waves
 // behind the same barrier) and its MFMAs; spreading the pieces over the step (wave w in front of its MFMA chunk w, BIG_SPREAD)
-// made it 10 % SLOWER, 256-row tiles (MI = 8) spill.  What would move it is a structure whose two waves per SIMD sit in
+// made it 10 % SLOWER, 256-row tiles (MI = 8) spill; a 4-wave form (one wave per SIMD with the whole register file, 96 x 128 wave
+// tiles, accumulators in AGPRs) ran at 1 174 us against 1 092 on the same box before its results were right, and was dropped.  What would move it is a structure whose two waves per SIMD sit in
 // opposite phases (one multiplies while the other issues and reads): not built.
 #pragma once
 #include "fmt_rb_kernels.hpp"  // -I comfyui-float_optimized_amd/csrc
