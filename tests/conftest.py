@@ -19,7 +19,9 @@ def pytest_configure(config):
 
 def pytest_collection_modifyitems(config, items):
     import torch
-    has_gpu = torch.cuda.is_available()
+    # device_count() does not create a HIP context in this process (is_available() does): tests/test_00_ranks8_gpu.py needs the
+    # GPU's eight compute process slots for its eight ranks
+    has_gpu = torch.cuda.device_count() > 0
     skip_gpu = pytest.mark.skip(reason="no GPU visible")
     skip_ref = pytest.mark.skip(reason="/root/reference not present")
     has_ref = os.path.isdir("/root/reference/src/nodes")
