@@ -155,3 +155,27 @@ def test_encoder_fp32_feeds_decoder_fp32():
     enc16.encode_image_into_latent(img)
     with pytest.raises(ValueError, match="dtype"):
         enc16.hand_feats_to(dec)
+
+
+def test_exported_skip_maps_feed_the_decoder_like_the_direct_hand_over():
+    """float_enc_export_feats16 (ABI 6): the copies a batch of portraits keeps per item decode to the same frames, bit for bit, as
+    the direct hand-over of the last forward (float_enc_feats16 -> float_dec_set_feats16) - also after ANOTHER image went through
+    the encoder in between, which is what the copies are for (nodes.py:189-209: B items, one decode each)."""
+    size = 64
+    enc = pkg.encoder.EncoderHIP(W.synth_encoder_state(size, seed=3), size, 512, 20, "cuda:0", "fp16")
+    dec = pkg.decoder.SynthesisHIP(W.synth_decoder_state(size, seed=3), size, 512, "cuda:0", "fp16", max_frames=4)
+    g = torch.Generator().manual_seed(5)
+    img_a, img_b = torch.rand(1, 3, size, size, generator=g) * 2 - 1, torch.rand(1, 3, size, size, generator=g) * 2 - 1
+    r_d = torch.randn(1, 3, 512, generator=g) * 0.5
+    s_a, _, _, _ = enc.encode_image_into_latent(img_a, want_feats=False)
+    enc.hand_feats_to(dec)
+    direct = dec.decode_latent_into_processed_images(s_a, r_d[0]).clone()
+    kept = enc.export_feats16()
+    enc.encode_image_into_latent(img_b, want_feats=False)  # the encoder's own buffers now hold image b
+    enc.hand_feats_to(dec)
+    other = dec.decode_latent_into_processed_images(s_a, r_d[0]).clone()
+    dec.set_feats16(kept, enc.dtype)
+    again = dec.decode_latent_into_processed_images(s_a, r_d[0])
+    assert torch.equal(again, direct) and not torch.equal(other, direct)
+    with pytest.raises(ValueError):
+        pkg.native.check(pkg.native.lib().float_enc_export_feats16(enc._h, None, 3, None))
