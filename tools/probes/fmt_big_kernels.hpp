@@ -27,6 +27,24 @@
 #ifndef BIG_SPREAD
 #define BIG_SPREAD 1  // 1: a wave issues its LDS-DMA pieces in front of MFMA chunk `wave index` of the step; 0: all waves behind the barrier
 #endif
+#ifdef BIG_NO_MFMA  // timing-only build: the fetch, the fragment reads and the barriers alone
+#define BIG_MFMA(m, AC, BC) asm volatile("" ::"v"(AC[(m) / NJ]), "v"(BC[(m) % NJ]))
+#else
+#define BIG_MFMA(m, AC, BC) acc[(m) / NJ][(m) % NJ] = T::mfma(BC[(m) % NJ], AC[(m) / NJ], acc[(m) / NJ][(m) % NJ])
+#endif
+#ifndef BIG_INTERLEAVE
+#define BIG_INTERLEAVE 0  // > 0: one fragment read of the next stage in front of every BIG_INTERLEAVE-th MFMA
+#endif
+#ifdef BIG_NO_DMA   // timing-only: no LDS-DMA in the loop (the counted waits find nothing to wait for)
+#define BIG_ISSUE() do { } while (0)
+#else
+#define BIG_ISSUE() issue_next()
+#endif
+#ifdef BIG_NO_READS  // timing-only: no fragment reads in the loop
+#define BIG_READS(AN, BN_) do { } while (0)
+#else
+#define BIG_READS(AN, BN_) read_next(AN, BN_)
+#endif
 struct BigArgs {
   const u16* A;       // packed [row tiles][KB][64][8], rows dense, readable up to nrb row blocks
   const u16* W;       // packed [N/16][KB][64][8]
@@ -67,28 +85,40 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
   };
   const int Stot = ntl * KB;  // stages of this workgroup
 
-  // pieces of a stage issued by this wave: fragments f = w + 8 i (f < RT: row tile f of A, else column tile f - RT of W)
+  // ---- LEAN control (round 5, late): the first form of this loop recomputed (tile, k-block) from a global stage number in every
+  // step - integer divisions, 64-bit multiplies, a chain of run-time branches for the wait counts: 1 213 scalar instructions and
+  // 63 branches per step and wave, and with EVERYTHING else removed (no DMA, no reads, no MFMA, no stores) the kernel still took
+  // 607 of its ~1 100 us: a CU has ONE scalar unit for its 8 waves.  Here every per-step quantity is carried along: source
+  // pointers advance by 1 KiB, ring slots wrap by compare, the wait counts are immediates (the DMA never stops: behind the last
+  // real stage the last tile is issued again, so the counts hold to the end; every wave issues IMAX pieces, a duplicate where
+  // the stage has fewer), and the tile switch is one rarely taken branch.
   const u16* src[IMAX];
-  int cur_issue_tile = -1;
   auto set_tile_ptrs = [&](int j) {
     int rb, cb;
     tile_of(j, rb, cb);
 #pragma unroll
     for (int i = 0; i < IMAX; ++i) {
       const int f = min(w + 8 * i, NF - 1);
-      src[i] = f < RT ? g.A + (size_t)(rb * RT + f) * tstride : g.W + (size_t)(cb * CT + f - RT) * tstride;  // wave-uniform: scalar registers
+      src[i] = f < RT ? g.A + (size_t)(rb * RT + f) * tstride : g.W + (size_t)(cb * CT + f - RT) * tstride;  // wave-uniform
     }
-    cur_issue_tile = j;
   };
-  auto issue = [&](int gs) {
-    const int j = gs / KB, kb = gs - j * KB;
-    if (j != cur_issue_tile) set_tile_ptrs(j);
-    unsigned char* dst = lds + (gs % NS) * STAGE + w * 1024;
+  int ij = 0, ikb = 0;
+  unsigned ioff = (unsigned)(w * 1024);  // LDS byte offset of this wave's first piece in the slot being filled
+  set_tile_ptrs(0);
+  auto issue_next = [&]() {
 #pragma unroll
     for (int i = 0; i < IMAX; ++i)
-      if (i < ILO || w < NHI)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (size_t)kb * 512 + lane * 8),
-                                         (__attribute__((address_space(3))) void*)(dst + i * 8 * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + lane * 8),
+                                       (__attribute__((address_space(3))) void*)(lds + ioff + i * 8 * 1024), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < IMAX; ++i) src[i] += 512;
+    ioff += STAGE;
+    if (ioff >= (unsigned)(NS * STAGE)) ioff -= (unsigned)(NS * STAGE);
+    if (++ikb == KB) {
+      ikb = 0;
+      ij = min(ij + 1, ntl - 1);  // behind the last tile: the last tile again (never read)
+      set_tile_ptrs(ij);
+    }
   };
   // bias of this wave's 64 columns, 4 per lane (lane % 16), by a register load the compiler does not see (no wait of its own)
   auto load_bias = [&](int j) -> f32x4 {
@@ -103,47 +133,39 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
   const unsigned abase = (unsigned)(lane * 16 + (wr * MI) * 1024), bbase = (unsigned)(lane * 16 + (RT + wc * NJ) * 1024);
   f32x4 acc[MI][NJ];
   u32x4 a0[MI], b0[NJ], a1[MI], b1[NJ];
-  auto read_frags = [&](int gs, u32x4(&ar)[MI], u32x4(&br)[NJ]) {
-    const unsigned so = (unsigned)((gs % NS) * STAGE);
-    fh_static_for<0, MI>([&](auto i) { ar[i.value] = fh_ds_read128<i.value * 1024>(abase + so); });
-    fh_static_for<0, NJ>([&](auto j) { br[j.value] = fh_ds_read128<j.value * 1024>(bbase + so); });
+  unsigned roff = 0u;  // LDS byte offset of the slot to read next
+  auto read_next = [&](u32x4(&ar)[MI], u32x4(&br)[NJ]) {
+    fh_static_for<0, MI>([&](auto i) { ar[i.value] = fh_ds_read128<i.value * 1024>(abase + roff); });
+    fh_static_for<0, NJ>([&](auto j) { br[j.value] = fh_ds_read128<j.value * 1024>(bbase + roff); });
+    roff += STAGE;
+    if (roff >= (unsigned)(NS * STAGE)) roff -= (unsigned)(NS * STAGE);
   };
-  // wait until stage gs + 1 has landed: `extra` = 1 while the last epilogue's NST operations are younger than that stage
-#define BIG_WAIT(K, EXTRA)                                                  \
-  do {                                                                      \
-    if (NHI == 0 || w < NHI) {                                              \
-      if (EXTRA) fh_wait_vmcnt<(K)*IMAX + NST>();                           \
-      else fh_wait_vmcnt<(K)*IMAX>();                                       \
-    } else {                                                                \
-      if (EXTRA) fh_wait_vmcnt<(K)*ILO + NST>();                            \
-      else fh_wait_vmcnt<(K)*ILO>();                                        \
-    }                                                                       \
-  } while (0)
-#define BIG_WAIT_UPTO(K, EXTRA)                              \
-  do {                                                       \
-    const int k_ = (K);                                      \
-    if (NS == 4 && k_ >= 2) BIG_WAIT(2, EXTRA);              \
-    else if (k_ >= 1) BIG_WAIT(1, EXTRA);                    \
-    else BIG_WAIT(0, EXTRA);                                 \
-  } while (0)
-#define BIG_STEP(GS, SINCE, AC, BC, AN, BN_)                                                    \
+  // one step: stage s + 1 has landed (behind it: NS - 2 younger stages, and - EXTRA - the last epilogue's NST operations)
+#define BIG_STEP(EXTRA, AC, BC, AN, BN_)                                                        \
   do {                                                                                          \
-    const int s_ = (GS);                                                                        \
-    if (s_ + 1 < Stot) {                                                                        \
-      if ((SINCE) < NS - 1 && drained == 0) BIG_WAIT_UPTO(Stot - 2 - s_, true);                 \
-      else BIG_WAIT_UPTO(Stot - 2 - s_, false);                                                 \
-    }                                                                                           \
+    if (EXTRA) fh_wait_vmcnt<(NS - 2) * IMAX + NST>();                                          \
+    else fh_wait_vmcnt<(NS - 2) * IMAX>();                                                      \
     __builtin_amdgcn_s_barrier();                                                               \
-    if (BIG_SPREAD == 0 && s_ + NS < Stot) issue(s_ + NS);                                      \
-    if (s_ + 1 < Stot) read_frags(s_ + 1, AN, BN_);                                             \
-    __builtin_amdgcn_sched_barrier(0);                                                          \
-    _Pragma("unroll") for (int c = 0; c < 8; ++c) {                                             \
-      /* wave w issues its pieces of stage s + NS in front of its chunk w: the CU's 28 pieces of a stage enter the address  */ \
-      /* path spread over the step instead of as one burst behind the barrier                                              */ \
-      if (BIG_SPREAD != 0 && c == w && s_ + NS < Stot) issue(s_ + NS);                          \
-      _Pragma("unroll") for (int m = c * (MI * NJ / 8); m < (c + 1) * (MI * NJ / 8); ++m)       \
-        acc[m / NJ][m % NJ] = T::mfma(BC[m % NJ], AC[m / NJ], acc[m / NJ][m % NJ]);             \
-      if (BIG_SPREAD != 0) __builtin_amdgcn_sched_barrier(0);                                   \
+    BIG_ISSUE();                                                                                \
+    if (BIG_INTERLEAVE == 0) {                                                                  \
+      BIG_READS(AN, BN_);                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                        \
+      _Pragma("unroll") for (int m = 0; m < MI * NJ; ++m) BIG_MFMA(m, AC, BC);                  \
+    } else {                                                                                    \
+      /* the MI + NJ fragment reads of stage s + 1 one by one between the MFMAs of stage s (every BIG_INTERLEAVE MFMAs):   */ \
+      /* 8 waves that all read first fill the LDS queue, and the last of them reaches its MFMAs hundreds of clocks late    */ \
+      fh_static_for<0, MI * NJ>([&](auto m) {                                                   \
+        constexpr int il_ = BIG_INTERLEAVE > 0 ? BIG_INTERLEAVE : 1, r_ = m.value / il_;                                            \
+        if constexpr (m.value % il_ == 0 && r_ < MI + NJ) {                          \
+          if constexpr (r_ < NJ) BN_[r_] = fh_ds_read128<r_ * 1024>(bbase + roff);              \
+          else AN[r_ - NJ] = fh_ds_read128<(r_ - NJ) * 1024>(abase + roff);                     \
+          __builtin_amdgcn_sched_barrier(0);                                                    \
+        }                                                                                       \
+        BIG_MFMA(m.value, AC, BC);                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                      \
+      });                                                                                       \
+      roff += STAGE;                                                                            \
+      if (roff >= (unsigned)(NS * STAGE)) roff -= (unsigned)(NS * STAGE);                       \
     }                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                          \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                          \
@@ -153,27 +175,29 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
   f32x4 bias_cur = load_bias(0);  // older than every DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int s = 0; s < NS; ++s)
-    if (s < Stot) issue(s);
-  if (Stot >= NS) BIG_WAIT(NS - 1, false);
-  else fh_wait_vmcnt<0>();
+  for (int s = 0; s < NS; ++s) issue_next();
+  fh_wait_vmcnt<(NS - 1) * IMAX>();
   __builtin_amdgcn_s_barrier();
-  read_frags(0, a0, b0);
+  read_next(a0, b0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 
-  unsigned char* const stg = lds + NS * STAGE + w * 4096;  // this wave's private slab: [16 rows][16 granules of 16 B], granule ^ row
-  const unsigned stg_lds = (unsigned)(NS * STAGE + w * 4096);
-  int drained = 1;  // 1: nothing of an epilogue is outstanding (first tile, or an epilogue that ended with vmcnt(0))
+  const unsigned stg_lds = (unsigned)(NS * STAGE + w * 4096);  // this wave's private slab: [16 rows][16 granules of 16 B], granule ^ row
+  bool extra = false;  // the previous tile's epilogue left NST operations in the counter
   for (int j = 0; j < ntl; ++j) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) acc[i][jj] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int gs0 = j * KB;
-    for (int kb = 0; kb < KB; kb += 2) {
-      BIG_STEP(gs0 + kb, kb, a0, b0, a1, b1);
-      BIG_STEP(gs0 + kb + 1, kb + 1, a1, b1, a0, b0);
+    // the first NS - 1 steps behind an epilogue count its operations as younger than the stage they wait for
+    static_assert(NS == 4, "the peeled steps below are written for a ring of 4");
+    BIG_STEP(extra, a0, b0, a1, b1);
+    BIG_STEP(extra, a1, b1, a0, b0);
+    BIG_STEP(extra, a0, b0, a1, b1);
+    BIG_STEP(false, a1, b1, a0, b0);
+    for (int kb = 4; kb < KB; kb += 2) {
+      BIG_STEP(false, a0, b0, a1, b1);
+      BIG_STEP(false, a1, b1, a0, b0);
     }
     // ---- epilogue of tile j from the accumulators; the ring keeps filling with tile j + 1 meanwhile
     int rb, cb;
@@ -229,15 +253,13 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
       }
     }
     bias_cur = bias_next;
-    if (!whole) {  // fewer than 32 stores may have been issued: start the count afresh
+    if (!whole) {  // fewer stores than NST may have been issued: start the count afresh (the prefetched stages land too)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      drained = 1;
+      extra = false;
     } else {
-      drained = 0;
+      extra = true;
     }
-    (void)stg;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-issued stages behind the last tile: no LDS-DMA may outlive the workgroup
 #undef BIG_STEP
-#undef BIG_WAIT_UPTO
-#undef BIG_WAIT
 }

@@ -11,6 +11,9 @@
 #include <random>
 #include <vector>
 
+#ifndef BIG_NS
+#define BIG_NS 4
+#endif
 #ifndef BIG_MI
 #define BIG_MI 6
 #endif
@@ -52,7 +55,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dout, 0xff, out_rows * N * 4));
   BigArgs g{dA, dW, db, dout, M, N, K, N, nrb, N / 256};
-  constexpr int NS = 4, smem = NS * (2 * MI + 16) * 1024 + 8 * 4096;
+  constexpr int NS = BIG_NS, smem = NS * (2 * MI + 16) * 1024 + 8 * 4096;
   auto kern = fmt_gemm_big_kernel<FP16, MI, NS>;
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   int ncu = 0;
