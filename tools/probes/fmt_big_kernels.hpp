@@ -35,10 +35,25 @@
 #ifndef BIG_INTERLEAVE
 #define BIG_INTERLEAVE 0  // > 0: one fragment read of the next stage in front of every BIG_INTERLEAVE-th MFMA
 #endif
+#ifndef BIG_DMA_EVERY
+#define BIG_DMA_EVERY 0  // > 0 (with BIG_INTERLEAVE > 0): LDS-DMA piece d of the step in front of MFMA 1 + d * BIG_DMA_EVERY instead of all behind the barrier
+#endif
+#ifndef BIG_PHASE
+#define BIG_PHASE 0
+#endif
+#define BIG_ISSUE_ALWAYS()                                          \
+  do {                                                              \
+    _Pragma("unroll") for (int i_ = 0; i_ < NP; ++i_) issue_piece(i_); \
+    issue_advance();                                                \
+  } while (0)
 #ifdef BIG_NO_DMA   // timing-only: no LDS-DMA in the loop (the counted waits find nothing to wait for)
 #define BIG_ISSUE() do { } while (0)
+#define BIG_ISSUE_PIECE(d) do { } while (0)
+#define BIG_ISSUE_ADVANCE() do { } while (0)
 #else
-#define BIG_ISSUE() issue_next()
+#define BIG_ISSUE() BIG_ISSUE_ALWAYS()
+#define BIG_ISSUE_PIECE(d) issue_piece(d)
+#define BIG_ISSUE_ADVANCE() issue_advance()
 #endif
 #ifdef BIG_NO_READS  // timing-only: no fragment reads in the loop
 #define BIG_READS(AN, BN_) do { } while (0)
@@ -105,11 +120,13 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
   int ij = 0, ikb = 0;
   unsigned ioff = (unsigned)(w * 1024);  // LDS byte offset of this wave's first piece in the slot being filled
   set_tile_ptrs(0);
-  auto issue_next = [&]() {
-#pragma unroll
-    for (int i = 0; i < IMAX; ++i)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + lane * 8),
-                                       (__attribute__((address_space(3))) void*)(lds + ioff + i * 8 * 1024), 16, 0, 0);
+  // this wave's pieces of a stage: NP = IMAX for waves < NHI, ILO for the others (BIG_EXACT; otherwise every wave issues IMAX and
+  // the surplus ones fetch the stage's last fragment again: 32 pieces for 28 fragments, 14 % more than the CU has to take in)
+  auto issue_piece = [&](int i) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + lane * 8),
+                                     (__attribute__((address_space(3))) void*)(lds + ioff + i * 8 * 1024), 16, 0, 0);
+  };
+  auto issue_advance = [&]() {
 #pragma unroll
     for (int i = 0; i < IMAX; ++i) src[i] += 512;
     ioff += STAGE;
@@ -140,13 +157,15 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
     roff += STAGE;
     if (roff >= (unsigned)(NS * STAGE)) roff -= (unsigned)(NS * STAGE);
   };
+  auto run = [&](auto np_c) {
+  constexpr int NP = decltype(np_c)::value;
   // one step: stage s + 1 has landed (behind it: NS - 2 younger stages, and - EXTRA - the last epilogue's NST operations)
 #define BIG_STEP(EXTRA, AC, BC, AN, BN_)                                                        \
   do {                                                                                          \
-    if (EXTRA) fh_wait_vmcnt<(NS - 2) * IMAX + NST>();                                          \
-    else fh_wait_vmcnt<(NS - 2) * IMAX>();                                                      \
+    if (EXTRA) fh_wait_vmcnt<(NS - 2) * NP + NST>();                                          \
+    else fh_wait_vmcnt<(NS - 2) * NP>();                                                      \
     __builtin_amdgcn_s_barrier();                                                               \
-    BIG_ISSUE();                                                                                \
+    if (BIG_INTERLEAVE == 0 || BIG_DMA_EVERY == 0) BIG_ISSUE();                                 \
     if (BIG_INTERLEAVE == 0) {                                                                  \
       BIG_READS(AN, BN_);                                                                       \
       __builtin_amdgcn_sched_barrier(0);                                                        \
@@ -161,9 +180,21 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
           else AN[r_ - NJ] = fh_ds_read128<(r_ - NJ) * 1024>(abase + roff);                     \
           __builtin_amdgcn_sched_barrier(0);                                                    \
         }                                                                                       \
+        if constexpr (BIG_DMA_EVERY > 0) {                                                      \
+          /* LDS-DMA piece d in front of MFMA 1 + d * BIG_DMA_EVERY: a piece's issue blocks its wave while the CU's intake   */ \
+          /* queue is full (~27 clocks per KiB), and pieces issued first put that in front of EVERY wave's MFMAs             */ \
+          /* BIG_PHASE: the two waves of a SIMD (w and w + 4: NP = IMAX and ILO with BIG_EXACT) issue in opposite halves     */ \
+          constexpr int de_ = BIG_DMA_EVERY > 0 ? BIG_DMA_EVERY : 1;                            \
+          constexpr int m0_ = (BIG_PHASE && NP != IMAX) ? MI * NJ / 2 + 1 : 1, d_ = (m.value - m0_) / de_; \
+          if constexpr (m.value >= m0_ && (m.value - m0_) % de_ == 0 && d_ < NP) {              \
+            BIG_ISSUE_PIECE(d_);                                                                \
+            __builtin_amdgcn_sched_barrier(0);                                                  \
+          }                                                                                     \
+        }                                                                                       \
         BIG_MFMA(m.value, AC, BC);                                                              \
         __builtin_amdgcn_sched_barrier(0);                                                      \
       });                                                                                       \
+      if (BIG_DMA_EVERY > 0) BIG_ISSUE_ADVANCE();                                               \
       roff += STAGE;                                                                            \
       if (roff >= (unsigned)(NS * STAGE)) roff -= (unsigned)(NS * STAGE);                       \
     }                                                                                           \
@@ -175,8 +206,8 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
   f32x4 bias_cur = load_bias(0);  // older than every DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int s = 0; s < NS; ++s) issue_next();
-  fh_wait_vmcnt<(NS - 1) * IMAX>();
+  for (int s = 0; s < NS; ++s) BIG_ISSUE_ALWAYS();
+  fh_wait_vmcnt<(NS - 1) * NP>();
   __builtin_amdgcn_s_barrier();
   read_next(a0, b0);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -261,5 +292,12 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-issued stages behind the last tile: no LDS-DMA may outlive the workgroup
+  };
+#ifdef BIG_EXACT
+  if (NHI == 0 || w < NHI) run(std::integral_constant<int, IMAX>{});
+  else run(std::integral_constant<int, ILO>{});
+#else
+  run(std::integral_constant<int, IMAX>{});
+#endif
 #undef BIG_STEP
 }

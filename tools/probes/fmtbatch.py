@@ -19,7 +19,7 @@ for B in [int(b) for b in os.environ.get("BATCHES", "1,2,4,8").split(",")]:
         r_d = fmt.sample(r_s, wa, we, noise, 51, 2.0, 1.0, 1.0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 3
+    n = int(os.environ.get("REPS", "3"))
     for _ in range(n):
         r_d = fmt.sample(r_s, wa, we, noise, 51, 2.0, 1.0, 1.0)
     torch.cuda.synchronize()

@@ -96,6 +96,17 @@ int main(int argc, char** argv) {
     const double us = ms * 1e3 / 5;
     printf("fmt_gemm_big_kernel  M=%d: %8.1f us  %7.1f TFLOP/s (%.3f of 2.5 PFLOP/s)\n", M, us, 2.0 * M * N * K / us * 1e-6, 2.0 * M * N * K / us * 1e-6 / 2500);
   }
+  if (const char* e = getenv("BIG_LOOP")) {  // keep the chip busy for a clock / power sample from outside (rocm-smi)
+    const int n = atoi(e);
+    CK(hipEventRecord(e0, nullptr));
+    for (int i = 0; i < n; ++i) launch();
+    CK(hipEventRecord(e1, nullptr));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("loop of %d launches: %8.1f us per launch\n", n, ms * 1e3 / n);
+    return 0;
+  }
   // the 192 x 320 one-tile-per-workgroup kernel on the padded layout (steps x 192 rows)
   {
     const int Mpad = 192;
@@ -113,6 +124,17 @@ int main(int argc, char** argv) {
     constexpr int smem2 = 4 * 32 * 1024;
     auto k2 = fmt_gemm_dma_kernel<FP16, 4, 4, 1>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, smem2));
+    if (const char* e = getenv("DMA_LOOP")) {  // the library kernel under the same outside sample
+      const int n = atoi(e);
+      CK(hipEventRecord(e0, nullptr));
+      for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k2, dim3((N / 320) * steps), dim3(512), smem2, nullptr, ga);
+      CK(hipEventRecord(e1, nullptr));
+      CK(hipEventSynchronize(e1));
+      float ms = 0.f;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      printf("loop of %d launches of fmt_gemm_dma_kernel: %8.1f us per launch\n", n, ms * 1e3 / n);
+      return 0;
+    }
     if (rows <= 192) {
       for (int rep = 0; rep < 2; ++rep) {
         CK(hipEventRecord(e0, nullptr));
