@@ -25,6 +25,7 @@ struct Level {  // ToFlow + ToRGB of one resolution
   float* lin = nullptr;  // [R] np.linspace(-1, 1, R) as float32
   int style_off = 0;
   void* feat = nullptr;  // [R][R][C] T::elem
+  float upk_flow[8], upk_rgb[8];  // per-axis taps of the two Upsamples (upsample_taps)
 };
 
 int ilog2(int v) {
@@ -195,17 +196,41 @@ int blur_taps(const TensorTable& tt, const std::string& buffer_key, float fir[4]
 }
 
 // The Upsample of ToRGB / ToFlow (styledecoder.py:373,394) is built with its default [1,3,3,1] whatever the loader's widget says
-// (:489-491) and dec_flow_kernel has that FIR in its code: a checkpoint whose `upsample.kernel` buffer differs is refused.
-int check_default_upsample(const TensorTable& tt, const std::string& key) {
+// (:489-491): make_kernel(k) * 4 as a registered 4 x 4 BUFFER `upsample.kernel`, which the strict load (nodes_vadv_loader.py:632)
+// overwrites with the checkpoint's.  dec_flow_kernel applies it per axis: the buffer must be a rank-1 4 x 4 matrix K = ky (x) kx
+// (every make_kernel of a 1-D kernel is; a x b with different factors passes too); taps = {ky[4], kx[4]}.  No buffer in the
+// state: (1, 3, 3, 1) / 4 per axis.  Another size (the Upsample's padding belongs to 4 taps) or a rank > 1 kernel is refused.
+int upsample_taps(const TensorTable& tt, const std::string& key, float taps[8]) {
+  static const float dflt[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+  for (int i = 0; i < 8; ++i) taps[i] = dflt[i & 3];
   const float_tensor_t* kb = tt.find(key);
   if (!kb) return FLOAT_OK;
-  const float k1[4] = {1.f, 3.f, 3.f, 1.f};
-  bool ok = TensorTable::numel(kb) == 16;
-  for (int i = 0; ok && i < 4; ++i)
-    for (int j = 0; j < 4; ++j) ok = ok && fabsf(kb->data[i * 4 + j] - k1[i] * k1[j] / 16.f) <= 1e-6f;
-  if (!ok) {
-    fh_set_error("'%s' is not the [1,3,3,1] up-sampling kernel; other ToRGB / ToFlow up-sampling kernels are not implemented", key.c_str());
+  if (TensorTable::numel(kb) != 16 || kb->ndim != 2 || kb->shape[0] != 4) {
+    fh_set_error("'%s' is not a 4 x 4 kernel; ToRGB / ToFlow up-sampling kernels of other sizes are not implemented", key.c_str());
     return FLOAT_E_INVALID;
+  }
+  double r[4] = {0, 0, 0, 0}, c[4] = {0, 0, 0, 0}, S = 0, amax = 0;
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j) {
+      const double v = kb->data[i * 4 + j];
+      r[i] += v, c[j] += v, S += v;
+      amax = std::max(amax, fabs(v));
+    }
+  if (!(S > 1e-12)) {
+    fh_set_error("'%s' does not have a positive sum", key.c_str());
+    return FLOAT_E_INVALID;
+  }
+  // K_ij = u_i v_j  =>  row sums u_i sum(v), column sums v_j sum(u), S = sum(u) sum(v): K_ij = r_i c_j / S
+  const double rs = sqrt(S);
+  for (int i = 0; i < 4; ++i)
+    for (int j = 0; j < 4; ++j)
+      if (fabs(kb->data[i * 4 + j] - r[i] * c[j] / S) > 1e-5 * amax) {
+        fh_set_error("'%s' is not a rank-1 kernel ky (x) kx (make_kernel's form); other up-sampling kernels are not implemented", key.c_str());
+        return FLOAT_E_INVALID;
+      }
+  for (int i = 0; i < 4; ++i) {
+    taps[i] = (float)(r[i] / rs);
+    taps[4 + i] = (float)(c[i] / rs);
   }
   return FLOAT_OK;
 }
@@ -339,7 +364,7 @@ int create_impl(float_dec* h, const TensorTable& tt) {
     const float_tensor_t* rb1 = need(tt, pr + ".conv.1.bias", 3);
     const float_tensor_t* rb2 = need(tt, pr + ".bias", 3);
     if (!fw || !fmw || !fmb || !fb || !rw || !rb1 || !rb2) return FLOAT_E_MISSING;
-    if ((rc = check_default_upsample(tt, pf + ".upsample.kernel")) || (rc = check_default_upsample(tt, pr + ".upsample.kernel"))) return rc;
+    if ((rc = upsample_taps(tt, pf + ".upsample.kernel", L.upk_flow)) || (rc = upsample_taps(tt, pr + ".upsample.kernel", L.upk_rgb))) return rc;
     const float sc = 1.0f / sqrtf((float)L.C);  // 1x1: fan_in = C (styledecoder.py:134,223)
     std::vector<float> a(3 * L.C), b(3 * L.C);
     for (int i = 0; i < 3 * L.C; ++i) {
@@ -741,6 +766,8 @@ int run_level(float_dec* h, int li, int n, const void* x_in, void* Zb, void* U, 
   g.feat = L.feat;
   g.pflow = flow_prev;
   g.prgb = rgb_prev;
+  memcpy(g.upk_flow, L.upk_flow, sizeof(g.upk_flow));
+  memcpy(g.upk_rgb, L.upk_rgb, sizeof(g.upk_rgb));
   g.wflow = L.wflow;
   g.sflow = styles + L.style_off;
   g.bflow = L.bflow;
@@ -1105,6 +1132,7 @@ int unit_flow_level(const float_dec_unit_t* cfg, const TensorTable& tt, const fl
   g.feat = Ft;
   g.pflow = pf;
   g.prgb = pr;
+  if ((rc = upsample_taps(tt, "to_flow.upsample.kernel", g.upk_flow)) || (rc = upsample_taps(tt, "to_rgb.upsample.kernel", g.upk_rgb))) return rc;
   g.wflow = wflow;
   g.sflow = styles;
   g.bflow = bflow;

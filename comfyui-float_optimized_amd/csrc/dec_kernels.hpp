@@ -342,6 +342,7 @@ struct FlowArgs {
   const void* x;       // [F][R][R][C] conv2 output (unscaled), T::elem
   const void* feat;    // [R][R][C], T::elem
   const float* pflow;  // [F][R/2][R/2][4] (3 channels + pad: one 16-byte load per tap) or nullptr
+  float upk_flow[8], upk_rgb[8];  // per-axis taps {ky[4], kx[4]} of ToFlow's / ToRGB's Upsample (K = ky (x) kx; (1,3,3,1)/4 each by default)
   const float* prgb;   // [F][R/2][R/2][4] or nullptr
   const float* wflow;  // [3][C], already * 1/sqrt(C)
   const float* sflow;  // [F][ld_s] style of the ToFlow conv (offset applied)
@@ -363,14 +364,17 @@ struct FlowArgs {
   unsigned long long* sat;  // saturation counter of this level's xnext stores
 };
 
-__device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, int Rp, int Y, int X, float out[3]) {
-  // Upsample([1,3,3,1]) of a 3-channel map (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR
-  // gain 4 -> per axis: even 2m: .25*p[m-1] + .75*p[m];  odd 2m+1: .75*p[m] + .25*p[m+1].
+__device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, int Rp, int Y, int X, float out[3], const float (&k)[8]) {
+  // Upsample of a 3-channel map (styledecoder.py:74-90): zero-insert x2, pad (2,1), correlate with the flipped 4 x 4 kernel K =
+  // ky (x) kx (k = {ky[4], kx[4]}: make_kernel([1,3,3,1]) * 4 -> (1, 3, 3, 1) / 4 per axis unless the checkpoint's `upsample.kernel`
+  // buffer says otherwise).  Output 2m takes p[m-1], p[m] with weights k[3], k[1]; output 2m+1 takes p[m], p[m+1] with k[2], k[0]
+  // (default: .25, .75 / .75, .25 - the products below are then exact and equal to the literal-tap code this replaces).
   // The map is stored with 4 floats per pixel, so a tap is ONE 16-byte load for all three channels (the 4-byte-per-lane
   // version issued 32 scattered load instructions per 4 pixels and cost 5 of the decoder's 34 ms).
   const int my = Y >> 1, mx = X >> 1;
   const int y0 = (Y & 1) ? my : my - 1, x0 = (X & 1) ? mx : mx - 1;
-  const float wy0 = (Y & 1) ? 0.75f : 0.25f, wx0 = (X & 1) ? 0.75f : 0.25f;
+  const float wy[2] = {(Y & 1) ? k[2] : k[3], (Y & 1) ? k[0] : k[1]};
+  const float wx[2] = {(X & 1) ? k[6] : k[7], (X & 1) ? k[4] : k[5]};
   // every tap is loaded from a clamped (valid) address and an outside tap gets weight 0: no branch per tap (a divergent
   // branch around each load cost an exec save / restore and kept the loads from being issued back to back)
   float4 t[4];
@@ -390,7 +394,7 @@ __device__ __forceinline__ void up2_tap3(const float* __restrict__ prev, int f, 
   for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const float wgt = (a ? 1.f - wy0 : wy0) * (b ? 1.f - wx0 : wx0) * tw[a * 2 + b];
+      const float wgt = wy[a] * wx[b] * tw[a * 2 + b];
       out[0] += wgt * t[a * 2 + b].x;
       out[1] += wgt * t[a * 2 + b].y;
       out[2] += wgt * t[a * 2 + b].z;
@@ -460,7 +464,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
   {
     const int Y = p0 / R, X0 = p0 - Y * R;  // R % PIX == 0: the PIX pixels share a row
     float upf[3] = {0.f, 0.f, 0.f};  // up-sampled previous flow of THIS lane's pixel
-    if (ff.pflow && owner) up2_tap3(ff.pflow, 0, Rp, Y, X0 + sub, upf);
+    if (ff.pflow && owner) up2_tap3(ff.pflow, 0, Rp, Y, X0 + sub, upf, g.upk_flow);
     const float gy = g.lin[Y];
     float o[PIX][3];
 #pragma unroll
@@ -547,7 +551,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
         for (int t = 0; t < 4; ++t) fu[k][t] = dec_load8_b<T>(g.feat, fo[k][t] + cb0);
     }
     float upr[3] = {0.f, 0.f, 0.f};
-    if (ff.prgb && owner) up2_tap3(ff.prgb, 0, Rp, Y, X0 + sub, upr);
+    if (ff.prgb && owner) up2_tap3(ff.prgb, 0, Rp, Y, X0 + sub, upr, g.upk_rgb);
     float rgb[PIX][3];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {

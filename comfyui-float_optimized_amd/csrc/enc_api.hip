@@ -17,6 +17,7 @@ struct EConv {
 struct ResBlk {
   EConv conv1, conv2, skip;
   int R = 0;  // input resolution
+  EncFir fir2, firs;  // the Blur in front of conv2 / of the skip conv, flipped (enc_blur_taps)
 };
 
 struct FcLayer {
@@ -125,26 +126,29 @@ void householder_q(const std::vector<double>& A_in, int m, int n, std::vector<do
   }
 }
 
+// The Blur of a down-sampling ConvLayer is a registered 4 x 4 buffer (encoder.py:59-75: make_kernel([1,3,3,1]) = outer / 64) that
+// the reference's strict load takes from the checkpoint; upfirdn2d correlates with it FLIPPED (encoder.py:28-29).  Any 4 x 4 values
+// are applied as they are; no buffer in the state: the default.  Another size is refused (the layer's padding belongs to 4 taps).
+int enc_blur_taps(const TensorTable& tt, const std::string& key, EncFir* f) {
+  static const float k1[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) f->k[a * 4 + b] = k1[a] * k1[b];
+  const float_tensor_t* kb = tt.find(key);
+  if (!kb) return FLOAT_OK;
+  if (TensorTable::numel(kb) != 16 || kb->ndim != 2 || kb->shape[0] != 4) {
+    fh_set_error("'%s' is not a 4 x 4 kernel; encoder blur kernels of other sizes are not implemented", key.c_str());
+    return FLOAT_E_INVALID;
+  }
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) f->k[a * 4 + b] = kb->data[(3 - a) * 4 + (3 - b)];
+  return FLOAT_OK;
+}
+
 template <class T>
 int create_impl(float_enc* h, const TensorTable& tt) {
   const float_enc_cfg_t& c = h->cfg;
   int rc;
   const std::string p = "net_app.convs.";
-  // The Blur of every down-sampling ConvLayer is a registered buffer (encoder.py:59-75) that the reference's strict load takes
-  // from the checkpoint; enc_blur_kernel has make_kernel([1,3,3,1]) in its code, so a checkpoint that holds anything else is
-  // refused instead of being filtered with the wrong FIR.
-  for (const auto& kv : tt.m) {
-    const std::string& k = kv.first;
-    if (k.size() < 7 || k.compare(k.size() - 7, 7, ".kernel") != 0 || k.compare(0, p.size(), p) != 0) continue;
-    const float k1[4] = {1.f, 3.f, 3.f, 1.f};
-    bool ok = TensorTable::numel(kv.second) == 16;
-    for (int i = 0; ok && i < 4; ++i)
-      for (int j = 0; j < 4; ++j) ok = ok && fabsf(kv.second->data[i * 4 + j] - k1[i] * k1[j] / 64.f) <= 1e-6f;
-    if (!ok) {
-      fh_set_error("'%s' is not the [1,3,3,1] blur kernel; other encoder blur kernels are not implemented", k.c_str());
-      return FLOAT_E_INVALID;
-    }
-  }
   {  // convs.0: (C0, 3, 1, 1) + FusedLeakyReLU bias (1, C0, 1, 1)
     const float_tensor_t* w = tt.find(p + "0.0.weight");
     const float_tensor_t* b = tt.find(p + "0.1.bias");
@@ -173,6 +177,7 @@ int create_impl(float_enc* h, const TensorTable& tt) {
     if ((rc = pack_conv<T>(h, tt, q + "conv1.0.weight", q + "conv1.1.bias", &B.conv1))) return rc;
     if ((rc = pack_conv<T>(h, tt, q + "conv2.1.weight", q + "conv2.2.bias", &B.conv2))) return rc;
     if ((rc = pack_conv<T>(h, tt, q + "skip.1.weight", "", &B.skip))) return rc;
+    if ((rc = enc_blur_taps(tt, q + "conv2.0.kernel", &B.fir2)) || (rc = enc_blur_taps(tt, q + "skip.0.kernel", &B.firs))) return rc;
     FH_REQUIRE(B.conv1.cin == C && B.conv1.cout == C && B.conv1.k == 3 && B.conv2.cin == C && B.conv2.k == 3 &&
                    B.skip.cin == C && B.skip.k == 1 && B.skip.cout == B.conv2.cout,
                "ResBlock %d has unexpected shapes", i);
@@ -333,7 +338,7 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
     // skip: Blur pad (1,1) -> 1x1 stride 2, no bias / activation (encoder.py:191)
     {
       const size_t tot = (size_t)(R - 1) * (R - 1) * (C / 8);
-      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, reinterpret_cast<E*>(h->tb), R, C, 1, h->sat);
+      hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, x, reinterpret_cast<E*>(h->tb), R, C, 1, B.firs, h->sat);
     }
     if ((rc = launch_conv<T>(B.skip, h->tb, R - 1, R - 1, 2, 0, h->tsk, nullptr, nullptr, st, h->sat))) return rc;
     // conv1 3x3 + act; conv2: Blur pad (2,2) -> 3x3 stride 2 + act; (out + skip) / sqrt(2)
@@ -344,7 +349,7 @@ int forward_impl(float_enc* h, const float* img, float* s_r, float* lam, float* 
     {
       const size_t tot = (size_t)(R + 1) * (R + 1) * (C / 8);
       hipLaunchKernelGGL((enc_blur_kernel<T>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const E*>(h->t1),
-                         reinterpret_cast<E*>(h->tb), R, C, 2, h->sat);
+                         reinterpret_cast<E*>(h->tb), R, C, 2, B.fir2, h->sat);
     }
     if ((rc = launch_conv<T>(B.conv2, h->tb, R + 1, R + 1, 2, 0, h->res[b + 1], feat_out(b + 1), h->tsk, st, h->sat))) return rc;
   }

@@ -33,18 +33,22 @@ __global__ __launch_bounds__(256) void enc_first_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------
-// Blur([1,3,3,1], pad=(p,p)) of a down-sampling ConvLayer (encoder.py:59-75, 160-166): zero-pad by p,
-// correlate with the separable 4x4 FIR / 64; output (R + 2p - 3)^2.  One thread = one pixel x 8 channels.
+// Blur(kernel, pad=(p,p)) of a down-sampling ConvLayer (encoder.py:59-75, 160-166): zero-pad by p, correlate with the FLIPPED
+// 4 x 4 FIR (upfirdn2d, encoder.py:28-29); output (R + 2p - 3)^2.  One thread = one pixel x 8 channels.
+// EncFir: k[a][b] = weight of in[Y + a - pad][X + b - pad] = the layer's `kernel` buffer flipped in both axes
+// (make_kernel([1,3,3,1]) = (1,3,3,1) (x) (1,3,3,1) / 64 for every released checkpoint; exact in fp32 either way).
+struct EncFir {
+  float k[16];
+};
 template <class T>
 __global__ __launch_bounds__(256) void enc_blur_kernel(const typename T::elem* __restrict__ in, typename T::elem* __restrict__ out,
-                                                       int R, int C, int pad, unsigned long long* sat) {
+                                                       int R, int C, int pad, EncFir fir, unsigned long long* sat) {
   const int Ro = R + 2 * pad - 3, c8 = C >> 3;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)Ro * Ro * c8) return;
   const int cg = (int)(idx % c8);
   const size_t p = idx / c8;
   const int X = (int)(p % Ro), Y = (int)(p / Ro);
-  const float k1[4] = {0.125f, 0.375f, 0.375f, 0.125f};
   float acc[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) acc[i] = 0.f;
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void enc_blur_kernel(const typename T::elem* _
       const int ix = X + b - pad;
       if (ix < 0 || ix >= R) continue;
       const typename T::pack8 u = T::load8(in + ((size_t)iy * R + ix) * C + cg * 8);
-      const float kk = k1[a] * k1[b];
+      const float kk = fir.k[a * 4 + b];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc[i] += kk * T::get(u, i);
     }

@@ -224,6 +224,33 @@ def synth_encoder_state(size=512, dim=512, dim_motion=20, seed=0):
     return sd
 
 
+def fir_buffer_states(size=64, seed=0):
+    """(encoder state, decoder state) of synth_*_state(size, seed) whose FIR BUFFERS outside the up-sampling StyledConvs are not
+    make_kernel([1,3,3,1]) - what a checkpoint may hold and the reference's strict load takes over (tests/golden/fir_buffers.npz):
+    encoder `conv2.0.kernel` = make_kernel([1,2,4,1]) (asymmetric: pins upfirdn2d's flip), `skip.0.kernel` = a seeded non-separable
+    positive 4 x 4 kernel of sum 1; decoder `to_rgbs.N.upsample.kernel` = make_kernel([1,2,4,1]) * 4, `to_flows.N.upsample.kernel` =
+    4 * outer([1,3,3,1], [1,2,4,1]) / 64 (rank 1 with different factors per axis)."""
+    def mk(a, b, gain):
+        k = torch.tensor(a, dtype=torch.float32)[:, None] * torch.tensor(b, dtype=torch.float32)[None, :]
+        return k / k.sum() * gain
+    esd = synth_encoder_state(size, seed=seed)
+    nsk = 0
+    for k in sorted(esd):
+        if k.endswith("conv2.0.kernel"):
+            esd[k] = mk([1, 2, 4, 1], [1, 2, 4, 1], 1.0)
+        elif k.endswith("skip.0.kernel"):
+            r = torch.from_numpy(np.random.RandomState(seed + 50 + nsk).rand(4, 4).astype(np.float32)) + 0.1
+            esd[k] = r / r.sum()
+            nsk += 1
+    dsd = synth_decoder_state(size, seed=seed)
+    for k in sorted(dsd):
+        if k.startswith("to_rgbs.") and k.endswith("upsample.kernel"):
+            dsd[k] = mk([1, 2, 4, 1], [1, 2, 4, 1], 4.0)
+        elif k.startswith("to_flows.") and k.endswith("upsample.kernel"):
+            dsd[k] = mk([1, 3, 3, 1], [1, 2, 4, 1], 4.0)
+    return esd, dsd
+
+
 def scale_encoder_convs(sd, gain):
     """Every conv weight (4-D `*.weight`) of an encoder state times `gain`: the range-stress fixtures (tools/make_goldens.py,
     tests/test_enc_gpu.py) - activations grow by `gain` per conv layer."""

@@ -187,8 +187,10 @@ typedef struct float_dec float_dec_t;
  * Blur FIR of the up-sampling StyledConvs (styledecoder.py:209-213): the checkpoint's `convs.N.conv.blur.kernel` buffer where
  * present (what the reference ends up with after its strict load_state_dict, nodes_vadv_loader.py:632), else the optional
  * 1-D tensor `blur_kernel` (the loader's widget: Synthesis(blur_kernel=...), styledecoder.py:448), else [1,3,3,1].  4-tap
- * kernels only, a buffer must be make_kernel's outer product k (x) k; ToRGB / ToFlow `upsample.kernel` buffers other than
- * [1,3,3,1] are refused (FLOAT_E_INVALID). */
+ * kernels only, a buffer must be make_kernel's outer product k (x) k.  ToRGB / ToFlow `to_rgbs.N.upsample.kernel` /
+ * `to_flows.N.upsample.kernel` buffers (styledecoder.py:373,394: make_kernel([1,3,3,1]) * 4 by construction, the checkpoint's
+ * after the strict load): any rank-1 4 x 4 kernel ky (x) kx is applied per level and per module; another size or a kernel of
+ * rank > 1 is refused (FLOAT_E_INVALID). */
 int float_dec_create(const float_dec_cfg_t* cfg, const float_tensor_t* tensors, int32_t n_tensors,
                      float_dec_t** out);
 void float_dec_destroy(float_dec_t* h);
@@ -287,7 +289,9 @@ int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_
  * Direction (styledecoder.py:428-444, QR hoisted to create time), as called by
  * FLOAT.encode_image_into_latent / inference (FLOAT.py:283-291).
  * Checkpoint keys: `net_app.convs.*`, `fc.*` (prefix `motion_autoencoder.enc.` stripped) and,
- * optionally, `direction.weight` (from `motion_autoencoder.dec.`) to get r_s as well. */
+ * optionally, `direction.weight` (from `motion_autoencoder.dec.`) to get r_s as well.  The Blur buffers of the down-sampling
+ * ConvLayers (`net_app.convs.N.conv2.0.kernel`, `net_app.convs.N.skip.0.kernel`, encoder.py:59-75) are applied as the
+ * checkpoint holds them (any 4 x 4 values; make_kernel([1,3,3,1]) where the state has none); another size is refused. */
 typedef struct {
   int32_t size;        /* input resolution, power of two in [64, 1024] */
   int32_t dim;         /* 512 */

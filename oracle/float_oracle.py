@@ -324,9 +324,11 @@ def styled_conv(x, style, sd, prefix, upsample=False, blur_kernel=(1, 3, 3, 1)):
     return F.leaky_relu(y + sd[prefix + ".activate.bias"].to(x.dtype), 0.2) * _SQRT2
 
 
-def upsample2(x):
-    """Upsample([1,3,3,1]) (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR gain 4."""
-    return upfirdn(x, fir_kernel(4.0, x.dtype), up=2, pad=(2, 1))
+def upsample2(x, k=None):
+    """Upsample([1,3,3,1]) (styledecoder.py:74-90): zero-insert x2, pad (2,1), FIR gain 4.  k: the module's registered
+    `upsample.kernel` buffer where the state holds one (the strict load, nodes_vadv_loader.py:632, puts the checkpoint's 4 x 4
+    buffer over the constructor's make_kernel([1,3,3,1]) * 4; the padding stays the constructor's)."""
+    return upfirdn(x, fir_kernel(4.0, x.dtype) if k is None else k.to(x.dtype), up=2, pad=(2, 1))
 
 
 def to_rgb(x, sd, prefix, skip=None):
@@ -337,7 +339,7 @@ def to_rgb(x, sd, prefix, skip=None):
     y = F.leaky_relu(y + sd[prefix + ".conv.1.bias"].to(x.dtype), 0.2) * _SQRT2
     y = y + sd[prefix + ".bias"].to(x.dtype)
     if skip is not None:
-        y = y + upsample2(skip)
+        y = y + upsample2(skip, sd.get(prefix + ".upsample.kernel"))
     return y
 
 
@@ -346,7 +348,7 @@ def to_flow(x, style, feat, sd, prefix, skip=None):
     out = modulated_conv(x, style, sd, prefix + ".conv", demodulate=False)
     out = out + sd[prefix + ".bias"].to(x.dtype)
     if skip is not None:
-        out = out + upsample2(skip)
+        out = out + upsample2(skip, sd.get(prefix + ".upsample.kernel"))
     R = x.shape[2]
     lin = torch.linspace(-1, 1, R, dtype=torch.float64).to(torch.float32).to(x.dtype)  # np.linspace f64 -> f32
     gx = lin[None, :].expand(R, R)
@@ -412,10 +414,11 @@ def direction(sd, lam, dtype=torch.float32):
 # EncoderApp / Encoder (encoder.py:183-281), once per clip.
 
 
-def enc_blur(x, pad):
+def enc_blur(x, pad, k=None):
     """Blur([1,3,3,1], pad) of a down-sampling ConvLayer (encoder.py:59-75,160-166): upfirdn with
-    up = down = 1, i.e. zero-pad by (pad0, pad1) and correlate with the (symmetric) 4x4 FIR / 64."""
-    return upfirdn(x, fir_kernel(1.0, x.dtype), up=1, pad=pad)
+    up = down = 1, i.e. zero-pad by (pad0, pad1) and correlate with the FLIPPED 4x4 FIR (encoder.py:28-29) - make_kernel([1,3,3,1])
+    = outer / 64, or the layer's registered `kernel` buffer `k` where the state holds one (any 4 x 4 values)."""
+    return upfirdn(x, fir_kernel(1.0, x.dtype) if k is None else k.to(x.dtype), up=1, pad=pad)
 
 
 def equal_conv2d(x, w, stride=1, padding=0):
@@ -429,7 +432,7 @@ def enc_conv_layer(x, sd, prefix, k, downsample=False, activate=True):
     [blur, conv, act] with pad0 = (p+1)//2, pad1 = p//2, p = (4 - 2) + (k - 1), stride 2, padding 0."""
     if downsample:
         p = (4 - 2) + (k - 1)
-        x = enc_blur(x, ((p + 1) // 2, p // 2))
+        x = enc_blur(x, ((p + 1) // 2, p // 2), sd.get(prefix + "0.kernel"))
         y = equal_conv2d(x, sd[prefix + "1.weight"], stride=2, padding=0)
         bias_key = prefix + "2.bias"
     else:

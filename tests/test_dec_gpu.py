@@ -190,7 +190,7 @@ def test_blur_kernel_from_checkpoint_and_widget(dtype):
     """A Synthesis trained with another 4-tap blur kernel (tests/golden/dec_blur.npz: reference Synthesis(blur_kernel=[1,2,4,1])
     with that kernel's `conv.blur.kernel` buffers loaded strictly, nodes_vadv_loader.py:567-632).  The operator takes the FIR of
     every up-sampling StyledConv from the checkpoint's buffer; a state without the buffers takes the loader's widget value;
-    ToRGB / ToFlow up-sampling kernels other than [1,3,3,1] are refused.  fp32 mode max-abs <= 1e-4, fp16 rel-L2 <= 5e-3."""
+    ToRGB / ToFlow up-sampling kernels of rank > 1 or of another size are refused (rank-1 ones: test_upsample_kernels_from_checkpoint).  fp32 mode max-abs <= 1e-4, fp16 rel-L2 <= 5e-3."""
     g = golden("dec_blur")
     bk = g["kernels"].tolist()[1]
     sd = W.synth_decoder_state(128, seed=g["seed"], blur_kernel=bk)
@@ -213,8 +213,40 @@ def test_blur_kernel_from_checkpoint_and_widget(dtype):
     assert float((dflt - g["raw"]).norm() / g["raw"].norm()) > 0.05  # [1,3,3,1] is a different decoder
     assert torch.equal(run(sd, blur_kernel=[1, 3, 3, 1]), raw)  # a contradicting widget loses to the checkpoint (strict load)
     odd = dict(sd)
-    odd["to_rgbs.1.upsample.kernel"] = odd["convs.0.conv.blur.kernel"].clone()
-    with pytest.raises(ValueError, match="up-sampling kernel"):
+    odd["to_rgbs.1.upsample.kernel"] = torch.eye(4)  # rank 4: not ky (x) kx
+    with pytest.raises(ValueError, match="rank-1"):
+        pkg.decoder.SynthesisHIP(odd, 128, 512, "cuda:0", dtype=dtype, max_frames=2)
+    odd["to_rgbs.1.upsample.kernel"] = torch.ones(3, 3) / 9 * 4  # the Upsample's padding belongs to 4 taps
+    with pytest.raises(ValueError, match="4 x 4"):
         pkg.decoder.SynthesisHIP(odd, 128, 512, "cuda:0", dtype=dtype, max_frames=2)
     with pytest.raises(ValueError, match="4-tap"):
         pkg.decoder.SynthesisHIP(sd, 128, 512, "cuda:0", dtype=dtype, max_frames=2, blur_kernel=[1, 2, 1])
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_upsample_kernels_from_checkpoint(dtype):
+    """ToRGB / ToFlow `upsample.kernel` buffers that are not make_kernel([1,3,3,1]) * 4 (tests/golden/fir_buffers.npz: the reference
+    Synthesis after a strict load of weights.fir_buffer_states - ToRGB make_kernel([1,2,4,1]) * 4, ToFlow 4 outer([1,3,3,1],
+    [1,2,4,1]) / 64: asymmetric, different per axis and per module).  dec_flow_kernel takes the per-axis taps of both Upsamples
+    from the checkpoint.  fp32 mode max-abs <= 1e-4, fp16 rel-L2 <= 5e-3; the default kernels are a 41 % different decoder, and a
+    state without the buffers decodes bitwise like one that holds the default buffers."""
+    g = golden("fir_buffers")
+    size, seed = int(g["size"]), int(g["seed"])
+    _, sd = W.fir_buffer_states(size, seed)
+    feats = W.synth_feats(size, seed=seed)
+
+    def run(state):
+        dec = pkg.decoder.SynthesisHIP(state, size, 512, "cuda:0", dtype=dtype, max_frames=2)
+        dec.set_feats(feats)
+        raw = dec.synthesis_raw(g["dec_s_r"], g["dec_r_d"]).cpu()
+        assert dec.saturation() == 0
+        return raw
+
+    raw = run(sd)
+    m, r = float((raw - g["dec_raw"]).abs().max()), float((raw - g["dec_raw"]).norm() / g["dec_raw"].norm())
+    print("upsample kernels from the checkpoint, %s: max|d| %.2e rel-L2 %.2e" % (dtype, m, r))
+    assert (m <= 1e-4) if dtype == "fp32" else (r <= 5e-3)
+    sd0 = W.synth_decoder_state(size, seed=seed)
+    dflt = run(sd0)
+    assert float((dflt - g["dec_raw"]).norm() / g["dec_raw"].norm()) > 0.1
+    assert torch.equal(run({k: v for k, v in sd0.items() if not k.endswith("upsample.kernel")}), dflt)

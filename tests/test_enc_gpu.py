@@ -123,12 +123,37 @@ def test_encoder_errors():
     enc = pkg.encoder.EncoderHIP(esd, 64, 512, 20, "cuda:0")
     with pytest.raises(ValueError):
         enc.encode_image_into_latent(torch.zeros(1, 3, 32, 32))
-    # the Blur buffers come from the checkpoint in the reference (strict load); the operator has [1,3,3,1] in its code and says so
+    # the Blur buffers come from the checkpoint in the reference (strict load): any 4 x 4 values are applied
+    # (test_encoder_blur_buffers_from_checkpoint); another size is refused - the layer's padding belongs to 4 taps
     odd = dict(esd)
     key = [k for k in esd if k.endswith("conv2.0.kernel")][0]
-    odd[key] = torch.ones(4, 4) / 16
-    with pytest.raises(ValueError, match="blur kernel"):
+    odd[key] = torch.ones(3, 3) / 9
+    with pytest.raises(ValueError, match="4 x 4"):
         pkg.encoder.EncoderHIP(odd, 64, 512, 20, "cuda:0")
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "fp32"])
+def test_encoder_blur_buffers_from_checkpoint(dtype):
+    """Blur buffers other than make_kernel([1,3,3,1]) (tests/golden/fir_buffers.npz: the reference Encoder after a strict load of
+    weights.fir_buffer_states - `conv2.0.kernel` = make_kernel([1,2,4,1]), asymmetric: pins the flip of upfirdn2d; `skip.0.kernel`
+    = a non-separable positive kernel).  enc_blur_kernel takes every layer's 16 taps from the checkpoint; a state without the
+    buffers encodes bitwise like one holding the default buffers."""
+    g = golden("fir_buffers")
+    size, seed = int(g["size"]), int(g["seed"])
+    esd, _ = W.fir_buffer_states(size, seed)
+    enc = pkg.encoder.EncoderHIP(esd, size, 512, 20, "cuda:0", dtype)
+    s_r, lam, feats, _ = enc.encode_image_into_latent(_image(seed, size))
+    errs = dict(s_r=rel_l2(s_r.cpu(), g["enc_s_r"]), lam=rel_l2(lam.cpu(), g["enc_lam"]))
+    for i, f in enumerate(feats):
+        st = int(g["enc_feat%d_stride" % i])
+        errs["feat%d" % i] = rel_l2(f.cpu()[:, :, ::st, ::st], g["enc_feat%d" % i])
+    print(dtype, " ".join("%s %.2e" % kv for kv in errs.items()))
+    assert max(errs.values()) < TOL[dtype], errs
+    esd0 = W.synth_encoder_state(size, seed=seed)
+    a = pkg.encoder.EncoderHIP(esd0, size, 512, 20, "cuda:0", dtype).encode_image_into_latent(_image(seed, size))
+    assert rel_l2(a[2][0].cpu(), g["enc_feat0"]) > 0.05  # the default kernels: a different encoder (the 8-px map, behind every Blur)
+    b = pkg.encoder.EncoderHIP({k: v for k, v in esd0.items() if not k.endswith(".kernel")}, size, 512, 20, "cuda:0", dtype).encode_image_into_latent(_image(seed, size))
+    assert torch.equal(a[0], b[0]) and all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
 
 
 def test_encoder_fp32_feeds_decoder_fp32():

@@ -3,6 +3,7 @@
 seeded weights and inputs.  fp32 vs fp32 with different summation orders: tolerance 1e-4 rel."""
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -252,3 +253,27 @@ def test_dec_blur_kernels():
     sd0 = W.synth_decoder_state(128, seed=seed)  # default buffers in the checkpoint: the constructor argument alone changes nothing
     raw0 = torch.cat([O.synthesis(sd0, g["s_r"] + g["r_d"][:, t], feats, blur_kernel=bk) for t in range(2)])
     assert rel_l2(raw0, g["raw"]) > 0.05
+
+
+def test_fir_buffers_from_the_checkpoint():
+    """FIR buffers other than make_kernel([1,3,3,1]) outside the up-sampling StyledConvs (tests/golden/fir_buffers.npz: the
+    reference's Encoder / Synthesis after a strict load of weights.fir_buffer_states): the oracle's encoder Blur reads
+    `conv2.0.kernel` / `skip.0.kernel` (asymmetric and non-separable kernels: the flip of upfirdn2d is pinned), its ToRGB / ToFlow
+    Upsample reads `upsample.kernel`; with the default kernels the answers differ by 24 % / 41 %."""
+    g = golden("fir_buffers")
+    size, seed = int(g["size"]), int(g["seed"])
+    esd, dsd = W.fir_buffer_states(size, seed)
+    img = torch.from_numpy(np.random.RandomState(seed).rand(1, 3, size, size).astype(np.float32)) * 2 - 1
+    s_r, feats, lam = O.encode_appearance(esd, img)
+    assert rel_l2(s_r, g["enc_s_r"]) < TOL_REL and rel_l2(lam, g["enc_lam"]) < TOL_REL
+    for i, f in enumerate(feats):
+        st = int(g["enc_feat%d_stride" % i])
+        assert rel_l2(f[:, :, ::st, ::st], g["enc_feat%d" % i]) < TOL_REL
+        assert rel_l2(f.mean(dim=(2, 3)), g["enc_feat%d_mean" % i]) < TOL_REL
+    d_feats = O.encode_appearance(W.synth_encoder_state(size, seed=seed), img)[1]
+    assert rel_l2(d_feats[0], g["enc_feat0"]) > 0.05  # make_kernel([1,3,3,1]) is a different encoder
+    dfeats = W.synth_feats(size, seed=seed)
+    raw = torch.cat([O.synthesis(dsd, g["dec_s_r"] + g["dec_r_d"][:, t], dfeats) for t in range(2)])
+    assert rel_l2(raw, g["dec_raw"]) < TOL_REL
+    dflt = torch.cat([O.synthesis(W.synth_decoder_state(size, seed=seed), g["dec_s_r"] + g["dec_r_d"][:, t], dfeats) for t in range(2)])
+    assert rel_l2(dflt, g["dec_raw"]) > 0.1

@@ -447,6 +447,50 @@ def gen_dec_blur(ns, seed=1900, size=128):
     save("dec_blur", **arrs)
 
 
+def gen_fir_buffers(ns, seed=2000, size=64):
+    """FIR buffers that are NOT make_kernel([1,3,3,1]) outside the up-sampling StyledConvs - what a checkpoint may hold and the
+    strict load (nodes_vadv_loader.py:632) puts over the constructor's kernels:
+      * encoder (encoder.py:59-75,160-166): `conv2.0.kernel` of every ResBlock = make_kernel([1,2,4,1]) (asymmetric: pins the flip of
+        upfirdn2d, encoder.py:28-29), `skip.0.kernel` = a seeded NON-separable positive 4 x 4 kernel of sum 1;
+      * decoder (styledecoder.py:74-90,373,394): `to_rgbs.N.upsample.kernel` = make_kernel([1,2,4,1]) * 4, `to_flows.N.upsample.kernel`
+        = 4 * outer([1,3,3,1], [1,2,4,1]) / 64 (rank 1, different factors per axis).
+    Outputs of the reference's Encoder / Synthesis with those states loaded strictly."""
+    print("[FIR buffers from the checkpoint]")
+    esd, dsd = weights.fir_buffer_states(size, seed)
+    enc = ns.encoder.Encoder(size, 512, 20)
+    enc.load_state_dict(esd, strict=True)
+    enc.eval()
+    img = torch.from_numpy(np.random.RandomState(seed).rand(1, 3, size, size).astype(np.float32)) * 2 - 1
+    with torch.no_grad():
+        s_r, _, feats = enc(img, None)
+        lam = enc.fc(s_r)
+    o_s, o_f, o_l = O.encode_appearance(esd, img)
+    d_s, d_f, _ = O.encode_appearance(weights.synth_encoder_state(size, seed=seed), img)
+    print("  encoder oracle-ref max|d|: s_r %.3e lam %.3e feats %.3e ; default kernels vs ref: feats rel %.3e" % (
+        maxdiff(o_s, s_r)[0], maxdiff(o_l, lam)[0], max(maxdiff(a, b)[0] for a, b in zip(o_f, feats)),
+        max(maxdiff(a, b)[1] for a, b in zip(d_f, feats))))
+    arrs = dict(seed=seed, size=size, enc_s_r=s_r, enc_lam=lam)
+    for i, f in enumerate(feats):  # every 4th pixel of the larger maps (+ per-channel means of the whole map)
+        st = 4 if f.shape[-1] > 16 else 1
+        arrs["enc_feat%d_stride" % i] = st
+        arrs["enc_feat%d" % i] = f[:, :, ::st, ::st]
+        arrs["enc_feat%d_mean" % i] = f.mean(dim=(2, 3))
+    d = ns.styledecoder.Synthesis(size, 512, 20)
+    d.load_state_dict(dsd, strict=True)
+    d.eval()
+    dfeats = weights.synth_feats(size, seed=seed)
+    s_r2 = rnd(seed + 21, 1, 512)
+    r_d = rnd(seed + 22, 1, 2, 512, std=0.5)
+    with torch.no_grad():
+        raw = torch.cat([d(s_r2 + r_d[:, t], None, dfeats)[0] for t in range(2)])
+    orc = torch.cat([O.synthesis(dsd, s_r2 + r_d[:, t], dfeats) for t in range(2)])
+    dflt = torch.cat([O.synthesis(weights.synth_decoder_state(size, seed=seed), s_r2 + r_d[:, t], dfeats) for t in range(2)])
+    print("  synthesis raw std %.3f ; oracle-ref max|d| %.3e ; default kernels vs ref rel %.3e" % (
+        float(raw.std()), maxdiff(orc, raw)[0], maxdiff(dflt, raw)[1]))
+    arrs.update(dec_s_r=s_r2, dec_r_d=r_d, dec_raw=raw)
+    save("fir_buffers", **arrs)
+
+
 def gen_e2e_config1(ns, seed=900):
     """BASELINE.json configs[0]: 1 s audio -> 25 frames, 512x512, nfe=10 (9 Euler evaluations), fp32, the
     reference's own sampler (nodes_adv.py:545-694) and decode loop (FLOAT.py:113-169) chained on CPU."""
@@ -685,6 +729,9 @@ def main():
     if os.environ.get("GOLDENS_ONLY") == "blur":
         gen_dec_blur(ns)
         return
+    if os.environ.get("GOLDENS_ONLY") == "fir":
+        gen_fir_buffers(ns)
+        return
     if os.environ.get("GOLDENS_ONLY") == "encx":
         gen_encoder(ns, 64, seed=1010, sparse=False, gain=2.0, name="enc_stress_64_g2")
         gen_encoder(ns, 64, seed=1010, sparse=False, gain=6.0, name="enc_stress_64_g6")
@@ -717,6 +764,7 @@ def main():
     gen_dec(ns, 512, seed=800, n_frames=2, sparse=True)
     gen_dec_units_hip(ns, seed=1600)
     gen_dec_blur(ns)
+    gen_fir_buffers(ns)
     gen_dec_stress(ns, 64, 1700, "warp", sparse=False)
     gen_dec_stress(ns, 64, 1710, "range", sparse=False)
     gen_dec_stress(ns, 512, 1720, "warp_smooth", sparse=True)
