@@ -55,13 +55,18 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
   CK(hipMemset(dout, 0xff, out_rows * N * 4));
   BigArgs g{dA, dW, db, dout, M, N, K, N, nrb, N / 256};
-  constexpr int NS = BIG_NS, smem = NS * (2 * MI + 16) * 1024 + 8 * 4096;
+#ifdef BIG4
+  constexpr int NS = 4, smem = NS * 28 * 1024 + 4 * 4096, NTHR = 256;
+  auto kern = fmt_gemm_big4_kernel<FP16, NS>;
+#else
+  constexpr int NS = BIG_NS, smem = NS * (2 * MI + 16) * 1024 + 8 * 4096, NTHR = 512;
   auto kern = fmt_gemm_big_kernel<FP16, MI, NS>;
+#endif
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
   int ncu = 0;
   CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
   const int grid = (ncu / 8) * 8;
-  auto launch = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, nullptr, g); };
+  auto launch = [&] { hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), smem, nullptr, g); };
   launch();
   CK(hipDeviceSynchronize());
   // sampled check: 4000 random outputs + the corners of the last row block
