@@ -120,8 +120,7 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
   int ij = 0, ikb = 0;
   unsigned ioff = (unsigned)(w * 1024);  // LDS byte offset of this wave's first piece in the slot being filled
   set_tile_ptrs(0);
-  // this wave's pieces of a stage: NP = IMAX for waves < NHI, ILO for the others (BIG_EXACT; otherwise every wave issues IMAX and
-  // the surplus ones fetch the stage's last fragment again: 32 pieces for 28 fragments, 14 % more than the CU has to take in)
+  // this wave's pieces of a stage: NP = IMAX for waves < NHI, ILO for the others
   auto issue_piece = [&](int i) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + lane * 8),
                                      (__attribute__((address_space(3))) void*)(lds + ioff + i * 8 * 1024), 16, 0, 0);
@@ -138,13 +137,13 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
     }
   };
   // bias of this wave's 64 columns, 4 per lane (lane % 16), by a register load the compiler does not see (no wait of its own)
-  auto load_bias = [&](int j) -> f32x4 {
+  // (loaded INTO the loop-carried registers behind the last use of the old value: a copy of a freshly loaded value may be emitted
+  // as a register move in front of which the compiler, not knowing that the asm is an asynchronous load, puts no wait)
+  auto load_bias = [&](int j, f32x4& v) {
     int rb, cb;
     tile_of(min(j, ntl - 1), rb, cb);
     const float* p = g.bias + cb * 256 + wc * 64 + (lane & 15) * 4;
-    f32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-    return v;
   };
 
   const unsigned abase = (unsigned)(lane * 16 + (wr * MI) * 1024), bbase = (unsigned)(lane * 16 + (RT + wc * NJ) * 1024);
@@ -183,7 +182,7 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
         if constexpr (BIG_DMA_EVERY > 0) {                                                      \
           /* LDS-DMA piece d in front of MFMA 1 + d * BIG_DMA_EVERY: a piece's issue blocks its wave while the CU's intake   */ \
           /* queue is full (~27 clocks per KiB), and pieces issued first put that in front of EVERY wave's MFMAs             */ \
-          /* BIG_PHASE: the two waves of a SIMD (w and w + 4: NP = IMAX and ILO with BIG_EXACT) issue in opposite halves     */ \
+          /* BIG_PHASE: the two waves of a SIMD (w and w + 4: NP = IMAX and ILO) issue in opposite halves     */ \
           constexpr int de_ = BIG_DMA_EVERY > 0 ? BIG_DMA_EVERY : 1;                            \
           constexpr int m0_ = (BIG_PHASE && NP != IMAX) ? MI * NJ / 2 + 1 : 1, d_ = (m.value - m0_) / de_; \
           if constexpr (m.value >= m0_ && (m.value - m0_) % de_ == 0 && d_ < NP) {              \
@@ -203,7 +202,8 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
     __builtin_amdgcn_sched_barrier(0);                                                          \
   } while (0)
 
-  f32x4 bias_cur = load_bias(0);  // older than every DMA
+  f32x4 bias_cur;
+  load_bias(0, bias_cur);  // older than every DMA
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int s = 0; s < NS; ++s) BIG_ISSUE_ALWAYS();
@@ -234,7 +234,6 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
     int rb, cb;
     tile_of(j, rb, cb);
     const int row0 = rb * ROWS + wr * (MI * 16), col0 = cb * 256 + wc * 64;
-    const f32x4 bias_next = load_bias(j + 1);  // 1 of the NST operations; used by the next epilogue
     const bool whole = row0 + MI * 16 <= g.M;   // every store of this wave is issued: the hand count of NST holds
     // running output address = scalar base (4 rows further per store) + this lane's 32-bit offset.  The base is kept opaque:
     // the compiler would otherwise precompute one 64-bit address per store at kernel start and spill them - and scratch
@@ -283,7 +282,7 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
         asm volatile("" : "+s"(obase));
       }
     }
-    bias_cur = bias_next;
+    load_bias(j + 1, bias_cur);  // 1 of the NST operations, behind the stores; used by the next epilogue
     if (!whole) {  // fewer stores than NST may have been issued: start the count afresh (the prefetched stages land too)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       extra = false;
@@ -293,12 +292,9 @@ __global__ __launch_bounds__(512) void fmt_gemm_big_kernel(BigArgs g) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the re-issued stages behind the last tile: no LDS-DMA may outlive the workgroup
   };
-#ifdef BIG_EXACT
+  // two code paths: waves < NHI issue IMAX pieces per stage, the others ILO (a surplus piece would land in the NEXT stage's slot)
   if (NHI == 0 || w < NHI) run(std::integral_constant<int, IMAX>{});
   else run(std::integral_constant<int, ILO>{});
-#else
-  run(std::integral_constant<int, IMAX>{});
-#endif
 #undef BIG_STEP
 }
 
@@ -365,14 +361,12 @@ __global__ __launch_bounds__(256) void fmt_gemm_big4_kernel(BigArgs g) {
   struct Bias2 {
     f32x4 v[2];
   };
-  auto load_bias = [&](int j) -> Bias2 {
+  auto load_bias = [&](int j, Bias2& b) {
     int rb, cb;
     tile_of(min(j, ntl - 1), rb, cb);
     const float* p = g.bias + cb * 256 + wc * 128 + (lane & 15) * 4;
-    Bias2 b;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(b.v[0]) : "v"(p) : "memory");
     asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(b.v[1]) : "v"(p) : "memory");
-    return b;
   };
   const unsigned abase = (unsigned)(lane * 16 + (wr * MI) * 1024), bbase = (unsigned)(lane * 16 + (RT + wc * NJ) * 1024);
   f32x4 acc[MI][NJ];
@@ -407,7 +401,8 @@ __global__ __launch_bounds__(256) void fmt_gemm_big4_kernel(BigArgs g) {
     __builtin_amdgcn_sched_barrier(0);                                                                \
   } while (0)
 
-  Bias2 bias_cur = load_bias(0);
+  Bias2 bias_cur;
+  load_bias(0, bias_cur);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
@@ -441,7 +436,6 @@ __global__ __launch_bounds__(256) void fmt_gemm_big4_kernel(BigArgs g) {
     int rb, cb;
     tile_of(j, rb, cb);
     const int row0 = rb * ROWS + wr * (MI * 16), col0 = cb * 256 + wc * 128;
-    const Bias2 bias_next = load_bias(j + 1);
     const bool whole = row0 + MI * 16 <= g.M;
     typedef __attribute__((address_space(1))) char gchar;
     gchar* obase = (gchar*)(g.out + (size_t)row0 * g.ldo + col0);
@@ -483,7 +477,7 @@ __global__ __launch_bounds__(256) void fmt_gemm_big4_kernel(BigArgs g) {
         asm volatile("" : "+s"(obase));
       }
     }
-    bias_cur = bias_next;
+    load_bias(j + 1, bias_cur);  // 2 of the NST operations, behind the stores
     if (!whole) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       extra = false;

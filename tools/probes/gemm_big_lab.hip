@@ -82,7 +82,10 @@ int main(int argc, char** argv) {
     for (int k = 0; k < K; ++k) ref += (double)h2f(hA[fmt_pack_off(row, k, KB)]) * h2f(hW[fmt_pack_off(n, k, KB)]);
     const double d = got - ref;
     num += d * d, den += ref * ref, mx = std::max(mx, std::fabs(d));
-    if (std::fabs(d) > 1e-2) ++bad;
+    if (std::fabs(d) > 1e-2 || d != d) {
+      if (bad < 12 && getenv("BIG_SHOW_BAD")) printf("  bad: row %d (%d in block %d) col %d (%d in block %d): got %g want %g\n", row, row % 192, row / 192, n, n % 256, n / 256, got, ref);
+      ++bad;
+    }
   }
   // rows >= M must be untouched (0xff pattern = NaN)
   float tail;
