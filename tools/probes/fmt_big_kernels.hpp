@@ -12,15 +12,14 @@
 //     spills: scratch reloads are vector-memory operations);
 //   * tile order: an XCD's 32 workgroups hold 8 row blocks x 4 column blocks at any time (FETCH_SIZE: 1.55 GB of the 8.4 GB of
 //     tile fetches of a launch leave the L2s: 82 % hits).
-// MEASURED (MI355X): in the lab, on uniform random operands, 1 094-1 110 us per launch against 1 232-1 273 for
-// fmt_gemm_dma_kernel on the same box; IN THE PIPELINE (real SiLU operands: a higher clock for both) a tie - FMT sampling
-// 81.6 vs 81.3 ms per clip, 161.5 vs 160.3 ms per 4 clips, 469 vs 460 per 16.  Counters: MFMA pipe 41 % of the cycles, waves
-// 43 % issue-stalled, 29 % parked - with the stores removed still 0.37-0.41 of the peak: the K loop, not what surrounds it, is
-// the limit.  A step costs the sum of its LDS-DMA issue (28 pieces of 1 KiB per k-block, ~100 clocks of issue each, all waves
-// behind the same barrier) and its MFMAs; spreading the pieces over the step (wave w in front of its MFMA chunk w, BIG_SPREAD)
-// made it 10 % SLOWER, 256-row tiles (MI = 8) spill; a 4-wave form (one wave per SIMD with the whole register file, 96 x 128 wave
-// tiles, accumulators in AGPRs) ran at 1 174 us against 1 092 on the same box before its results were right, and was dropped.  What would move it is a structure whose two waves per SIMD sit in
-// opposite phases (one multiplies while the other issues and reads): not built.
+// MEASURED (MI355X, uniform random operands; DESIGN.md sections 6 / 7, profiles/r05_clock_power.txt):
+//   * first form: 1 094-1 110 us per launch against 1 232-1 273 for fmt_gemm_dma_kernel on the same box; IN THE PIPELINE a tie (FMT
+//     sampling 81.6 vs 81.3 ms per clip, 161.5 vs 160.3 per 4 clips, 469 vs 460 per 16);
+//   * its K loop spent a third of its time in the scalar unit (integer divisions and branch chains per step): LEAN control below;
+//   * sustained loops sit at the socket's 1 400-W cap and 1.92-1.97 GHz whatever the issue order (exact piece counts, pieces and
+//     fragment reads spread between the MFMAs - BIG_INTERLEAVE / BIG_DMA_EVERY -, SIMD partners in opposite phases - BIG_PHASE);
+//   * 945 us sustained (8 waves, this kernel) / 934 (fmt_gemm_big4_kernel below: one wave per SIMD, 96 x 128 wave tiles; 746 =
+//     0.51 of 2.5 PFLOP/s without its stores) against 1 083 for the library kernel.  256-row tiles of the 8-wave form (MI = 8) spill.
 #pragma once
 #include "fmt_rb_kernels.hpp"  // -I comfyui-float_optimized_amd/csrc
 
