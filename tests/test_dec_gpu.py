@@ -250,3 +250,24 @@ def test_upsample_kernels_from_checkpoint(dtype):
     dflt = run(sd0)
     assert float((dflt - g["dec_raw"]).norm() / g["dec_raw"].norm()) > 0.1
     assert torch.equal(run({k: v for k, v in sd0.items() if not k.endswith("upsample.kernel")}), dflt)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "fp16"])
+def test_upsample_kernels_at_512(dtype):
+    """The same non-default ToRGB / ToFlow up-sampling buffers at 512 px (the 256- and 512-px levels run dec_flow_kernel with 4
+    pixels per lane group, the golden's 64-px decoder only the 2-pixel form), one frame against the oracle - which equals the
+    reference to the last bit on tests/golden/fir_buffers.npz."""
+    from oracle import float_oracle as O
+    _, sd = W.fir_buffer_states(512, 2100)
+    feats = W.synth_feats(512, seed=2100)
+    g = torch.Generator().manual_seed(2100)
+    s_r, r_d = torch.randn(1, 512, generator=g), torch.randn(1, 1, 512, generator=g) * 0.5
+    want = O.synthesis(sd, s_r + r_d[:, 0], feats)
+    dec = pkg.decoder.SynthesisHIP(sd, 512, 512, "cuda:0", dtype=dtype, max_frames=2)
+    dec.set_feats(feats)
+    raw = dec.synthesis_raw(s_r, r_d).cpu()
+    m, r = float((raw - want).abs().max()), float((raw - want).norm() / want.norm())
+    print("512 px, upsample kernels from the checkpoint, %s: max|d| %.2e rel-L2 %.2e" % (dtype, m, r))
+    assert dec.saturation() == 0
+    # fp32 mode: rel-L2 5e-6, single pixels 2.6e-4 (the warp turns a 1e-7 difference in a flow into a sampling difference)
+    assert (m <= 5e-4 and r <= 2e-5) if dtype == "fp32" else (r <= 5e-3)
