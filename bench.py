@@ -421,7 +421,7 @@ def main():
         conv_roof["frac"] = round(conv_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
         mod_roof = None
         if m_n > 0:
-            mod_roof = {"kernel": "fmt_gemm_dma_kernel (adaLN projection of all evaluations of a window)", "bound": "mfma",
+            mod_roof = {"kernel": "fmt_gemm_big4_kernel (adaLN projection of all evaluations of a window; FLOAT_FMT_BIG=0: fmt_gemm_dma_kernel)", "bound": "mfma",
                         "achieved": round(mod_flop / (mod_total_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "launches": m_n, "avg_launch_us": round(m_ms * 1e3, 2), "algorithmic_flop_per_launch": round(mod_flop / m_n),
                         "traffic": None}

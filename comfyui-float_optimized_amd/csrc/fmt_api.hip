@@ -5,6 +5,7 @@
 #include "fmt_gemm.hpp"
 #include "fmt_kernels.hpp"
 #include "fmt_rb_kernels.hpp"
+#include "fmt_big_kernels.hpp"
 
 namespace {
 
@@ -52,6 +53,7 @@ struct float_fmt {
   // depend on x (FMT.py:333-335, 163-166), so every adaLN projection of those evaluations is ONE GEMM per window.
   float* modall = nullptr;
   int Mmod = 0;
+  size_t mod_zs = 0;  // floats between two evaluations' modulations in modall, as the last run_mod_all laid them out
   // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, method, scales); least recently used entry evicted
   struct GraphKey {
     int nfe, bc, we_len, method, nclip;
@@ -193,10 +195,43 @@ int launch_dma_t(GemmArgs g, bool prime, hipStream_t s) {
 }
 bool dma_shape_ok(const GemmArgs& g, int bn) { return g.N % bn == 0 && g.K % 64 == 0 && g.K >= 128; }
 
+// The hoisted projection of a whole batch of evaluations on DENSE rows: the persistent one-wave-per-SIMD kernel
+// (fmt_big_kernels.hpp), one workgroup per CU.  N in column blocks of 256, eight of them per XCD group; an even number (>= 4) of
+// k-blocks (the K loop is unrolled by two behind four peeled steps).  Bitwise the numbers of fmt_gemm_dma_kernel.
+// FLOAT_FMT_BIG=0 keeps the one-tile-per-workgroup kernels on rows padded per evaluation (the A/B switch).
+int g_fmt_big = 1;
+constexpr int kBigMinRows = 1536;  // below 8 row blocks the padded layout's kernels stay (a single evaluation: 180 rows)
+constexpr int kBigSmem = 4 * 28 * 1024 + 4 * 4096;
+bool big_shape_ok(int rows_total, int N, int K, int n_cu) {
+  return g_fmt_big && rows_total >= kBigMinRows && N % 2048 == 0 && K % 64 == 0 && K >= 128 && n_cu >= 8;
+}
+template <class T>
+int launch_big4(const u16* A, const FmtLin& L, float* out, int rows_total, int ldo, int n_cu, bool prime, hipStream_t s) {
+  if constexpr (T::is32) {
+    fh_set_error("the fp32 verification mode has no persistent projection kernel");
+    return FLOAT_E_INVALID;
+  } else {
+    auto kern = fmt_gemm_big4_kernel<T, 4>;
+    if (prime) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, kBigSmem) != hipSuccess)
+        (void)hipGetLastError();
+      return FLOAT_OK;
+    }
+    BigArgs g{A, L.W, L.b, out, rows_total, L.N, L.K, ldo, (rows_total + 191) / 192, L.N / 256};
+    const dim3 grid((unsigned)((n_cu / 8) * 8));
+    hipEvent_t e0, e1;
+    if (fh_prof_pair(2, &e0, &e1)) hipExtLaunchKernelGGL(kern, grid, dim3(256), kBigSmem, s, e0, e1, 0, g);
+    else hipLaunchKernelGGL(kern, grid, dim3(256), kBigSmem, s, g);
+    FH_CHECK_HIP(hipGetLastError());
+    return FLOAT_OK;
+  }
+}
+
 template <class T>
 int launch_wide(const GemmArgs& g, bool prime, hipStream_t s) {
   const int mt = (g.M + 15) / 16;
   if (prime) {
+    (void)launch_big4<T>(nullptr, FmtLin{}, nullptr, 0, 0, 0, true, s);
     (void)launch_dma_t<T, 4, 4, 0>(g, true, s);
     (void)launch_dma_t<T, 4, 4, 1>(g, true, s);
     (void)launch_wide_t<T, 4, 4>(g, true, s);
@@ -734,8 +769,14 @@ template <class T>
 int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
   const int D = h->D;
   FH_REQUIRE(n >= 1 && n <= kScSteps, "modulation batch of %d evaluations (max %d)", n, kScSteps);
+  // dense rows for the persistent kernel (row z * M + r of one packed image), else one padded image per evaluation
+  const bool big = !T::is32 && g_fmt_wide && big_shape_ok(n * M, h->adaln_all.N, h->adaln_all.K, h->n_cu);
   hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256, n), dim3(256), 0, s, h->sc16, h->temb + (size_t)e0 * D,
-                     h->ccond, M, D, (size_t)h->Mpad * D, h->sat);
+                     h->ccond, M, D, (size_t)h->Mpad * D, big ? M : 0, h->sat);
+  h->mod_zs = big ? (size_t)M * h->Ntot : (size_t)h->Mmod * h->Ntot;
+  if constexpr (!T::is32) {
+    if (big) return launch_big4<T>(h->sc16, h->adaln_all, h->modall, n * M, h->Ntot, h->n_cu, false, s);
+  }
   GemmArgs g = base_args(h->sc16, h->adaln_all, M);
   g.sat = h->sat;
   g.out_f32 = h->modall;
@@ -1246,14 +1287,13 @@ int run_window_steps(float_fmt* h, const CfgMode& m, int nfe, const std::vector<
   const size_t kstride = (size_t)h->Bmax * kMaxTok * c.dim_w;  // one stage's velocities: [clip][ntok][dim_w]
   const int n = m.nclip * c.n_cur * c.dim_w, rows = m.nclip * m.bc * h->ntok;
   const int nev = n_evals(h->method, nfe), batch = g_fmt_hoist ? kScSteps : 1;
-  const size_t zs = (size_t)h->Mmod * h->Ntot;
   const bool euler = h->method == FLOAT_ODE_EULER;
   int rc;
   for (int ev = 0; ev < nev; ++ev) {
     const int i = ev / tb.s, j = ev - i * tb.s, z = ev % batch;
     const float dt = ts[i + 1] - ts[i];
     if (z == 0 && (rc = run_mod_all<T>(h, rows, ev, std::min(batch, nev - ev), s))) return rc;
-    const float* mod = h->modall + (size_t)z * zs;
+    const float* mod = h->modall + (size_t)z * h->mod_zs;  // the layout run_mod_all chose for this batch
     if (euler) {
       if ((rc = run_blocks<T>(h, m.nclip, m.bc, mod, true, dt, a, r, e, s))) return rc;
       continue;
@@ -1576,6 +1616,7 @@ int float_fmt_create(const float_fmt_cfg_t* cfg, const float_tensor_t* tensors, 
   }
   if (const char* v = getenv("FLOAT_FMT_HOIST")) g_fmt_hoist = atoi(v) != 0;
   if (const char* v = getenv("FLOAT_FMT_ZGROUP")) g_fmt_zgroup = std::max(0, atoi(v));
+  if (const char* v = getenv("FLOAT_FMT_BIG")) g_fmt_big = atoi(v) != 0;
   if (const char* pl = getenv("FLOAT_FMT_PLAN"))
     sscanf(pl, "%d,%d,%d,%d,%d,%d", &g_fmt_plan_override[0], &g_fmt_plan_override[1], &g_fmt_plan_override[2],
            &g_fmt_plan_override[3], &g_fmt_plan_override[4], &g_fmt_plan_override[5]);

@@ -1388,12 +1388,13 @@ __global__ void fmt_tsin_kernel(u16* __restrict__ out, const float* __restrict__
 // written packed: the A operand of the fused adaLN projection.  8 columns per thread.
 template <class T>
 __global__ void fmt_silu_c_kernel(u16* __restrict__ out, const float* __restrict__ temb, const float* __restrict__ ccond,
-                                  int M, int D, size_t step_stride, unsigned long long* sat) {
-  // blockIdx.y = Euler step: all steps of a window are produced by one launch when they fit
+                                  int M, int D, size_t step_stride, int dense_rows, unsigned long long* sat) {
+  // blockIdx.y = Euler step: all steps of a window are produced by one launch when they fit.  dense_rows = 0: one packed image
+  // per step, step_stride elements apart; dense_rows = M: ONE packed image whose row z * M + r is row r of step z (fmt_gemm_big4_kernel)
   const int idx = (blockIdx.x * blockDim.x + threadIdx.x) * 8;
   if (idx >= M * D) return;
-  const int row = idx / D, c = idx % D;
-  typename T::elem* const o = reinterpret_cast<typename T::elem*>(out) + (size_t)blockIdx.y * step_stride;
+  const int c = idx % D, row = idx / D + (int)blockIdx.y * dense_rows;
+  typename T::elem* const o = reinterpret_cast<typename T::elem*>(out) + (dense_rows ? (size_t)0 : (size_t)blockIdx.y * step_stride);
   temb += (size_t)blockIdx.y * D;
   typename T::pack8 u;
 #pragma unroll

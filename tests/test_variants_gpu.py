@@ -33,6 +33,20 @@ if what == "fmt":
     r3 = fmt.sample(cond["r_s"], cond["wa"], cond["we"], noise, 6, 2.0, 1.0, 1.0).cpu()
     r4 = fmt.sample(cond["r_s"], cond["wa"], cond["we"], noise, 6, 2.0, 1.5, 1.0, include_r_cfg=True).cpu()
     torch.save({"r3": r3, "r4": r4}, out)
+elif what == "fmtbig":
+    # 10 evaluations per window: 1 800 (3-way CFG) / 2 400 (4-way) dense rows - the persistent adaLN projection kernel's range
+    cfg = pkg.config.FmtConfig()
+    sd = pkg.weights.synth_fmt_state(cfg, seed=3)
+    dt = os.environ.get("CHILD_DTYPE", "fp16")
+    fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, "cuda:0", dt, max_batch=2)
+    cs = [pkg.pipeline.synth_conditions(cfg, 75, seed=q, device="cuda:0") for q in range(2)]
+    cat = lambda k: torch.cat([c[k] for c in cs])
+    n1, n2 = pkg.fmt.draw_noise(2, 1, cfg, 15).cuda(), pkg.fmt.draw_noise(2, 2, cfg, 15).cuda()
+    c = cs[0]
+    r3 = fmt.sample(c["r_s"], c["wa"], c["we"], n1, 11, 2.0, 1.0, 1.0).cpu()
+    r4 = fmt.sample(c["r_s"], c["wa"], c["we"], n1, 11, 2.0, 1.5, 1.0, include_r_cfg=True).cpu()
+    rb = fmt.sample(cat("r_s"), cat("wa"), cat("we"), n2, 11, 2.0, 1.0, 1.0).cpu()
+    torch.save({"r3": r3, "r4": r4, "rb": rb}, out)
 elif what == "fmtbatch":
     cfg = pkg.config.FmtConfig()
     sd = pkg.weights.synth_fmt_state(cfg, seed=3)
@@ -78,6 +92,22 @@ def test_fmt_touch_and_token_blocked_head_are_bitwise_neutral(tmp_path):
         assert torch.equal(base[k], per_step[k]), k
         assert torch.equal(base[k], grouped[k]), k
         assert torch.equal(base[k], regstage[k]), k
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_persistent_adaln_projection_is_bitwise_neutral(tmp_path, dtype):
+    """fmt_gemm_big4_kernel (one persistent launch over the DENSE rows of a window's evaluations, from 1 536 rows on) against
+    fmt_gemm_dma_kernel on one padded row block per evaluation (FLOAT_FMT_BIG=0) and against one launch per evaluation
+    (FLOAT_FMT_HOIST=0): every modulation is the same MFMA sequence over k plus one bias add, so r_d is bitwise identical - for
+    one clip with 3- and 4-way CFG (1 800 / 2 400 rows, the last row block ragged) and for two stacked clips (3 600 rows)."""
+    env = {"CHILD_DTYPE": dtype}
+    big = run_child(tmp_path, "fmtbig", "big_" + dtype, env)
+    dma = run_child(tmp_path, "fmtbig", "dma_" + dtype, dict(env, FLOAT_FMT_BIG="0"))
+    per_step = run_child(tmp_path, "fmtbig", "step_" + dtype, dict(env, FLOAT_FMT_HOIST="0"))
+    for k in ("r3", "r4", "rb"):
+        assert torch.isfinite(big[k]).all()
+        assert torch.equal(big[k], dma[k]), k
+        assert torch.equal(big[k], per_step[k]), k
 
 
 def test_fused_upsample_matches_separate_kernels(tmp_path):

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import source_hash  # noqa: E402  (identity of the kernel sources the counters were taken on)
 
 N_SIMD = 256 * 4
-CLASSES = (("fmt_adaln_gemm", ("void fmt_gemm_wide", "void fmt_gemm_dma")), ("fmt_gemm", ("void fmt_gemm_kernel",)), ("fmt_gemm_rb", ("void fmt_gemm_rbs",)), ("dec_conv", ("void dec_conv", "void dec_zconv")), ("fmt_small", ("void fmt_lnmod", "void fmt_attn")),
+CLASSES = (("fmt_adaln_gemm", ("void fmt_gemm_wide", "void fmt_gemm_dma", "void fmt_gemm_big4")), ("fmt_gemm", ("void fmt_gemm_kernel",)), ("fmt_gemm_rb", ("void fmt_gemm_rbs",)), ("dec_conv", ("void dec_conv", "void dec_zconv")), ("fmt_small", ("void fmt_lnmod", "void fmt_attn")),
            ("dec_flow", ("void dec_flow",)), ("dec_blur", ("void dec_blur",)))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 disp = collections.defaultdict(set)

@@ -22,7 +22,7 @@ def per_class(d):
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
-            cls = ("fmt_adaln_gemm" if n.startswith(("void fmt_gemm_wide", "void fmt_gemm_dma")) else "fmt_gemm" if n.startswith("void fmt_gemm_kernel") else
+            cls = ("fmt_adaln_gemm" if n.startswith(("void fmt_gemm_wide", "void fmt_gemm_dma", "void fmt_gemm_big4")) else "fmt_gemm" if n.startswith("void fmt_gemm_kernel") else
                    "fmt_gemm_rb" if n.startswith("void fmt_gemm_rbs") else
                    "dec_conv" if n.startswith(("void dec_conv", "void dec_zconv")) else "dec_flow" if n.startswith("void dec_flow") else
                    "dec_zblur" if n.startswith("void dec_zblur") else "dec_other" if n.startswith("void dec_") else None)
