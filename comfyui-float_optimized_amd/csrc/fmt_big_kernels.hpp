@@ -8,8 +8,8 @@
 //     fragment reads per 48 MFMAs instead of the 20 of two 96 x 64 tiles; 7 LDS-DMA pieces per wave and k-block exactly; every
 //     piece and every fragment read is placed between MFMAs; control flow carried in registers (a CU has one scalar unit);
 //   * the epilogue does not touch the ring: 16 rows x 64 columns at a time through a wave-PRIVATE 4-KB LDS slab (XOR-swizzled
-//     granules, no workgroup barrier), whole 256-byte runs per store, `sc1` (the 1.8 GB of modulations of a launch do not pass
-//     through the L2s as dirty lines); stores and the bias loads are counted by hand in the vmcnt waits - the kernel must compile
+//     granules, no workgroup barrier), whole 256-byte runs per NON-TEMPORAL store (the 1.8 GB of modulations of a launch stream past
+//     the caches); stores and the bias loads are counted by hand in the vmcnt waits - the kernel must compile
 //     WITHOUT scratch (a reload is a vector-memory operation);
 //   * tile order: an XCD's 32 workgroups hold 8 row blocks x 4 column blocks at any time (82 % L2 hits).
 // Bitwise the numbers of fmt_gemm_dma_kernel (the same MFMA sequence per output element, one bias add).  MI355X, 9 000 x 51 200
@@ -194,8 +194,11 @@ __global__ __launch_bounds__(256) void fmt_gemm_big4_kernel(BigArgs g) {
 #if defined(BIG_NO_STORE)  // timing-only (tools/probes/gemm_big_lab.hip)
           asm volatile("" ::"v"(o0), "v"(o1));
 #else
-          asm volatile("global_store_dwordx4 %0, %1, %2 sc1" ::"v"(ovoff), "v"(o0), "s"(obase) : "memory");
-          asm volatile("global_store_dwordx4 %0, %1, %2 offset:256 sc1" ::"v"(ovoff), "v"(o1), "s"(obase) : "memory");
+          // non-temporal: the 1.8 GB of modulations of a launch are next read by the step chain's LayerNorms, evaluations later;
+          // streamed past the caches they leave the operand tiles (105 MB of weights, the activation rows) where they are.
+          // MI355X, one launch every 15 ms: 842 us against 954 with `sc1` (write-through, kept out of the L2s only), 970 plain
+          asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(ovoff), "v"(o0), "s"(obase) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, %2 offset:256 nt" ::"v"(ovoff), "v"(o1), "s"(obase) : "memory");
 #endif
         }
         obase += ostep;
