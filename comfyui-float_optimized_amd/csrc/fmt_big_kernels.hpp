@@ -13,8 +13,8 @@
 //     WITHOUT scratch (a reload is a vector-memory operation);
 //   * tile order: an XCD's 32 workgroups hold 8 row blocks x 4 column blocks at any time (82 % L2 hits).
 // Bitwise the numbers of fmt_gemm_dma_kernel (the same MFMA sequence per output element, one bias add).  MI355X, 9 000 x 51 200
-// x 1 024, one launch every 15 ms: 943 us against 1 100 for fmt_gemm_dma_kernel; sustained loops 934 against 1 083, both at the
-// socket's 1 400-W cap (1.97 GHz); without its stores 746 us = 0.51 of 2.5 PFLOP/s.
+// x 1 024, one launch every 15 ms: 842 us (943 with `sc1` stores) against 1 100 for fmt_gemm_dma_kernel; sustained loops 885 (934)
+// against 1 083, at the socket's 1 400-W cap (1.97 GHz); without its stores 746 us = 0.51 of 2.5 PFLOP/s.
 #pragma once
 #include "fmt_rb_kernels.hpp"
 
