@@ -94,8 +94,8 @@ __device__ __forceinline__ void fmt_gemm_body(const GemmArgs& g, const unsigned 
       const float* gt = g.gate + (size_t)row * g.ldg + nb;
       res_pf[0] = fh_load_f4<COH>(o);
       res_pf[1] = fh_load_f4<COH>(o + 4);
-      gate_pf[0] = *reinterpret_cast<const float4*>(gt);
-      gate_pf[1] = *reinterpret_cast<const float4*>(gt + 4);
+      gate_pf[0] = fh_load_f4_stream(gt);
+      gate_pf[1] = fh_load_f4_stream(gt + 4);
     }
   }
 
@@ -251,7 +251,7 @@ __device__ __forceinline__ void fmt_gemm_body(const GemmArgs& g, const unsigned 
             gg = gate_pf[e / 4];
           } else {
             x = fh_load_f4<COH>(o + e);
-            gg = *reinterpret_cast<const float4*>(gt + e);
+            gg = fh_load_f4_stream(gt + e);
           }
           x.x += gg.x * v[e + 0];
           x.y += gg.y * v[e + 1];
@@ -731,8 +731,8 @@ __device__ __forceinline__ void fmt_lnmod_body(float* __restrict__ x, int M, con
   for (int i = 0; i < NV; ++i) {
     const int c = i * 256 + lane * 4;
     v[i] = fh_load_f4<COH>(xr + c);
-    a[i] = *reinterpret_cast<const float4*>(sh + c);
-    b[i] = *reinterpret_cast<const float4*>(sc + c);
+    a[i] = fh_load_f4_stream(sh + c);
+    b[i] = fh_load_f4_stream(sc + c);
   }
   if (KS == 0 && touch) fmt_touch(pf, bid & 7, tfirst, tstride, touched);  // behind the row's own loads (in-order retirement)
   if constexpr (KS > 0) {
@@ -741,8 +741,12 @@ __device__ __forceinline__ void fmt_lnmod_body(float* __restrict__ x, int M, con
     for (int i = 0; i < NV; ++i) {
       const int c = i * 256 + lane * 4;
 #pragma unroll
-      for (int k = 0; k < KS; ++k) p[k][i] = fh_load_f4<COH>(red.slab + k * red.slab_stride + (size_t)row * D + c);
-      gt[i] = *reinterpret_cast<const float4*>(red.gate + (size_t)row * ldm + c);
+      for (int k = 0; k < KS; ++k) {
+        const float* ps = red.slab + k * red.slab_stride + (size_t)row * D + c;
+        if constexpr (COH) p[k][i] = fh_load_f4<true>(ps);
+        else p[k][i] = fh_load_f4_stream(ps);  // the slab's only read
+      }
+      gt[i] = fh_load_f4_stream(red.gate + (size_t)row * ldm + c);
       bi[i] = *reinterpret_cast<const float4*>(red.bias + c);
     }
     if (touch) fmt_touch(pf, bid & 7, tfirst, tstride, touched);
