@@ -53,7 +53,7 @@ class FloatHotPath:
         """An FMT handle whose workspace holds `n_clips` stacked clips (float_fmt_sample_batch), built on first use from the
         same weights and cached: the default handle is sized for ONE clip (3.1 GB of workspace per clip).  Up to
         FLOAT_AMD_FMT_MAX_BATCH (default 16, the operator's limit: 50 GB of workspace of the 288) clips per chain; larger
-        batches run in chunks of that size.  Per clip the chain costs 80 / 55 / 39 / 31 / 28 ms at 1 / 2 / 4 / 8 / 16 clips."""
+        batches run in chunks of that size.  Per clip the chain costs 79 / 52 / 36 / 28 / 24 ms at 1 / 2 / 4 / 8 / 16 clips."""
         cap = max(1, min(16, int(os.environ.get("FLOAT_AMD_FMT_MAX_BATCH", "16"))))
         mb = min(cap, max(1, int(n_clips)))
         if mb <= self.fmt.max_batch:
