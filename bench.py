@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--no-s2e", action="store_true", help="skip the measurement with the speech-emotion model in the step "
                     "(emotion='none', the reference's default widget: wav2vec2-large classifier on the clip's audio)")
     ap.add_argument("--no-variants", action="store_true", help="skip the literal nfe=50 run, the run from host inputs and the batches")
+    ap.add_argument("--no-clock-sample", action="store_true", help="skip the rocm-smi sample of the delivered clock / power (3 s of extra steps)")
     ap.add_argument("--batches", default="4,8,16", help="stacked-clip throughput runs (value_batchB), comma separated; empty = none")
     return ap.parse_args()
 
@@ -450,6 +451,42 @@ def main():
                     r_["frac_measured"] = round(r_["achieved"] / pk, 4)
         except Exception as e:  # the probe needs 4 GiB of scratch; the line is valid without it
             warnings.append("float_probe_peaks failed: %s" % e)
+        # Shader clock and socket power the board DELIVERS under the step (outside the timed region: a few more steps run while
+        # `rocm-smi` is asked from a side thread).  2.5 PFLOP/s is the MFMA rate at 2.4 GHz; profiles/r05_clock_power.txt has the
+        # same sample under each kernel class (the adaLN GEMM alone sits at the socket's power cap, 1.92-1.97 GHz).
+        if product and not args.no_clock_sample:
+            try:
+                import re
+                import subprocess
+                import threading
+                samples, stop = [], threading.Event()
+
+                def sampler():
+                    while not stop.is_set():
+                        try:
+                            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                        except Exception:  # noqa: BLE001
+                            return
+                        m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+                        w = re.search(r"Power \(W\): ([\d.]+)", out)
+                        if m:
+                            samples.append((int(m.group(1)), float(w.group(1)) if w else None))
+                th = threading.Thread(target=sampler, daemon=True)
+                t_end = time.perf_counter() + 3.0
+                step()
+                th.start()
+                while time.perf_counter() < t_end:
+                    step()
+                stop.set()
+                th.join(timeout=15)
+                samples = [x for x in samples if x[0] > 500]  # a sample that fell between two steps reads the idle clock
+                if samples and "device" in extra:
+                    extra["device"]["sclk_MHz_under_step"] = [min(x[0] for x in samples), max(x[0] for x in samples)]
+                    pw = [x[1] for x in samples if x[1] is not None]
+                    if pw:
+                        extra["device"]["power_W_under_step"] = [min(pw), max(pw)]
+            except Exception as e:  # noqa: BLE001  (no rocm-smi on the box: the line is valid without the sample)
+                warnings.append("clock sample failed: %s" % (str(e).splitlines()[0][:120],))
         roofs = sorted([(gemm_total_ms, gemm_roof), (conv_total_ms, conv_roof)] + ([(mod_total_ms, mod_roof)] if mod_roof else []),
                        key=lambda x: -x[0])
         roof = [r for _, r in roofs]

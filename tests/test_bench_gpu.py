@@ -37,6 +37,8 @@ def test_single_gpu_line_has_the_contract_fields():
     assert "workload" in r["config"] and "pinned host memory" in r["config"]["workload"]
     # value is the end-to-end rate: frames / wall of the timed steps
     assert abs(r["value"] - 50 * r["steps"] / (r["ms_per_step"] * r["steps"] * 1e-3)) < 0.01 * r["value"]
+    clk = r["device"].get("sclk_MHz_under_step")  # rocm-smi from a side thread, outside the timed region; absent without rocm-smi
+    assert clk is None or (500 < clk[0] <= clk[1] < 3000), clk
     rb = r["roofline_batch"]
     assert rb["bound"] == "mfma" and rb["batch"] == 8 and rb["launches"] > 0 and abs(rb["frac"] - rb["achieved"] / rb["peak"]) < 1e-3
     ro = r["roofline"]
