@@ -99,18 +99,19 @@ def process_img(img_hwc, input_size, margin=1.6, index=1, logger=None):
     H, Wd = int(img_hwc.shape[0]), int(img_hwc.shape[1])
     mult = 360.0 / H
     bboxes = None
-    try:
-        import face_alignment  # noqa: F401  (optional)
+    fa = None
+    try:  # ANY failure to obtain a detector (package absent, a stub or broken install, model files unreachable) takes the
+        fa = _face_detector()  # reference's no-face branch below instead of failing the node at its default face_align=True
+    except Exception as e:  # noqa: BLE001
+        if logger is not None:
+            logger.warning("face_align=True, but no face detector is available (%s: %s): no face detection, the centre square "
+                           "of the image is used (install face_alignment for the reference's crop)" % (type(e).__name__, e))
+    if fa is not None:
         import numpy as np
-        fa = _face_detector()
         small = F.interpolate(img_hwc.permute(2, 0, 1)[None], scale_factor=mult, mode="area" if mult < 1.0 else "bicubic")
         small = (small[0].permute(1, 2, 0).clamp(0, 1) * 255).round().to(torch.uint8).cpu().numpy()
         det = fa.face_detector.detect_from_image(np.ascontiguousarray(small))
         bboxes = [(int(x1 / mult), int(y1 / mult), int(x2 / mult), int(y2 / mult), sc) for (x1, y1, x2, y2, sc) in (det or []) if sc > 0.95]
-    except ImportError:
-        if logger is not None:
-            logger.warning("face_align=True, but the `face_alignment` package is not installed: no face detection, "
-                           "the centre square of the image is used (install face_alignment for the reference's crop)")
     if not bboxes:
         if bboxes is not None and logger is not None:
             logger.warning("Failed to detect any face in the image, no face align performed")

@@ -257,6 +257,7 @@ class InferenceAgent:
         host = self.G.generate_to_host(c["r_s"], c["wa"], c["we"], c["s_r"], None, self.opt.nfe, a_cfg_scale, r_cfg_scale,
                                        e_cfg_scale, noise=noise, out=out)
         torch.cuda.current_stream(self.rank).synchronize()  # the frames are in host memory
+        self.G.release_host_inflight()
         if self.check_range("InferenceAgent.infer_device", allow_rebuild=True) == "rebuilt":
             return self.infer_device(s, a, a_cfg_scale, r_cfg_scale, e_cfg_scale, emo, seed, out)  # once more, in the wider types
         return host
@@ -332,6 +333,7 @@ class InferenceAgent:
             self.G.dec.set_feats16(feats[i], self.enc.dtype)
             out.append(self.G.decode_to_host(conds[i]["s_r"], r_d[i]))
         torch.cuda.current_stream(self.rank).synchronize()
+        self.G.release_host_inflight()
         self.check_range("InferenceAgent.infer_device_batch")
         return out
 

@@ -117,12 +117,15 @@ def test_other_temporal_structures(n_prev, n_cur, window):
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
-@pytest.mark.parametrize("B,dynamic,rcfg", [(2, False, False), (4, True, False), (3, False, True), (4, False, False), (8, False, False)])
+@pytest.mark.parametrize("B,dynamic,rcfg", [(2, False, False), (4, True, False), (3, False, True), (4, False, False), (8, False, False),
+                                            (13, False, False), (16, False, False), (10, False, True), (16, True, False)])
 def test_batched_sampling_equals_per_clip(B, dynamic, rcfg, dtype):
     """float_fmt_sample_batch: B clips stacked along the rows of ONE launch chain (nodes_vadv.py:618-735 takes batches).  Each
     clip must be what the one-clip chain gives for it - within rounding, the GEMM tilings depend on the row count - and
     within the operand type's tolerance of the oracle; 70 frames = 2 windows, so the per-clip AR hand-off, replicate pad and
-    (dynamic) prev_we are covered."""
+    (dynamic) prev_we are covered.  B = 13 / 16 (3-way CFG: 2 340 / 2 880 rows) and B = 10 with 4-way CFG (2 400 rows) run
+    tier 3 of `pick_rb` (csrc/fmt_api.hip: 192 x 128 tiles for all four layers, fc2 as 2 K slices) - the default cap of
+    FLOAT Process batches (pipeline.py) and bench.py's value_batch16."""
     sd = pkg.weights.synth_fmt_state(CFG, seed=41)
     one = pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", dtype)
     many = pkg.fmt.FlowMatchingTransformerHIP(sd, CFG, "cuda:0", dtype, max_batch=B)

@@ -78,3 +78,23 @@ def test_batched_and_runge_kutta_fp32():
     got = fmt.sample(cs[0]["r_s"], cs[0]["wa"], cs[0]["we"], noise[:, :1], 3).cpu()
     ref = O.sample_rd(sd, cfg, cs[0]["r_s"], cs[0]["wa"], cs[0]["we"], noise[:, :1], 3, 2.0, 1.0, 1.0, method="rk4")
     assert rel_l2(got, ref) < TOL
+
+
+def test_stacked_chain_of_13_clips_fp32():
+    """Tier 3 of `pick_rb` (>= 2 200 rows: 13 clips x 180 rows = 2 340) at reference precision: the row-blocked 192 x 128 tiles,
+    fc2 as 2 K slices folded by the next LayerNorm - every clip against the oracle at the fp32 limit (FLOAT.py:215 batch;
+    nodes.py:189-209 per-item loop)."""
+    cfg = C.FmtConfig()
+    B = 13
+    sd, fmt = _fmt(cfg, 93, max_batch=B)
+    cs = [pkg.pipeline.synth_conditions(cfg, 70, seed=120 + q) for q in range(B)]
+    noise = pkg.fmt.draw_noise(2, B, cfg, seed=15)
+    cat = lambda k: torch.cat([c[k] for c in cs])  # noqa: E731
+    got = fmt.sample(cat("r_s"), cat("wa"), cat("we"), noise, 4, 2.0, 1.0, 1.0).cpu()
+    assert torch.equal(got, fmt.sample(cat("r_s"), cat("wa"), cat("we"), noise, 4, 2.0, 1.0, 1.0).cpu())
+    errs = []
+    for q in (0, 6, 12):
+        ref = O.sample_rd(sd, cfg, cs[q]["r_s"], cs[q]["wa"], cs[q]["we"], noise[:, q:q + 1], 4, 2.0, 1.0, 1.0)
+        errs.append(rel_l2(got[q:q + 1], ref))
+    print("13 stacked clips, fp32 mode, rel-L2 vs the oracle:", " ".join("%.1e" % e for e in errs))
+    assert max(errs) < TOL

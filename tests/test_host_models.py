@@ -49,6 +49,29 @@ def test_face_crop_fallback_is_the_reference_no_face_branch():
     assert same.shape == (64, 64, 3) and bbox == (0, 0, 64, 64)
 
 
+def test_face_crop_falls_back_when_the_detector_cannot_be_built(monkeypatch):
+    """An importable but unusable `face_alignment` (a stub left in sys.modules, a broken install, unreachable model files) must
+    take the reference's no-face branch with a warning (utils/image.py:151-158), not crash FLOAT Process at its default
+    face_align=True."""
+    import logging
+    import sys
+    import types
+    monkeypatch.setitem(sys.modules, "face_alignment", types.ModuleType("face_alignment"))  # no FaceAlignment attribute
+    monkeypatch.setattr(hm, "_FA", None)
+    seen = []
+
+    class H(logging.Handler):
+        def emit(self, rec):
+            seen.append(rec.getMessage())
+    log = logging.getLogger("test_face_crop")
+    log.addHandler(H())
+    img = torch.rand(720, 800, 3)
+    crop, bbox = hm.process_img(img, 360, logger=log)
+    want = torch.nn.functional.adaptive_avg_pool2d(img[:, 40:760].permute(2, 0, 1)[None], (360, 360))[0].permute(1, 2, 0)
+    assert bbox == (40, 0, 720, 720) and torch.allclose(crop, want, atol=1e-6)
+    assert seen and "no face detector is available" in seen[0]
+
+
 def test_emotion_labels_follow_label2id_get():
     assert hm.emotion_index("Happy") == 3 and hm.emotion_index("neutral") == 4
     for other in (None, "none", "S2E", "s2e", "joyful"):

@@ -152,3 +152,28 @@ def test_float_process_batch_runs_stacked_chains(pipe, monkeypatch):
         assert psnr >= 45.0
     print("B = 4, 25 frames each: batched %.1f ms, per-item loop %.1f ms (%.2fx)" % (t_b * 1e3, t_l * 1e3, t_b / t_l))
     assert t_b < t_l  # isolated: 60 vs 95 ms; inside the whole suite the margin shrinks (host-side wall clocks of 100-frame calls)
+
+
+def test_float_process_batch_of_16_runs_tier3_chain(pipe, monkeypatch):
+    """16 items x 25 frames through FloatProcess (nodes.py:189-209): ONE stacked chain of 16 x 180 = 2 880 rows, i.e. tier 3 of
+    `pick_rb` (csrc/fmt_api.hip) - the default cap of FLOAT_AMD_FMT_MAX_BATCH.  Every item against the per-item loop at the fp16
+    limit of the path (>= 45 dB), the range counters silent, and the stacked handle really sized for 16."""
+    g = torch.Generator().manual_seed(5)
+    img, audio = _inputs()
+    imgs = torch.cat([img, torch.rand(15, 512, 512, 3, generator=g)])
+    node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    monkeypatch.setattr(pipe.opt, "nfe", 11)
+    batched, _, _ = node.floatprocess(imgs, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    batched = batched.clone()
+    assert pipe.G.batched_fmt(16).max_batch == 16
+    monkeypatch.setenv("FLOAT_AMD_BATCH_CLIPS", "0")
+    looped, _, _ = node.floatprocess(imgs, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    assert batched.shape == looped.shape == (400, 512, 512, 3)
+    worst = 99.0
+    for i in range(16):
+        mse = float(((batched[i * 25:(i + 1) * 25] - looped[i * 25:(i + 1) * 25]) ** 2).mean())
+        psnr = 99.0 if mse == 0 else -10 * torch.log10(torch.tensor(mse)).item()
+        worst = min(worst, psnr)
+        assert psnr >= 45.0, (i, psnr)
+    print("16 items x 25 frames: batched vs per-item loop, worst item %.1f dB" % worst)
+    assert sum(pipe.G.range_counts().values()) == 0

@@ -582,7 +582,7 @@ def gen_emotion(ns, tag, cfg, seed, seconds):
     import importlib
     from transformers import Wav2Vec2Model
     print("[speech emotion %s]" % tag)
-    ser = importlib.import_module("floatref.src.nodes.models.wav2vec2_ser")
+    ser = ref_import.import_ref("src.nodes.models.wav2vec2_ser")
     sd = weights.synth_audio_state(cfg, seed=seed)
     hf = cfg.to_hf()
     hf.final_dropout = 0.0
@@ -610,7 +610,7 @@ def gen_node_surface(ns):
     st = _sys.modules["seconohe.torch"]
     st.model_to_target = lambda logger, model: contextlib.nullcontext()
     import importlib
-    nodes = importlib.import_module("floatref.src.nodes.nodes")
+    nodes = ref_import.import_ref("src.nodes.nodes")
     adv = ns.nodes_adv
 
     def contract(cls):
@@ -672,7 +672,7 @@ def gen_node_surface_va(ns):
         return o
     out = {}
     for m in ("nodes_vadv_loader", "nodes_vadv"):
-        mod = importlib.import_module("floatref.src.nodes." + m)
+        mod = ref_import.import_ref("src.nodes." + m)
         for name in dir(mod):
             c = getattr(mod, name)
             if isinstance(c, type) and hasattr(c, "UNIQUE_NAME") and c.__module__ == mod.__name__:

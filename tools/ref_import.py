@@ -97,12 +97,32 @@ def _install_stubs():
 
         _mod("torchdiffeq", odeint=odeint)
 
-    for name in ("cv2", "librosa", "face_alignment"):
+    for name in _EMPTY_STUBS:
         if name not in sys.modules:
             _mod(name)
+            _installed_empty.append(name)
 
 
+# Empty stand-ins that only have to exist while the reference modules are imported (`import cv2` at module scope).  They
+# are taken out of sys.modules again at the end of load(): code this tool does not own (the product's optional
+# `import face_alignment`) must see the package as absent, not as an importable module without attributes.
+_EMPTY_STUBS = ("cv2", "librosa", "face_alignment")
+_installed_empty = []
 _loaded = {}
+
+
+def import_ref(name):
+    """importlib.import_module("floatref." + name) for a reference module imported after load() (tools/make_goldens.py): the
+    empty stand-ins exist for the duration of the import only."""
+    load()
+    added = [n for n in _EMPTY_STUBS if n not in sys.modules]
+    for n in added:
+        _mod(n)
+    try:
+        return importlib.import_module("floatref." + name)
+    finally:
+        for n in added:
+            sys.modules.pop(n, None)
 
 
 def load():
@@ -136,5 +156,7 @@ def load():
     except Exception as e:  # pragma: no cover - optional
         ns.FLOAT = None
         ns.FLOAT_error = e
+    while _installed_empty:
+        sys.modules.pop(_installed_empty.pop(), None)
     _loaded["ns"] = ns
     return ns
