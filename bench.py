@@ -68,6 +68,10 @@ def parse():
                     "(emotion='none', the reference's default widget: wav2vec2-large classifier on the clip's audio)")
     ap.add_argument("--no-variants", action="store_true", help="skip the literal nfe=50 run, the run from host inputs and the batches")
     ap.add_argument("--no-clock-sample", action="store_true", help="skip the rocm-smi sample of the delivered clock / power (3 s of extra steps)")
+    ap.add_argument("--overlap", default=None, help="prio | cu:N: decode window k on a second stream beside the FMT chain of window "
+                    "k + 1 (FLOAT_AMD_OVERLAP; pipeline.generate_to_host_overlap).  Default: the product's default (sequential)")
+    ap.add_argument("--quick", action="store_true", help="only the headline measurement (A/B runs): no extras / roofline / "
+                    "CPU baseline / bf16 / s2e / variants")
     ap.add_argument("--batches", default="4,8,16", help="stacked-clip throughput runs (value_batchB), comma separated; empty = none")
     return ap.parse_args()
 
@@ -197,6 +201,10 @@ def cpu_baseline(pkg, torch, cfg, fmt_sd, dec_sd, feats, cond, nfe_evals):
 
 def main():
     args = parse()
+    if args.quick:
+        args.no_extras = args.no_roofline = args.no_cpu_baseline = args.no_bf16 = args.no_s2e = args.no_variants = True
+    if args.overlap is not None:
+        os.environ["FLOAT_AMD_OVERLAP"] = args.overlap
     if os.environ.get("FLOAT_BENCH_WATCHDOG"):  # debugging aid: dump every thread's stack and exit after that many seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["FLOAT_BENCH_WATCHDOG"]), exit=True)
@@ -653,6 +661,8 @@ def main():
                        "decode_batch": args.max_frames, "hip_graph": not args.no_graph, "parallelism": par},
         }
         out.update(extra)
+        out["config"]["stage_overlap"] = os.environ.get("FLOAT_AMD_OVERLAP", "") or "off"
+        out["frames_sha1"] = hashlib.sha1(host[::7].contiguous().numpy().tobytes()).hexdigest()[:16]  # bitwise identity of A/B runs
         out["host_threads_per_rank"] = host_threads if world > 1 else torch.get_num_threads()
         out["rccl_ranks"] = rccl_ranks  # ranks as counted by an RCCL all_reduce of ones (None: no RCCL communicator in this run)
         out["fp16_range_hits"] = sum(range_hits.values())

@@ -290,9 +290,10 @@ int pack_styled(DevicePool* pool, const TensorTable& tt, const std::string& p, i
 
 // dynamic LDS above the 64 KiB default: 64 KiB per workgroup with 16-bit operands (2 workgroups per CU), twice that in the
 // fp32 verification mode (the z tile of dec_zblur_kernel: 32 x 32 x 128 B)
+static int env_int(const char* name, int dflt, int lo, int hi);
 template <class T>
 int raise_lds_limits() {
-  const int lim = 32 * 1024 * T::EB;
+  const int lim = std::max(32 * 1024 * T::EB, env_int("FLOAT_DEC_LDS_PAD", 0, 0, 160 * 1024));
 #define CONV16_ATTR(NTv, TYv, TXv) \
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, NTv, TYv, TXv>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3)
@@ -305,6 +306,9 @@ int raise_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zconv4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zblur_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flow_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flow_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flow_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipGetLastError();
   return FLOAT_OK;
 }
@@ -452,6 +456,11 @@ static int env_int(const char* name, int dflt, int lo, int hi) {  // tuning knob
   const long x = strtol(v, &end, 10);
   return (end && *end == 0 && x >= lo && x <= hi) ? (int)x : dflt;
 }
+// FLOAT_DEC_LDS_PAD=<bytes>: every launch of the level kernels (3x3 conv, up-conv + blur, flow) asks for at least that much dynamic
+// LDS, i.e. the decoder's occupancy is capped (82 000: ONE workgroup per CU instead of two - room for a 98-KB workgroup of the FMT
+// chain beside it when the two stages overlap on two streams, pipeline.generate_to_host_overlap).  0 = off.
+static const int kLdsPad = env_int("FLOAT_DEC_LDS_PAD", 0, 0, 160 * 1024);
+static inline size_t dec_smem(size_t need) { return std::max(need, (size_t)kLdsPad); }
 static const unsigned kRideWgs = (unsigned)env_int("FLOAT_DEC_RIDE_WGS", 16, 0, 64) / 8 * 8;
 static const int kRideMinRes = env_int("FLOAT_DEC_RIDE_MIN_RES", 64, 64, 512);
 static const unsigned kRidePace = (unsigned)env_int("FLOAT_DEC_RIDE_PACE", 3, 0, 64);
@@ -601,8 +610,8 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
       }                                                                                                           \
     }                                                                                                             \
     if (!db) {                                                                                                    \
-      if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, e0, e1, 0, g); \
-      else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), smem, st, g);                \
+      if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), dec_smem(smem), st, e0, e1, 0, g); \
+      else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), dec_smem(smem), st, g);     \
     }                                                                                                             \
   }
     CONV16(4, 3, 3) CONV16(2, 3, 3)
@@ -668,8 +677,8 @@ int launch_upconv(float_dec* h, const Styled& up, int Ri, int n, const void* x_i
       grid = dim3(z.ngroups * z.ncb + z.ct.nwg, 1);
     }
     const size_t smem = 32 * 32 * RB;
-    if (prof) hipExtLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, e0, e1, 0, z);
-    else hipLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), smem, st, z);
+    if (prof) hipExtLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), dec_smem(smem), st, e0, e1, 0, z);
+    else hipLaunchKernelGGL((dec_zblur_kernel<T>), grid, dim3(256), dec_smem(smem), st, z);
     *U_out = Zb;
     FH_CHECK_HIP(hipGetLastError());
     return FLOAT_OK;
@@ -732,9 +741,11 @@ int launch_flow(float_dec* h, FlowArgs g, hipStream_t st) {
   g.band_pix = ((R * R + bx - 1) / bx + step - 1) / step * step;
   g.nbands = bx = (R * R + g.band_pix - 1) / g.band_pix;
   if (h) g.ct = take_ride(h, R, 2);
-  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
-  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
-  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n + g.ct.nwg), dim3(256), 0, st, g);
+  // dynamic LDS only as an occupancy cap (FLOAT_DEC_LDS_PAD); the kernel's own 14 KB are static
+  const size_t pad = kLdsPad > 14 * 1024 ? (size_t)kLdsPad - 14 * 1024 : 0;
+  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n + g.ct.nwg), dim3(256), pad, st, g);
+  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n + g.ct.nwg), dim3(256), pad, st, g);
+  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n + g.ct.nwg), dim3(256), pad, st, g);
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }

@@ -901,6 +901,7 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
 
   P8 ra[NA], rb[NB];
   float4 re = float4{0.f, 0.f, 0.f, 0.f};
+  bool first = true;
   auto issue = [&]() {
     const unsigned edge = (sty == 0 ? 1u : 0u) | (sty == g.tiles_y - 1 ? 2u : 0u) | (stx == 0 ? 4u : 0u) | (stx == g.tiles_x - 1 ? 8u : 0u);
     s_edge = edge;
@@ -914,7 +915,12 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
 #pragma unroll
       for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const P8*>(Xo + (((s_hit >> (4 * i)) & 15u) ? a_safe : a_off[i]));
     }
+#ifdef DEC_DIAG_WSTAGE1  // timing-only build (WRONG frames): the weight slab is fetched and staged for the workgroup's first item only -
+    // the ceiling of any weight-stationary form of this kernel
+    if (first) {
+#else
     if (nchunks > 1 || schunk == 0) {
+#endif
       const unsigned char* const Wc = Wn + (size_t)(schunk << 5) * EB;
 #pragma unroll
       for (int i = 0; i < NB - 1; ++i) rb[i] = *reinterpret_cast<const P8*>(Wc + i * b_round + b_off);
@@ -944,7 +950,6 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
 
   f32x4 acc[4][NT];
   int chunk = 0;
-  bool first = true;
   issue();
   DEC_PH(8);
   if constexpr (DB) {
@@ -1089,7 +1094,11 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
 #pragma unroll
         for (int i = 0; i < NA; ++i) *reinterpret_cast<P8*>(sA + a_lds[i]) = ((s_hit >> (4 * i)) & 15u) ? T::zero8() : ra[i];
       }
+#ifdef DEC_DIAG_WSTAGE1
+      if (first) {
+#else
       if (nchunks > 1 || first) {
+#endif
 #pragma unroll
         for (int i = 0; i < NB - 1; ++i) *reinterpret_cast<P8*>(sB + b_lds + i * 64 * RB) = rb[i];
         *reinterpret_cast<P8*>(sB + b_lds_l) = rb[NB - 1];

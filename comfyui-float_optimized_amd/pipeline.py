@@ -151,6 +151,64 @@ class FloatHotPath:
         host = self.decode_to_host(s_r, r_d, None, frame_range, out)
         return (host, r_d) if return_rd else host
 
+    def _overlap_streams(self, mode):
+        """(chain stream, decoder stream) of the stage-overlapped form.  mode "prio": two streams of one device queue set, the
+        chain on the higher priority; "cu:N": disjoint CU sets (hipExtStreamCreateWithCUMask), the decoder on the last N CUs."""
+        cache = self.__dict__.setdefault("_ov_streams", {})
+        if mode not in cache:
+            dev = self.device
+            if mode.startswith("cu:"):
+                n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+                n_dec = max(8, min(n_cu - 8, int(mode[3:])))
+                with torch.cuda.device(dev):
+                    cache[mode] = (native.cu_range_stream(0, n_cu - n_dec, dev), native.cu_range_stream(n_cu - n_dec, n_cu, dev))
+            elif mode == "prio":
+                lo, hi = torch.cuda.Stream.priority_range()  # (least, greatest): greatest priority = the smaller number
+                cache[mode] = (torch.cuda.Stream(dev, priority=hi), torch.cuda.Stream(dev, priority=lo))
+            else:
+                raise ValueError("overlap mode must be 'prio' or 'cu:N', got %r" % (mode,))
+        return cache[mode]
+
+    @torch.no_grad()
+    def generate_to_host_overlap(self, r_s, wa, we, s_r, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, noise=None,
+                                 out=None, mode="prio", return_rd=False):
+        """generate_to_host with the two stages pipelined (FLOAT.py runs 209-253 then 113-169; here window k is decoded and
+        handed to the host on a second stream while the chain samples window k + 1).  Same kernels on the same operands as
+        the sequential order, per-window decode batches (50 frames = 32 + 18 instead of 250 = 7 x 32 + 26): frames bitwise
+        equal to generate_to_host (decode batching does not change a frame, tests/test_dec_gpu.py).  FLOAT_AMD_OVERLAP
+        selects it in InferenceAgent.infer_device; what it measures against the sequential order: DESIGN.md section 7."""
+        T = wa.shape[1]
+        dev = self.device
+        if noise is None:
+            noise = draw_noise(self.n_chunks(T), 1, self.cfg, 15)
+        s_fmt, s_dec = self._overlap_streams(mode)
+        cur = torch.cuda.current_stream(dev)
+        s_fmt.wait_stream(cur)
+        s_dec.wait_stream(cur)
+        inflight = self.__dict__.setdefault("_host_inflight", [])
+        inflight[:] = [(t, e) for t, e in inflight if not e.query()]
+        if out is None:
+            out = torch.empty((T, self.size, self.size, 3), dtype=torch.float32, pin_memory=True)
+        staging = self.staging(T)
+        s_r_d = s_r.to(dev, torch.float32).reshape(-1).contiguous()
+        with torch.cuda.stream(s_fmt):
+            ws = WindowSampler(self.fmt, r_s, wa, we, noise, nfe, a_cfg_scale, r_cfg_scale, e_cfg_scale)
+        while ws.left > 0:
+            with torch.cuda.stream(s_fmt):
+                _, (f0, f1) = ws.next()
+                ev = torch.cuda.Event()
+                ev.record(s_fmt)
+            with torch.cuda.stream(s_dec):
+                s_dec.wait_event(ev)
+                self.dec.decode_into_host(s_r_d, ws.r_d[0, f0:f1], out[f0:f1], staging[f0:f1])
+        cur.wait_stream(s_dec)
+        cur.wait_stream(s_fmt)
+        done = torch.cuda.Event()
+        done.record(cur)
+        inflight.append((out, done))
+        self._last_job = ws  # the job's tensors were allocated on the side streams: alive until the caller has synchronised
+        return (out, ws.r_d) if return_rd else out
+
     @torch.no_grad()
     def generate(self, r_s, wa, we, s_r, feats, nfe, a_cfg_scale=2.0, r_cfg_scale=1.0, e_cfg_scale=1.0, seed=15,
                  noise=None, overlap=False, frame_range=None, return_rd=False):

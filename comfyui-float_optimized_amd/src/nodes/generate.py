@@ -254,8 +254,13 @@ class InferenceAgent:
         c = self.conditions_device(s, a, emo)  # encoder kernels enqueued; nothing below waits for them on the host
         n_chunks = int(math.ceil(c["T"] / self.cfg.num_frames_for_clip))
         noise = self._noise_to_device(n_chunks, seed if seed is not None else self.opt.seed)
-        host = self.G.generate_to_host(c["r_s"], c["wa"], c["we"], c["s_r"], None, self.opt.nfe, a_cfg_scale, r_cfg_scale,
-                                       e_cfg_scale, noise=noise, out=out)
+        ov = os.environ.get("FLOAT_AMD_OVERLAP", "")  # "prio" | "cu:N": decode window k beside the chain of window k + 1 (pipeline.py)
+        if ov and ov != "0":
+            host = self.G.generate_to_host_overlap(c["r_s"], c["wa"], c["we"], c["s_r"], self.opt.nfe, a_cfg_scale, r_cfg_scale,
+                                                   e_cfg_scale, noise=noise, out=out, mode=ov)
+        else:
+            host = self.G.generate_to_host(c["r_s"], c["wa"], c["we"], c["s_r"], None, self.opt.nfe, a_cfg_scale, r_cfg_scale,
+                                           e_cfg_scale, noise=noise, out=out)
         torch.cuda.current_stream(self.rank).synchronize()  # the frames are in host memory
         self.G.release_host_inflight()
         if self.check_range("InferenceAgent.infer_device", allow_rebuild=True) == "rebuilt":
