@@ -25,6 +25,7 @@ struct Level {  // ToFlow + ToRGB of one resolution
   float* lin = nullptr;  // [R] np.linspace(-1, 1, R) as float32
   int style_off = 0;
   void* feat = nullptr;  // [R][R][C] T::elem
+  float* grgb = nullptr;  // [R][R][4]: ToRGB's conv of `feat` (dec_feat_rgb_kernel, refreshed whenever the features are set)
   float upk_flow[8], upk_rgb[8];  // per-axis taps of the two Upsamples (upsample_taps)
 };
 
@@ -306,9 +307,10 @@ int raise_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zconv4_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_zblur_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flow_kernel<T, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flow_kernel<T, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flow_kernel<T, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+#define FLOW_ATTR(PIXv, LASTv) \
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flow_kernel<T, PIXv, LASTv>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  FLOW_ATTR(4, false) FLOW_ATTR(2, false) FLOW_ATTR(1, false) FLOW_ATTR(4, true) FLOW_ATTR(2, true) FLOW_ATTR(1, true)
+#undef FLOW_ATTR
   (void)hipGetLastError();
   return FLOAT_OK;
 }
@@ -384,6 +386,7 @@ int create_impl(float_dec* h, const TensorTable& tt) {
     for (int i = 0; i < L.C; ++i) bm_host.push_back(fmb->data[i]);
     wm_rows.insert(wm_rows.end(), fmw->data, fmw->data + (size_t)L.C * sdim);
     if ((rc = alloc_elem<T>(&h->pool, &L.feat, (size_t)L.R * L.R * L.C))) return rc;
+    if ((rc = h->pool.alloc(&L.grgb, (size_t)L.R * L.R * 4, true))) return rc;
     {
       // np.linspace(-1, 1, R): start + i*step in float64, last element forced to stop, cast to f32
       std::vector<float> lin(L.R);
@@ -743,9 +746,14 @@ int launch_flow(float_dec* h, FlowArgs g, hipStream_t st) {
   if (h) g.ct = take_ride(h, R, 2);
   // dynamic LDS only as an occupancy cap (FLOAT_DEC_LDS_PAD); the kernel's own 14 KB are static
   const size_t pad = kLdsPad > 14 * 1024 ? (size_t)kLdsPad - 14 * 1024 : 0;
-  if (pix == 4) hipLaunchKernelGGL((dec_flow_kernel<T, 4>), dim3(bx * n + g.ct.nwg), dim3(256), pad, st, g);
-  else if (pix == 2) hipLaunchKernelGGL((dec_flow_kernel<T, 2>), dim3(bx * n + g.ct.nwg), dim3(256), pad, st, g);
-  else hipLaunchKernelGGL((dec_flow_kernel<T, 1>), dim3(bx * n + g.ct.nwg), dim3(256), pad, st, g);
+  const dim3 grid(bx * n + g.ct.nwg);
+#define FLOW_LAUNCH(PIXv)                                                                                  \
+  if (g.xnext) hipLaunchKernelGGL((dec_flow_kernel<T, PIXv, false>), grid, dim3(256), pad, st, g);         \
+  else hipLaunchKernelGGL((dec_flow_kernel<T, PIXv, true>), grid, dim3(256), pad, st, g);
+  if (pix == 4) { FLOW_LAUNCH(4) }
+  else if (pix == 2) { FLOW_LAUNCH(2) }
+  else { FLOW_LAUNCH(1) }
+#undef FLOW_LAUNCH
   FH_CHECK_HIP(hipGetLastError());
   return FLOAT_OK;
 }
@@ -783,6 +791,7 @@ int run_level(float_dec* h, int li, int n, const void* x_in, void* Zb, void* U, 
   g.sflow = styles + L.style_off;
   g.bflow = L.bflow;
   g.wrgb = L.wrgb;
+  g.grgb = L.grgb;
   g.b1 = L.b1;
   g.b2 = L.b2;
   g.lin = L.lin;
@@ -982,6 +991,19 @@ int frames_impl(float_dec* h, const float* s_r, const float* r_d, int n_frames, 
   return FLOAT_OK;
 }
 
+// G = ToRGB(features) of every level, after the features changed
+template <class T>
+int feats_rgb_impl(float_dec* h, hipStream_t st) {
+  for (int li = 0; li < h->n_levels; ++li) {
+    const Level& L = h->levels[li];
+    const int npix = L.R * L.R;
+    hipLaunchKernelGGL((dec_feat_rgb_kernel<T>), dim3((npix + 255) / 256), dim3(256), 0, st, L.grgb,
+                       reinterpret_cast<const typename T::elem*>(L.feat), L.wrgb, L.C, npix);
+  }
+  FH_CHECK_HIP(hipGetLastError());
+  return FLOAT_OK;
+}
+
 template <class T>
 int set_feats_impl(float_dec* h, const float* const* feats, hipStream_t st) {
   for (int li = 0; li < h->n_levels; ++li) {
@@ -991,7 +1013,7 @@ int set_feats_impl(float_dec* h, const float* const* feats, hipStream_t st) {
                        feats[li], L.C, L.R * L.R, h->sat + 33);
   }
   FH_CHECK_HIP(hipGetLastError());
-  return FLOAT_OK;
+  return feats_rgb_impl<T>(h, st);
 }
 
 // Run `call` with T = the handle's operand type.
@@ -1139,6 +1161,10 @@ int unit_flow_level(const float_dec_unit_t* cfg, const TensorTable& tt, const fl
     if ((rc = u.pool.alloc(&pr, (size_t)F * Rp * Rp * 4, true))) return rc;
     hipLaunchKernelGGL(dec_dbg_pyr_kernel, dim3((F * Rp * Rp + 255) / 256), dim3(256), 0, st, pr, prev_rgb, F, Rp * Rp, 0);
   }
+  float* G;
+  if ((rc = u.pool.alloc(&G, (size_t)R * R * 4, true))) return rc;
+  hipLaunchKernelGGL((dec_feat_rgb_kernel<T>), dim3((R * R + 255) / 256), dim3(256), 0, st, G, Ft, wrgb, C, R * R);
+  g.grgb = G;
   g.x = X;
   g.feat = Ft;
   g.pflow = pf;
@@ -1246,6 +1272,8 @@ int float_dec_set_feats16(float_dec_t* h, const void* const* feats16, int32_t n_
     int rc = fh_copy_d2d(L.feat, feats16[li], (size_t)L.R * L.R * L.C * eb, st);
     if (rc) return rc;
   }
+  int rc = DEC_DISPATCH(h->cfg.dtype, feats_rgb_impl<T>(h, st));
+  if (rc) return rc;
   h->feats_set = true;
   return FLOAT_OK;
 }

@@ -348,6 +348,7 @@ struct FlowArgs {
   const float* sflow;  // [F][ld_s] style of the ToFlow conv (offset applied)
   const float* bflow;  // [3]
   const float* wrgb;   // [3][C], already * 1/sqrt(C)
+  const float* grgb;   // [R][R][4]: ToRGB's 1x1 conv applied to the skip features themselves (dec_feat_rgb_kernel, once per clip)
   const float* b1;     // [3] FusedLeakyReLU bias
   const float* b2;     // [3] ToRGB bias
   const float* snext;  // [F][ld_s] or nullptr
@@ -449,7 +450,13 @@ __device__ __forceinline__ FlowFrame<T> dec_flow_frame(const FlowArgs& g, int f)
   return ff;
 }
 
-template <class T, int PIX>
+// ToRGB without a channel loop (round 6).  ToRGB's conv is an UNMODULATED 1x1 conv of the warped features, and the warp is
+// linear in the features: conv(mask * sum_t bil_t feat[tap_t]) = sum_t (mask bil_t) conv(feat)[tap_t].  conv(feat) =: G does not
+// depend on the frame - it is formed once per clip (dec_feat_rgb_kernel, [R][R][4] fp32) and the pixel's owner lane blends four
+// 16-byte taps of it: 12 FMAs per pixel where every lane of the pixel spent 24 FMAs + a cross-lane reduction, in fp32 from
+// fp32 sums (the old order rounded nothing either; the two differ by summation order only).  LAST (no next level: xnext ==
+// nullptr) needs the warped features for nothing else, so the last level gathers no features at all.
+template <class T, int PIX, bool LAST>
 __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFrame<T>& ff, const float* __restrict__ sw, int p0, int sub,
                                                 int lpp, const typename T::pack8 (&xu)[PIX], unsigned& sm) {
   typedef typename T::pack8 P8;
@@ -504,7 +511,9 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
     // and the kernel is VALU-bound).
     float mask[PIX], wg[PIX][4];
     unsigned fo[PIX][4];
-    P8 fu[PIX][4];
+    P8 fu[LAST ? 1 : PIX][4];
+    float4 gt[4];  // owner lane: the four taps of G = ToRGB(features) of its pixel
+    float gw[4];
     {
       const int ks = sub & (PIX - 1);
       float f0 = o[0][0], f1 = o[0][1], f2 = o[0][2];
@@ -523,7 +532,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
       const int x0 = (int)fx0, y0 = (int)fy0;  // |ix| <= R + 1: tanh bounds the sample position
       const float axk = ix - fx0, ayk = iy - fy0;
       float own_w[4];
-      unsigned own_o[4];
+      unsigned own_o[4], own_p[4];
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -532,40 +541,42 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
           const int yy = y0 + a, xx = x0 + b;
           const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
           const int yc = min(max(yy, 0), R - 1), xc = min(max(xx, 0), R - 1);
-          own_o[a * 2 + b] = (unsigned)((yc * R + xc) * C) * EB;  // bytes
+          own_p[a * 2 + b] = (unsigned)(yc * R + xc);
+          own_o[a * 2 + b] = own_p[a * 2 + b] * (unsigned)C * EB;  // bytes
           own_w[a * 2 + b] = (a ? ayk : 1.f - ayk) * (b ? axk : 1.f - axk) * mk * (in ? 1.f : 0.f);
         }
-      const int gb = (int)(threadIdx.x & 63) - sub;  // first lane of this pixel group
+      // lanes sub >= PIX hold a copy of pixel sub & (PIX - 1): a valid address, the value is dropped
 #pragma unroll
-      for (int k = 0; k < PIX; ++k) {
-        mask[k] = __shfl(mk, gb + k, 64);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          wg[k][t] = __shfl(own_w[t], gb + k, 64);
-          fo[k][t] = (unsigned)__shfl((int)own_o[t], gb + k, 64);
-        }
+      for (int t = 0; t < 4; ++t) {
+        gt[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const unsigned char*>(g.grgb) + own_p[t] * 16u);
+        gw[t] = own_w[t];
       }
+      if constexpr (!LAST) {
+        const int gb = (int)(threadIdx.x & 63) - sub;  // first lane of this pixel group
 #pragma unroll
-      for (int k = 0; k < PIX; ++k)
+        for (int k = 0; k < PIX; ++k) {
+          mask[k] = __shfl(mk, gb + k, 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) fu[k][t] = dec_load8_b<T>(g.feat, fo[k][t] + cb0);
+          for (int t = 0; t < 4; ++t) {
+            wg[k][t] = __shfl(own_w[t], gb + k, 64);
+            fo[k][t] = (unsigned)__shfl((int)own_o[t], gb + k, 64);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < PIX; ++k)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fu[k][t] = dec_load8_b<T>(g.feat, fo[k][t] + cb0);
+      }
     }
     float upr[3] = {0.f, 0.f, 0.f};
     if (ff.prgb && owner) up2_tap3(ff.prgb, 0, Rp, Y, X0 + sub, upr, g.upk_rgb);
-    float rgb[PIX][3];
+    if constexpr (!LAST) {
 #pragma unroll
-    for (int k = 0; k < PIX; ++k) {
-      float fw[8];  // the warped, masked features: sum over the 4 taps of weight * feature
-      dec_scale8<T>(fw, fu[k][0], wg[k][0]);
+      for (int k = 0; k < PIX; ++k) {
+        float fw[8];  // the warped, masked features: sum over the 4 taps of weight * feature
+        dec_scale8<T>(fw, fu[k][0], wg[k][0]);
 #pragma unroll
-      for (int t = 1; t < 4; ++t) dec_axpy8<T>(fw, fu[k][t], wg[k][t]);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const float4 w0 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0);
-        const float4 w1 = *reinterpret_cast<const float4*>(sw + (3 + j) * C + c0 + 4);
-        rgb[k][j] = w0.x * fw[0] + w0.y * fw[1] + w0.z * fw[2] + w0.w * fw[3] + w1.x * fw[4] + w1.y * fw[5] + w1.z * fw[6] + w1.w * fw[7];
-      }
-      if (ff.xnext) {
+        for (int t = 1; t < 4; ++t) dec_axpy8<T>(fw, fu[k][t], wg[k][t]);
         const float4 n0 = *reinterpret_cast<const float4*>(sw + 6 * C + c0);
         const float4 n1 = *reinterpret_cast<const float4*>(sw + 6 * C + c0 + 4);
         const float sn[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
@@ -576,23 +587,20 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
         dec_store8_b<T>(ff.xnext, (unsigned)((p0 + k) * C) * EB + cb0, dec_pack8<T>(ov, sm));
       }
     }
-    for (int d = 1; d < lpp; d <<= 1) {
-#pragma unroll
-      for (int k = 0; k < PIX; ++k) {
-        rgb[k][0] += __shfl_xor(rgb[k][0], d, 64);
-        rgb[k][1] += __shfl_xor(rgb[k][1], d, 64);
-        rgb[k][2] += __shfl_xor(rgb[k][2], d, 64);
-      }
-    }
     if (owner) {
-      // this lane's pixel: select its sums out of the unrolled arrays
-      float r0 = rgb[0][0], r1 = rgb[0][1], r2 = rgb[0][2], f0 = o[0][0], f1 = o[0][1], f2 = o[0][2];
+      // ToRGB's conv of the warped features = the four taps of G blended with the (masked) bilinear weights
+      float r0 = gw[0] * gt[0].x, r1 = gw[0] * gt[0].y, r2 = gw[0] * gt[0].z;
+#pragma unroll
+      for (int t = 1; t < 4; ++t) {
+        r0 += gw[t] * gt[t].x;
+        r1 += gw[t] * gt[t].y;
+        r2 += gw[t] * gt[t].z;
+      }
+      // this lane's pixel: select its flow sums out of the unrolled arrays
+      float f0 = o[0][0], f1 = o[0][1], f2 = o[0][2];
 #pragma unroll
       for (int k = 1; k < PIX; ++k)
         if (sub == k) {
-          r0 = rgb[k][0];
-          r1 = rgb[k][1];
-          r2 = rgb[k][2];
           f0 = o[k][0];
           f1 = o[k][1];
           f2 = o[k][2];
@@ -1720,10 +1728,10 @@ __global__ __launch_bounds__(256) void dec_blur_kernel(const typename T::elem* _
 // per-frame folded weights (flow conv * style, rgb conv, next style: 7 x C floats) live in LDS, not in
 // registers, which keeps the kernel at <=128 VGPRs (4 waves per SIMD) - the first version held them in
 // 56 registers per lane and ran at ONE wave per SIMD (r01 PMC: waves parked 56 % of their life).
-template <class T, int PIX>
+template <class T, int PIX, bool LAST>
 __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
-  __shared__ __attribute__((aligned(16))) float sw[7 * 512];  // [wf0 wf1 wf2 | wr0 wr1 wr2 | sn][C]
+  __shared__ __attribute__((aligned(16))) float sw[7 * 512];  // [wf0 wf1 wf2 | (unused since round 6: ToRGB reads G) | sn][C]
   const int C = g.C;
   const int lpp = C >> 3;            // lanes per pixel (4..64)
   const int gpb = 256 / lpp;         // lane groups per block
@@ -1750,7 +1758,6 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       sw[j * C + c] = g.wflow[j * C + c] * s;
-      sw[(3 + j) * C + c] = g.wrgb[j * C + c];
     }
     sw[6 * C + c] = g.snext ? g.snext[(size_t)f * g.ld_s + c] : 0.f;
   }
@@ -1764,10 +1771,31 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     typename T::pack8 xu[PIX];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) xu[k] = dec_load8_b_nt<T>(xf, (unsigned)(((p0 + k) * C + c0) * T::EB));  // read once: leave L2 to the features
-    dec_flow_pixels<T, PIX>(g, ff, sw, p0, sub, lpp, xu, sm);
+    dec_flow_pixels<T, PIX, LAST>(g, ff, sw, p0, sub, lpp, xu, sm);
   }
   dec_sat_flush<T>(g.sat, sm);
   DEC_STAMP_MAX(3);
+}
+
+// G = ToRGB's 1x1 conv (styledecoder.py:368-386: unmodulated, weight / sqrt(C) folded into wrgb) applied to a level's skip
+// features, once per clip: G[p][j] = sum_c wrgb[j][c] * feat[p][c], fp32, 4 floats per pixel (one 16-byte tap for dec_flow_kernel).
+template <class T>
+__global__ __launch_bounds__(256) void dec_feat_rgb_kernel(float* __restrict__ out, const typename T::elem* __restrict__ feat,
+                                                           const float* __restrict__ wrgb, int C, int npix) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= npix) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+  for (int c = 0; c < C; c += 8) {
+    const typename T::pack8 v = T::load8(feat + (size_t)p * C + c);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float x = T::get(v, i);
+      a0 += wrgb[c + i] * x;
+      a1 += wrgb[C + c + i] * x;
+      a2 += wrgb[2 * C + c + i] * x;
+    }
+  }
+  *reinterpret_cast<float4*>(out + (size_t)p * 4) = float4{a0, a1, a2, 0.f};
 }
 
 // Encoder skip feature NCHW fp32 -> NHWC 16-bit (once per clip).

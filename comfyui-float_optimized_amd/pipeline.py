@@ -162,9 +162,10 @@ class FloatHotPath:
                 n_dec = max(8, min(n_cu - 8, int(mode[3:])))
                 with torch.cuda.device(dev):
                     cache[mode] = (native.cu_range_stream(0, n_cu - n_dec, dev), native.cu_range_stream(n_cu - n_dec, n_cu, dev))
-            elif mode == "prio":
+            elif mode in ("prio", "plain"):
                 lo, hi = torch.cuda.Stream.priority_range()  # (least, greatest): greatest priority = the smaller number
-                cache[mode] = (torch.cuda.Stream(dev, priority=hi), torch.cuda.Stream(dev, priority=lo))
+                cache[mode] = ((torch.cuda.Stream(dev, priority=hi), torch.cuda.Stream(dev, priority=lo)) if mode == "prio" else
+                               (torch.cuda.Stream(dev), torch.cuda.Stream(dev)))
             else:
                 raise ValueError("overlap mode must be 'prio' or 'cu:N', got %r" % (mode,))
         return cache[mode]

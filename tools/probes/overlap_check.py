@@ -1,0 +1,28 @@
+"""Which part of the overlapped hand-over differs from the sequential order at full size (512 px, 250 frames, 50 evaluations)?
+r_d and per-window frames of generate_to_host_overlap against generate_to_host, per mode, several repetitions."""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from tests.util import load_pkg
+pkg = load_pkg()
+cfg = pkg.config.FmtConfig()
+hp = pkg.pipeline.FloatHotPath(pkg.weights.synth_fmt_state(cfg, seed=1), pkg.weights.synth_decoder_state(512, seed=1), cfg, "cuda:0", 512, max_frames=32)
+feats = pkg.weights.synth_feats(512, seed=1)
+T = 250
+c = pkg.pipeline.synth_conditions(cfg, T, seed=0, device="cuda:0")
+noise = pkg.fmt.draw_noise(5, 1, cfg, 15).to("cuda:0")
+a = (c["r_s"], c["wa"], c["we"], c["s_r"])
+nfe = int(sys.argv[1]) if len(sys.argv) > 1 else 51
+seq, rd = hp.generate_to_host(*a, feats, nfe, noise=noise, return_rd=True)
+torch.cuda.synchronize()
+seq, rd = seq.clone(), rd.clone()
+for mode in sys.argv[2:] or ["prio", "plain", "cu:64"]:
+    for rep in range(3):
+        t0 = time.perf_counter()
+        o, r = hp.generate_to_host_overlap(*a, nfe, noise=noise, mode=mode, return_rd=True)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        bad_rd = [k for k in range(5) if not torch.equal(r[0, k * 50:(k + 1) * 50], rd[0, k * 50:(k + 1) * 50])]
+        bad_fr = [k for k in range(5) if not torch.equal(o[k * 50:(k + 1) * 50], seq[k * 50:(k + 1) * 50])]
+        nbad = [int((o[k * 50:(k + 1) * 50] != seq[k * 50:(k + 1) * 50]).reshape(50, -1).any(1).sum()) for k in range(5)]
+        print(mode, rep, "%.1f ms" % ms, "r_d windows differing:", bad_rd, "frame windows differing:", bad_fr, "frames per window:", nbad, flush=True)
