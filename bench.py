@@ -126,6 +126,47 @@ def launch_ranks(n):
     sys.exit(0)
 
 
+def rendezvous_store(rank, world):
+    """The job's TCPStore (rank 0 hosts it unless a torchrun agent already does) with a roll call in front of
+    init_process_group: every rank signs in, rank 0 waits FLOAT_BENCH_RDZV_TIMEOUT seconds (default 180) for all of them and
+    otherwise says WHICH ranks never arrived and exits 3; the others exit 3 when rank 0's go-ahead does not come.  A hung
+    rendezvous of an 8-GPU run is then one readable line in the log, not a driver timeout."""
+    import datetime
+    import torch.distributed as dist
+    timeout = float(os.environ.get("FLOAT_BENCH_RDZV_TIMEOUT", "180"))
+    agent_store = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    try:
+        store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, is_master=(rank == 0 and not agent_store),
+                              timeout=datetime.timedelta(seconds=timeout), wait_for_workers=False)
+    except Exception as e:  # noqa: BLE001
+        sys.stderr.write("bench.py: rank %d could not reach the rendezvous store at %s:%s within %.0f s: %s\n"
+                         % (rank, os.environ.get("MASTER_ADDR"), os.environ.get("MASTER_PORT"), timeout, str(e).splitlines()[0][:200]))
+        sys.exit(3)
+    store.set("bench/here/%d" % rank, socket.gethostname())
+    if rank == 0:
+        t_end = time.time() + timeout
+        missing = list(range(world))
+        while missing and time.time() < t_end:
+            missing = [r for r in missing if not store.check(["bench/here/%d" % r])]
+            if missing:
+                time.sleep(0.2)
+        if missing:
+            sys.stderr.write("bench.py: rendezvous timed out after %.0f s: rank(s) %s of %d never arrived\n" % (timeout, missing, world))
+            store.set("bench/go", "abort")
+            sys.exit(3)
+        store.set("bench/go", "go")
+    else:
+        try:
+            store.wait(["bench/go"], datetime.timedelta(seconds=timeout))
+            ok = store.get("bench/go") == b"go"
+        except Exception:  # noqa: BLE001
+            ok = False
+        if not ok:
+            sys.stderr.write("bench.py: rank %d: no go-ahead from rank 0 within %.0f s (other ranks missing, or rank 0 died)\n" % (rank, timeout))
+            sys.exit(3)
+    return dist.PrefixStore("pg", store)
+
+
 class stdout_to_stderr:
     """RCCL prints a banner (ROCm version / hostname / library path) on the C-level stdout when the first communicator comes
     up; the driver reads ONE JSON line from this process's stdout, so file descriptor 1 points at stderr meanwhile."""
@@ -232,11 +273,12 @@ def main():
         # (also a one-rank launch by torchrun: its agent owns the store, a private tcp:// rendezvous would wait for ever)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        store = rendezvous_store(rank, world)  # exits non-zero, naming the ranks that never arrived, instead of hanging
         with stdout_to_stderr():
             if backend == "nccl":
-                dist.init_process_group("nccl", device_id=dev)
+                dist.init_process_group("nccl", store=store, rank=rank, world_size=world, device_id=dev)
             else:
-                dist.init_process_group(backend)
+                dist.init_process_group(backend, store=store, rank=rank, world_size=world)
         if dist.get_world_size() != world:
             raise RuntimeError("rendezvous gave %d ranks, expected %d" % (dist.get_world_size(), world))
     elif backend == "nccl" and os.environ.get("FLOAT_BENCH_RCCL1", "1") != "0":
@@ -357,6 +399,36 @@ def main():
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 seam[key] = float(t.item())
     host = last["host"]
+    per_rank = None
+    if world > 1:
+        # Every rank's own stage times (hipEvents, one more pass outside the timed region) and the latency of the job's one data-path
+        # collective - the boundary all_gather of 2 x 10 x 512 floats - so that the first multi-GPU run reads rank by rank
+        def ev_ms1(fn):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return out, round(e0.elapsed_time(e1), 3)
+        (s_r_, r_s_, wa_), t_cond = ev_ms1(conditioning)
+        r_d_, t_chain = ev_ms1(lambda: hp.sample(r_s_, wa_, we, args.nfe, a_cfg, 1.0, e_cfg, noise=noise))
+        _, t_dec = ev_ms1(lambda: hp.dec.decode_into_host(s_r_, r_d_[0, t0f:t1f], host, hp.staging(n_local)))
+        cdev = dev if backend == "nccl" else "cpu"
+        tail = torch.zeros(2, 10, 512, device=cdev)
+        gathered = [torch.empty_like(tail) for _ in range(world)]
+        dist.all_gather(gathered, tail)
+        barrier()
+        t_ag = time.perf_counter()
+        for _ in range(10):
+            dist.all_gather(gathered, tail)
+        if backend == "nccl":
+            torch.cuda.synchronize()
+        t_ag = (time.perf_counter() - t_ag) / 10
+        mine = {"rank": rank, "device": torch.cuda.get_device_properties(dev).name, "local_rank": local_rank, "frames": n_local,
+                "stage_ms": {"encoders": t_cond, "chain": t_chain, "decode_and_hand_over": t_dec},
+                "boundary_all_gather_us": round(t_ag * 1e6, 1), "host_threads": torch.get_num_threads()}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     assert host.shape[0] == n_local and host.is_pinned()
     assert float(host[0].min()) >= 0.0 and float(host[-1].max()) <= 1.0 and float(host.mean()) > 0.0
     # fp16 range: every timed clip went through agent.check_range in "raise" mode (product path); the operator-driven
@@ -468,11 +540,17 @@ def main():
                 import subprocess
                 import threading
                 samples, stop = [], threading.Event()
+                # rocm-smi numbers the physical GPUs: the bench device through HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES if they remap it
+                smi_index = dev.index or 0
+                vis = os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or ""
+                vis = [v.strip() for v in vis.split(",") if v.strip()]
+                if smi_index < len(vis) and vis[smi_index].isdigit():
+                    smi_index = int(vis[smi_index])
 
                 def sampler():
                     while not stop.is_set():
                         try:
-                            out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
+                            out = subprocess.run(["rocm-smi", "-d", str(smi_index), "--showclocks", "--showpower"], capture_output=True, text=True, timeout=10).stdout
                         except Exception:  # noqa: BLE001
                             return
                         m = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
@@ -488,6 +566,8 @@ def main():
                 stop.set()
                 th.join(timeout=15)
                 samples = [x for x in samples if x[0] > 500]  # a sample that fell between two steps reads the idle clock
+                if not samples:
+                    warnings.append("clock sample: rocm-smi -d %d gave no sample under the step (not installed, or no busy sample in 3 s)" % smi_index)
                 if samples and "device" in extra:
                     extra["device"]["sclk_MHz_under_step"] = [min(x[0] for x in samples), max(x[0] for x in samples)]
                     pw = [x[1] for x in samples if x[1] is not None]
@@ -663,6 +743,8 @@ def main():
         out.update(extra)
         out["config"]["stage_overlap"] = os.environ.get("FLOAT_AMD_OVERLAP", "") or "off"
         out["frames_sha1"] = hashlib.sha1(host[::7].contiguous().numpy().tobytes()).hexdigest()[:16]  # bitwise identity of A/B runs
+        if per_rank:
+            out["ranks"] = per_rank  # one entry per rank: its stage times, its all_gather latency (diagnosis of an N > 1 run)
         out["host_threads_per_rank"] = host_threads if world > 1 else torch.get_num_threads()
         out["rccl_ranks"] = rccl_ranks  # ranks as counted by an RCCL all_reduce of ones (None: no RCCL communicator in this run)
         out["fp16_range_hits"] = sum(range_hits.values())

@@ -60,6 +60,10 @@ struct float_dec {
   float *styles = nullptr, *demod = nullptr, *eps = nullptr;  // eps: [kStyleCap][16] = 1e-8 / (style normaliser)^2
   void *loA = nullptr, *loB = nullptr, *loZ = nullptr, *loX = nullptr;  // T::elem: low phase ping/pong/z + hand-over tensor
   void *hiA = nullptr, *hiB = nullptr, *hiZ = nullptr;
+  // last level with <= 64 channels (round 6): ToFlow's conv in conv2's epilogue (dec_conv16_kernel FLOWM) - its per-frame weight
+  // fragments and the [max_frames][size][size][4] sums that replace the stored V; FLOAT_DEC_FLOW_EPI=0 keeps dec_flow_kernel there
+  void* wfrag = nullptr;
+  float* oflow = nullptr;
   unsigned long long* sat = nullptr;  // [kDecSatSites] saturation counters (dec_kernels.hpp), device
   bool style_norm = true;
   float *loFlow[2] = {nullptr, nullptr}, *loRgb[2] = {nullptr, nullptr};
@@ -218,17 +222,20 @@ int upsample_taps(const TensorTable& tt, const std::string& key, float taps[8]) 
       amax = std::max(amax, fabs(v));
     }
   if (!(S > 1e-12)) {
-    fh_set_error("'%s' does not have a positive sum", key.c_str());
+    fh_set_error("'%s' sums to %.3g: the per-axis split K = ky (x) kx of the flow kernel needs a positive sum (INTEGRATION.md, "
+                 "'FIR buffers'); such an up-sampling kernel is not implemented", key.c_str(), S);
     return FLOAT_E_INVALID;
   }
   // K_ij = u_i v_j  =>  row sums u_i sum(v), column sums v_j sum(u), S = sum(u) sum(v): K_ij = r_i c_j / S
   const double rs = sqrt(S);
+  double resid = 0.0;
   for (int i = 0; i < 4; ++i)
-    for (int j = 0; j < 4; ++j)
-      if (fabs(kb->data[i * 4 + j] - r[i] * c[j] / S) > 1e-5 * amax) {
-        fh_set_error("'%s' is not a rank-1 kernel ky (x) kx (make_kernel's form); other up-sampling kernels are not implemented", key.c_str());
-        return FLOAT_E_INVALID;
-      }
+    for (int j = 0; j < 4; ++j) resid = std::max(resid, fabs(kb->data[i * 4 + j] - r[i] * c[j] / S));
+  if (resid > 1e-5 * amax) {
+    fh_set_error("'%s' is not a rank-1 kernel ky (x) kx (make_kernel's form): max |K - r c^T / sum| = %.3g against the limit 1e-5 * max|K| "
+                 "= %.3g; other up-sampling kernels are not implemented (INTEGRATION.md, 'FIR buffers')", key.c_str(), resid, 1e-5 * amax);
+    return FLOAT_E_INVALID;
+  }
   for (int i = 0; i < 4; ++i) {
     taps[i] = (float)(r[i] / rs);
     taps[4 + i] = (float)(c[i] / rs);
@@ -299,6 +306,9 @@ int raise_lds_limits() {
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, NTv, TYv, TXv>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   CONV16_ATTR(4, 3, 3) CONV16_ATTR(2, 3, 3)
 #undef CONV16_ATTR
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, 4, 3, 3, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, 2, 3, 3, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_flowlast_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
   if constexpr (!T::is32) {  // the double-buffered form (FLOAT_DEC_CONV_DB): two buffer sets, up to 115 KB
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, 4, 3, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(dec_conv16_kernel<T, 2, 3, 3, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -437,6 +447,14 @@ int create_impl(float_dec* h, const TensorTable& tt) {
   if ((rc = alloc_elem<T>(&h->pool, &h->hiA, FH * act_hi))) return rc;
   if ((rc = alloc_elem<T>(&h->pool, &h->hiB, FH * act_hi))) return rc;
   if ((rc = alloc_elem<T>(&h->pool, &h->hiZ, FH * act_hi))) return rc;
+  {
+    static const bool flow_epi = env_int("FLOAT_DEC_FLOW_EPI", 1, 0, 1) != 0;
+    const int cl = h->levels.back().C;
+    if (flow_epi && (cl == 32 || cl == 64) && size >= 16 && size % 16 == 0) {
+      if ((rc = alloc_elem<T>(&h->pool, &h->wfrag, FH * (size_t)(cl / 32) * (T::is32 ? 1 : 2) * 64 * 8))) return rc;
+      if ((rc = h->pool.alloc(&h->oflow, FH * (size_t)size * size * 4, true))) return rc;
+    }
+  }
   const size_t sk_lo = FL * 32 * 32 * 4, sk_hi = FH * (size_t)size * size * 4;  // flow / rgb pyramids: 4 floats per pixel
   for (int i = 0; i < 2; ++i) {
     if ((rc = h->pool.alloc(&h->loFlow[i], sk_lo, true))) return rc;
@@ -525,10 +543,13 @@ static const bool g_dec_cb_order = !(getenv("FLOAT_DEC_CB_ORDER") && atoi(getenv
 template <class T>
 int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, const void* Wt, int ntaps, const int* dy, const int* dx,
                 void* Y, int Ho, int Wo, int OH, int OW, int sy, int sx, int py, int px, int F, const float* demod, int ldd,
-                const float* bias, int act, const float* snext, int lds, unsigned long long* sat, hipStream_t st) {
+                const float* bias, int act, const float* snext, int lds, unsigned long long* sat, hipStream_t st,
+                const void* wfrag = nullptr, float* oflow = nullptr) {
   constexpr size_t RB = 32 * T::EB;
   ConvArgs g;
   memset(&g, 0, sizeof(g));
+  g.wfrag = wfrag;
+  g.oflow = oflow;
   g.sat = sat;
   g.X = X;
   g.Wt = Wt;
@@ -603,7 +624,8 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
     }
     // FLOAT_DEC_CONV_DB bit mask: 1 = double-buffered LDS for the 64-channel tiles, 2 = for the 32-channel tiles (A/B switch)
     static const int db_env = env_int("FLOAT_DEC_CONV_DB", 0, 0, 3);
-    const bool db = !T::is32 && ((bn == 64 && (db_env & 1)) || (bn == 32 && (db_env & 2)));
+    const bool db = !oflow && !T::is32 && ((bn == 64 && (db_env & 1)) || (bn == 32 && (db_env & 2)));
+    FH_REQUIRE(!oflow || s.cout == bn, "ToFlow epilogue needs the layer's %d output channels in one block of %d", s.cout, bn);
 #define CONV16(NTv, TYv, TXv)                                                                                    \
   if (bn == NTv * 16 && ty_taps == TYv && tx_taps == TXv) {                                                       \
     if constexpr (!T::is32) {                                                                                     \
@@ -612,7 +634,10 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
         else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv, 1>), grid, dim3(256), 2 * smem, st, g);      \
       }                                                                                                           \
     }                                                                                                             \
-    if (!db) {                                                                                                    \
+    if (!db && oflow) { /* ToFlow in the epilogue: the whole channel range in one block (cout == bn) */           \
+      if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv, 0, 1>), grid, dim3(256), dec_smem(smem), st, e0, e1, 0, g); \
+      else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv, 0, 1>), grid, dim3(256), dec_smem(smem), st, g); \
+    } else if (!db) {                                                                                             \
       if (prof) hipExtLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), dec_smem(smem), st, e0, e1, 0, g); \
       else hipLaunchKernelGGL((dec_conv16_kernel<T, NTv, TYv, TXv>), grid, dim3(256), dec_smem(smem), st, g);     \
     }                                                                                                             \
@@ -620,6 +645,7 @@ int launch_conv(float_dec* h, const void* X, int Hi, int Wi, const Styled& s, co
     CONV16(4, 3, 3) CONV16(2, 3, 3)
 #undef CONV16
   } else {
+    FH_REQUIRE(!oflow, "ToFlow epilogue: only on the 16x16-tile 3x3 kernel (%d x %d)", Ho, Wo);
     const size_t smem = (size_t)npix * RB + (size_t)ntaps * bn * RB;
     dim3 grid(g.tiles_x * g.tiles_y * fblocks, s.cout / bn);
     if (prof) {
@@ -732,6 +758,14 @@ int launch_upconv(float_dec* h, const Styled& up, int Ri, int n, const void* x_i
 // prologue (56 per-lane weight values) is amortised; one row of workgroups per frame.
 template <class T>
 int launch_flow(float_dec* h, FlowArgs g, hipStream_t st) {
+  if (g.oflow) {  // one lane per pixel (dec_flowlast_kernel)
+    const int runs = (g.R * g.R + 255) / 256;
+    if (h) g.ct = take_ride(h, g.R, 2);
+    const size_t lpad = (size_t)kLdsPad;
+    hipLaunchKernelGGL((dec_flowlast_kernel<T>), dim3(runs * g.F + g.ct.nwg), dim3(256), lpad, st, g);
+    FH_CHECK_HIP(hipGetLastError());
+    return FLOAT_OK;
+  }
   const int R = g.R, n = g.F;
   const int lpp = g.C / 8, gpb = 256 / lpp;
   static const int pix_env = env_int("FLOAT_DEC_FLOW_PIX", 0, 0, 4);  // tuning aid
@@ -775,10 +809,17 @@ int run_level(float_dec* h, int li, int n, const void* x_in, void* Zb, void* U, 
   // conv2 (plain 3x3); its unscaled output feeds ToFlow.  (Running the flow phase in conv2's epilogue at C <= 64 - the conv2
   // tile through LDS instead of memory, -33.6 MB per frame at 512 px - was built in round 2, was bitwise equal and slower:
   // 30.5-30.9 vs 26.2 ms per 250 frames; removed in round 3, see DESIGN.md "Negative results".)
-  if ((rc = launch_conv<T>(h, U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
-                           c2.abias, 1, nullptr, 0, h->sat + 2 + 2 * li, st)))
-    return rc;
   const bool last = (li == h->n_levels - 1);
+  // last level, <= 64 channels: ToFlow's conv rides in conv2's epilogue (V is not stored), dec_flowlast_kernel finishes the frame
+  const bool epi = last && h->oflow && R % 16 == 0 && R >= 16 && (c2.cout == 32 || c2.cout == 64) && L.C == c2.cout;
+  if (epi) {
+    typedef typename T::pack8 P8;
+    hipLaunchKernelGGL((dec_flowfrag_kernel<T>), dim3(n, c2.cout / 32), dim3(64), 0, st, reinterpret_cast<P8*>(h->wfrag), L.wflow,
+                       styles + L.style_off, h->Stot, L.C);
+  }
+  if ((rc = launch_conv<T>(h, U, R, R, c2, c2.W, 9, kDy9, kDx9, V, R, R, R, R, 1, 1, 0, 0, n, demod + c2.demod_off, h->Dtot,
+                           c2.abias, 1, nullptr, 0, h->sat + 2 + 2 * li, st, epi ? h->wfrag : nullptr, epi ? h->oflow : nullptr)))
+    return rc;
   FlowArgs g;
   memset(&g, 0, sizeof(g));
   g.x = V;
@@ -807,6 +848,7 @@ int run_level(float_dec* h, int li, int n, const void* x_in, void* Zb, void* U, 
   g.C = L.C;
   g.ld_s = h->Stot;
   g.sat = h->sat + 16 + li;
+  g.oflow = epi ? h->oflow : nullptr;
 #ifdef DEC_STAMPS
   if (last) {
     const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};

@@ -348,6 +348,7 @@ struct FlowArgs {
   const float* sflow;  // [F][ld_s] style of the ToFlow conv (offset applied)
   const float* bflow;  // [3]
   const float* wrgb;   // [3][C], already * 1/sqrt(C)
+  const float* oflow;  // dec_flowlast_kernel: [F][R][R][4] ToFlow's sums from conv2's epilogue (dec_conv16_kernel FLOWM)
   const float* grgb;   // [R][R][4]: ToRGB's 1x1 conv applied to the skip features themselves (dec_feat_rgb_kernel, once per clip)
   const float* b1;     // [3] FusedLeakyReLU bias
   const float* b2;     // [3] ToRGB bias
@@ -656,6 +657,9 @@ struct ConvArgs {
   // every released checkpoint runs); else four FMAs with the taps from here
   float fir[4];
   int fir_sym;
+  // dec_conv16_kernel<.., FLOWM = 1> (the LAST level's conv2): ToFlow's 1x1 conv in the epilogue, on the matrix pipe
+  const void* wfrag;  // [F][NT / 2][fp32: 1 | 16-bit: 2 (hi, lo * 2048)][64 lanes] T::pack8: dec_flowfrag_kernel
+  float* oflow;       // [F][OH][OW][4] fp32: sum_c wflow[j][c] s[f][c] V[c] (no bias) per pixel
 };
 
 // (tile group, output-channel block) of compute workgroup `bid`.  A layer with more than 32 output channels runs ncb workgroups
@@ -830,7 +834,13 @@ __global__ __launch_bounds__(256, T::is32 ? 1 : 2) void dec_conv_kernel(ConvArgs
 // i + 1 is written into the other buffer while item i is multiplied (the writes are spread between the three tap-column
 // groups of MFMAs), and the K loop has ONE barrier per item instead of two.  115 KB of LDS at 64 output channels: one
 // workgroup per CU instead of two.  Bitwise the same results.  MEASURED: see DESIGN.md section 7 (FLOAT_DEC_CONV_DB selects it).
-template <class T, int NT, int TY, int TX, int DB = 0>
+// FLOWM = 1 (round 6; the last level's conv2, whose output V feeds ToFlow and nothing else): V is never stored.  The epilogue's
+// values - rounded to the operand type exactly as the stored V was - are the B operand of one more MFMA per m-tile against
+// ToFlow's per-frame folded weights (A fragments from dec_flowfrag_kernel: row r holds output r & 3, so every lane group gets
+// the three sums of its pixel; 16-bit operands: weights as hi + lo * 2^-11, two MFMAs, exact products, i.e. fp32 weights as
+// before), and the lane that owns pixel (row w*4 + q, column r16) stores 16 bytes.  At 512 px that is 4 MB per frame written
+// and read back instead of 16.8 + 16.8, and the channel loop + cross-lane reduction of the flow kernel are gone.
+template <class T, int NT, int TY, int TX, int DB = 0, int FLOWM = 0>
 __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kernel(ConvArgs g) {
   DEC_COPY_PROLOGUE(g, bid)
   DEC_PH_BEGIN
@@ -910,6 +920,9 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
   P8 ra[NA], rb[NB];
   float4 re = float4{0.f, 0.f, 0.f, 0.f};
   bool first = true;
+  constexpr int NPK = NT / 2, NHL = T::is32 ? 1 : 2;  // FLOWM: weight fragments per frame (packs of 32 channels x (hi, lo))
+  static_assert(!FLOWM || (!DB && (NT == 2 || NT == 4)), "ToFlow epilogue: single-buffered kernel, 32 or 64 output channels");
+  P8 wa[FLOWM ? NPK : 1][NHL];
   auto issue = [&]() {
     const unsigned edge = (sty == 0 ? 1u : 0u) | (sty == g.tiles_y - 1 ? 2u : 0u) | (stx == 0 ? 4u : 0u) | (stx == g.tiles_x - 1 ? 8u : 0u);
     s_edge = edge;
@@ -1116,6 +1129,15 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
       __syncthreads();
       DEC_PH(9);
       if (item + 1 < nitems) issue();  // in flight while this item computes
+      if constexpr (FLOWM) {
+        if (chunk == nchunks - 1) {  // ToFlow's weight fragments of the tile's frame: in registers when the epilogue starts
+          const P8* const wf = reinterpret_cast<const P8*>(g.wfrag) + (size_t)cf * (NPK * NHL * 64) + lane;
+#pragma unroll
+          for (int pk = 0; pk < NPK; ++pk)
+#pragma unroll
+            for (int hl = 0; hl < NHL; ++hl) wa[pk][hl] = wf[(pk * NHL + hl) * 64];
+        }
+      }
       if (chunk == 0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -1187,8 +1209,10 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
         unsigned char* yt = reinterpret_cast<unsigned char*>(g.Y) +
                             ((((size_t)cf * g.OH + (size_t)cty * 16 * g.sy + g.py) * g.OW + (size_t)ctx * 16 * g.sx + g.px) * g.Cout + n0) * EB;
         unsigned sm = 0u;
+        f32x4 dh[FLOWM ? 4 : 1], dl[FLOWM ? 4 : 1];
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
+          float vv[NT * 4];
 #pragma unroll
           for (int j = 0; j < NT; ++j) {
             v2f v0 = v2f{acc[mt][j][0], acc[mt][j][1]} * ed[j][0] + eb[j][0];
@@ -1196,8 +1220,41 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
             const v2f l0 = slope * v0, l1 = slope * v1;
             v0 = v2f{__builtin_amdgcn_fmed3f(v0.x, l0.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v0.y, l0.y, __builtin_inff())} * es[j][0];
             v1 = v2f{__builtin_amdgcn_fmed3f(v1.x, l1.x, __builtin_inff()), __builtin_amdgcn_fmed3f(v1.y, l1.y, __builtin_inff())} * es[j][1];
-            dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + j * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
+            if constexpr (FLOWM) {
+              vv[j * 4] = v0.x;
+              vv[j * 4 + 1] = v0.y;
+              vv[j * 4 + 2] = v1.x;
+              vv[j * 4 + 3] = v1.y;
+            } else {
+              dec_store4<T>(reinterpret_cast<E*>(yt + mt * y_row + y_off + j * 16 * EB), v0.x, v0.y, v1.x, v1.y, sm);
+            }
           }
+          if constexpr (FLOWM) {
+            // K slot s of pack pk in lane group q <-> channel (2 pk + (s >> 2)) * 16 + q * 4 + (s & 3): the order dec_flowfrag_kernel packs
+            dh[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dl[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int pk = 0; pk < NPK; ++pk) {
+              const float v8[8] = {vv[pk * 8], vv[pk * 8 + 1], vv[pk * 8 + 2], vv[pk * 8 + 3], vv[pk * 8 + 4], vv[pk * 8 + 5], vv[pk * 8 + 6], vv[pk * 8 + 7]};
+              const P8 bp = dec_pack8<T>(v8, sm);  // the rounding (and range check) the stored V had
+              dh[mt] = T::mfma(wa[pk][0], bp, dh[mt]);
+              if constexpr (NHL == 2) dl[mt] = T::mfma(wa[pk][1], bp, dl[mt]);
+            }
+          }
+        }
+        if constexpr (FLOWM) {
+          // D[row 4 q' + i][pixel r16] = output i of m-tile mt's pixel, the same in every lane group q': lane (r16, q) keeps m-tile q
+          f32x4 oh = dh[0], ol = dl[0];
+#pragma unroll
+          for (int mt = 1; mt < 4; ++mt)
+            if (q == mt) {
+              oh = dh[mt];
+              ol = dl[mt];
+            }
+          float4 o4;
+          if constexpr (NHL == 2) o4 = float4{oh[0] + ol[0] * (1.f / 2048.f), oh[1] + ol[1] * (1.f / 2048.f), oh[2] + ol[2] * (1.f / 2048.f), 0.f};
+          else o4 = float4{oh[0], oh[1], oh[2], 0.f};
+          *reinterpret_cast<float4*>(g.oflow + ((((size_t)cf * g.OH + cty * 16 + w * 4 + q) * g.OW + ctx * 16 + r16) << 2)) = o4;
         }
         dec_sat_flush<T>(g.sat, sm);
         DEC_PH(11);
@@ -1774,6 +1831,113 @@ __global__ __launch_bounds__(256) void dec_flow_kernel(FlowArgs g) {
     dec_flow_pixels<T, PIX, LAST>(g, ff, sw, p0, sub, lpp, xu, sm);
   }
   dec_sat_flush<T>(g.sat, sm);
+  DEC_STAMP_MAX(3);
+}
+
+// A fragments of ToFlow's folded weights for dec_conv16_kernel<.., FLOWM = 1>: w[j][c] = wflow[j][c] * s[f][c] (styledecoder.py:
+// 399-425: a modulated 1x1 conv WITHOUT demodulation; wflow already / sqrt(C)).  Lane (row r = l & 15, group gq = l >> 4) of
+// pack pk holds output j = r & 3 (j == 3: zeros) at K slot s <-> channel (2 pk + (s >> 2)) * 16 + gq * 4 + (s & 3).  16-bit operand
+// types: two packs per (pk): hi = rnd(w), lo = rnd((w - hi) * 2048) - x * hi and x * lo are exact in the MFMA's fp32
+// accumulator, so the sum is the fp32-weight sum of the VALU kernel it replaces (the lo scale keeps it out of fp16's subnormals).
+template <class T>
+__global__ __launch_bounds__(64) void dec_flowfrag_kernel(typename T::pack8* __restrict__ out, const float* __restrict__ wflow,
+                                                          const float* __restrict__ sflow, int ld_s, int C) {
+  constexpr int NHL = T::is32 ? 1 : 2;
+  const int f = blockIdx.x, pk = blockIdx.y, l = threadIdx.x, r = l & 15, gq = l >> 4, j = r & 3;
+  float w[8], lo[8];
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) {
+    const int c = (2 * pk + (sl >> 2)) * 16 + gq * 4 + (sl & 3);
+    w[sl] = j < 3 ? wflow[j * C + c] * sflow[(size_t)f * ld_s + c] : 0.f;
+  }
+  typename T::pack8* const o = out + ((size_t)f * gridDim.y + pk) * NHL * 64 + l;
+  typename T::pack8 hi;
+#pragma unroll
+  for (int sl = 0; sl < 8; ++sl) T::set(hi, sl, w[sl]);
+  o[0] = hi;
+  if constexpr (NHL == 2) {
+    typename T::pack8 lp;
+#pragma unroll
+    for (int sl = 0; sl < 8; ++sl) {
+      lo[sl] = (w[sl] - T::get(hi, sl)) * 2048.f;
+      T::set(lp, sl, lo[sl]);
+    }
+    o[64] = lp;
+  }
+}
+
+// The last level after dec_conv16_kernel<.., FLOWM = 1>: one lane per pixel, no channels anywhere.  ToFlow's sums come from
+// g.oflow, the warped-and-converted features are four taps of G (dec_feat_rgb_kernel), the rest is dec_flow_pixels' owner-lane
+// arithmetic: + bias + Upsample(previous flow) -> tanh / sigmoid -> sample position -> ToRGB -> + Upsample(previous rgb) -> frame.
+template <class T>
+__global__ __launch_bounds__(256) void dec_flowlast_kernel(FlowArgs g) {
+  DEC_COPY_PROLOGUE(g, bid)
+  const int R = g.R, npix = R * R, Rp = R >> 1;
+  // block -> (frame, run of 256 pixels): all frames of a run back to back on one XCD (ids congruent mod 8), like dec_flow_kernel
+  const int runs = (npix + 255) >> 8;
+  int f, run;
+  if ((runs & 7) == 0) {
+    const int slot = (int)bid >> 3;
+    f = slot % g.F;
+    run = (slot / g.F) * 8 + ((int)bid & 7);
+  } else {
+    f = (int)bid / runs;
+    run = (int)bid % runs;
+  }
+  const int p = run * 256 + (int)threadIdx.x;
+  if (p >= npix) return;
+  const FlowFrame<T> ff = dec_flow_frame<T>(g, f);
+  const int Y = p / R, X = p - Y * R;
+  const float4 o = *reinterpret_cast<const float4*>(g.oflow + (((size_t)f * npix + p) << 2));
+  float upf[3] = {0.f, 0.f, 0.f};
+  if (ff.pflow) up2_tap3(ff.pflow, 0, Rp, Y, X, upf, g.upk_flow);
+  const float f0 = o.x + (upf[0] + ff.bf[0]), f1 = o.y + (upf[1] + ff.bf[1]), f2 = o.z + (upf[2] + ff.bf[2]);
+  const float fR = (float)R;
+  const float sx = fh_tanh_fast<T::is32>(f0) + g.lin[X], sy = fh_tanh_fast<T::is32>(f1) + g.lin[Y];
+  const float mk = fh_sigmoid_t<T::is32>(f2);
+  const float ix = ((sx + 1.f) * fR - 1.f) * 0.5f, iy = ((sy + 1.f) * fR - 1.f) * 0.5f;  // grid_sample, align_corners=False
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  const float axk = ix - fx0, ayk = iy - fy0;
+  float4 gt[4];
+  float gw[4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int yy = y0 + a, xx = x0 + b;
+      const bool in = yy >= 0 && yy < R && xx >= 0 && xx < R;
+      const int yc = min(max(yy, 0), R - 1), xc = min(max(xx, 0), R - 1);
+      gt[a * 2 + b] = *reinterpret_cast<const float4*>(g.grgb + ((size_t)(yc * R + xc) << 2));
+      gw[a * 2 + b] = (a ? ayk : 1.f - ayk) * (b ? axk : 1.f - axk) * mk * (in ? 1.f : 0.f);
+    }
+  float upr[3] = {0.f, 0.f, 0.f};
+  if (ff.prgb) up2_tap3(ff.prgb, 0, Rp, Y, X, upr, g.upk_rgb);
+  float r0 = gw[0] * gt[0].x, r1 = gw[0] * gt[0].y, r2 = gw[0] * gt[0].z;
+#pragma unroll
+  for (int t = 1; t < 4; ++t) {
+    r0 += gw[t] * gt[t].x;
+    r1 += gw[t] * gt[t].y;
+    r2 += gw[t] * gt[t].z;
+  }
+  const float v0 = fh_lrelu_s2(r0 + ff.b1[0]) + ff.b2[0] + upr[0], v1 = fh_lrelu_s2(r1 + ff.b1[1]) + ff.b2[1] + upr[1],
+              v2 = fh_lrelu_s2(r2 + ff.b1[2]) + ff.b2[2] + upr[2];
+  const unsigned po = (unsigned)p;
+  if (g.write_pyr) {
+    *reinterpret_cast<float4*>(ff.flow_out + po * 4u) = float4{f0, f1, f2, 0.f};
+    *reinterpret_cast<float4*>(ff.rgb_out + po * 4u) = float4{v0, v1, v2, 0.f};
+  }
+  if (g.final_mode == 1) {
+    typedef float f3v __attribute__((ext_vector_type(3)));
+    f3v o3 = {fminf(fmaxf(v0, -1.f), 1.f) * 0.5f + 0.5f, fminf(fmaxf(v1, -1.f), 1.f) * 0.5f + 0.5f,
+              fminf(fmaxf(v2, -1.f), 1.f) * 0.5f + 0.5f};
+    __builtin_memcpy(ff.final_hwc + po * 3u, &o3, 12);
+  } else if (g.final_mode == 2) {
+    float* fo = ff.final_chw + po;
+    fo[0] = v0;
+    fo[npix] = v1;
+    fo[2 * (size_t)npix] = v2;
+  }
   DEC_STAMP_MAX(3);
 }
 

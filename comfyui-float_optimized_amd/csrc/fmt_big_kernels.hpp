@@ -197,8 +197,13 @@ __global__ __launch_bounds__(256) void fmt_gemm_big4_kernel(BigArgs g) {
           // non-temporal: the 1.8 GB of modulations of a launch are next read by the step chain's LayerNorms, evaluations later;
           // streamed past the caches they leave the operand tiles (105 MB of weights, the activation rows) where they are.
           // MI355X, one launch every 15 ms: 842 us against 954 with `sc1` (write-through, kept out of the L2s only), 970 plain
+#ifdef BIG4_PLAIN_STORE
+          asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(ovoff), "v"(o0), "s"(obase) : "memory");
+          asm volatile("global_store_dwordx4 %0, %1, %2 offset:256" ::"v"(ovoff), "v"(o1), "s"(obase) : "memory");
+#else
           asm volatile("global_store_dwordx4 %0, %1, %2 nt" ::"v"(ovoff), "v"(o0), "s"(obase) : "memory");
           asm volatile("global_store_dwordx4 %0, %1, %2 offset:256 nt" ::"v"(ovoff), "v"(o1), "s"(obase) : "memory");
+#endif
 #endif
         }
         obase += ostep;
@@ -206,7 +211,11 @@ __global__ __launch_bounds__(256) void fmt_gemm_big4_kernel(BigArgs g) {
       }
     }
     load_bias(j + 1, bias_cur);  // 2 of the NST operations, behind the stores
+#ifdef BIG4_SAFE_EPI  // diagnostic: no store may be outstanding when the next tile's counted waits begin
+    if (true) {
+#else
     if (!whole) {
+#endif
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       extra = false;
     } else {

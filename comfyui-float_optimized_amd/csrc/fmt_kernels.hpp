@@ -723,8 +723,13 @@ __device__ __forceinline__ void fmt_lnmod_body(float* __restrict__ x, int M, con
     return;
   }
   float* xr = x + (size_t)row * D;
-  const float* sh = shift + (size_t)row * ldm;
-  const float* sc = scale + (size_t)row * ldm;
+#ifdef FMT_DIAG_HOTMOD  // timing-only build (WRONG results): every row reads the modulation row 0 - what the fp32 slab's reads cost
+  const size_t mrow = 0;
+#else
+  const size_t mrow = (size_t)row;
+#endif
+  const float* sh = shift + mrow * ldm;
+  const float* sc = scale + mrow * ldm;
   float4 v[NV], a[NV], b[NV];
   float s = 0.f;
 #pragma unroll
@@ -746,7 +751,7 @@ __device__ __forceinline__ void fmt_lnmod_body(float* __restrict__ x, int M, con
         if constexpr (COH) p[k][i] = fh_load_f4<true>(ps);
         else p[k][i] = fh_load_f4_stream(ps);  // the slab's only read
       }
-      gt[i] = fh_load_f4_stream(red.gate + (size_t)row * ldm + c);
+      gt[i] = fh_load_f4_stream(red.gate + mrow * ldm + c);
       bi[i] = *reinterpret_cast<const float4*>(red.bias + c);
     }
     if (touch) fmt_touch(pf, bid & 7, tfirst, tstride, touched);

@@ -46,6 +46,11 @@ def test_gpus_8_ranks_share_the_host(mode):
         if r["value"] >= one["value"] / limit:
             break
     assert r["n_gpus"] == 8 and r["host_threads_per_rank"] >= 1
+    # the line carries every rank's own stage times and its boundary all_gather latency (what the first 8-GPU run is read by)
+    assert [e["rank"] for e in r["ranks"]] == list(range(8))
+    for e in r["ranks"]:
+        assert e["frames"] == 50 and e["boundary_all_gather_us"] > 0
+        assert set(e["stage_ms"]) == {"encoders", "chain", "decode_and_hand_over"} and all(v > 0 for v in e["stage_ms"].values())
     assert wall < 300, wall
     assert r["config"]["frames_per_clip"] == (50 if mode == "replicas" else 400)
     # 8 ranks x 50 frames per step on one GPU against 50 frames per step of one rank.  In window mode a rank samples its one

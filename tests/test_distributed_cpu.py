@@ -10,7 +10,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import float_oracle as O
-from tests.util import load_pkg
+from tests.util import ROOT, load_pkg
 
 pkg = load_pkg()
 D = pkg.distributed
@@ -276,3 +276,32 @@ def test_window_parallel_seam_resolve(world):
             assert e_seam >= e_full - 1e-7
             if rank == 1:
                 assert e_full < 1e-5 and e1_seam < 1e-5
+
+
+def test_bench_rendezvous_names_the_missing_ranks():
+    """bench.py's roll call in front of init_process_group: with one of three ranks absent, rank 0 exits 3 within the timeout and
+    names the missing rank, the rank that did arrive exits 3 too; with everybody present all get a store."""
+    import socket
+    import subprocess
+    import sys
+
+    def free_port():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        p = s.getsockname()[1]
+        s.close()
+        return p
+    code = ("import os, sys; sys.path.insert(0, %r); import bench; "
+            "st = bench.rendezvous_store(int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])); st.set('ok', '1'); print('joined')" % ROOT)
+
+    def run(world, present, timeout):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(world),
+                   FLOAT_BENCH_RDZV_TIMEOUT=str(timeout))
+        ps = [subprocess.Popen([sys.executable, "-c", code], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+              for r in present]
+        return [(p.wait(timeout=120), p.stdout.read().decode(), p.stderr.read().decode()) for p in ps]
+    res = run(3, [0, 1], 6)
+    assert [r[0] for r in res] == [3, 3], res
+    assert "rank(s) [2] of 3 never arrived" in res[0][2] and "no go-ahead" in res[1][2]
+    res = run(2, [0, 1], 60)
+    assert [r[0] for r in res] == [0, 0] and all("joined" in r[1] for r in res), res

@@ -150,8 +150,10 @@ def test_float_process_batch_runs_stacked_chains(pipe, monkeypatch):
         psnr = 99.0 if mse == 0 else -10 * torch.log10(torch.tensor(mse)).item()
         print("item %d: batched vs per-item %.1f dB" % (i, psnr))
         assert psnr >= 45.0
+    # wall clocks are printed, not asserted (isolated: 60 vs 95 ms; a shared box moves them): what is asserted is the deterministic
+    # fact behind the speed-up - the batched call ran ONE stacked chain on a handle sized for the 4 items
     print("B = 4, 25 frames each: batched %.1f ms, per-item loop %.1f ms (%.2fx)" % (t_b * 1e3, t_l * 1e3, t_b / t_l))
-    assert t_b < t_l  # isolated: 60 vs 95 ms; inside the whole suite the margin shrinks (host-side wall clocks of 100-frame calls)
+    assert list(pipe.G.__dict__.get("_fmt_batched", {})) == [4] and pipe.G.batched_fmt(4).max_batch == 4
 
 
 def test_float_process_batch_of_16_runs_tier3_chain(pipe, monkeypatch):

@@ -32,6 +32,14 @@ int g_fh_profiling = 0;
   } while (0)
 static float h2f(u16 v) { return (float)__builtin_bit_cast(_Float16, v); }
 
+// BIG_STRESS=<mode>: the kernel on a high-priority stream BESIDE a bandwidth-bound kernel on a low-priority stream (round 6: under
+// FLOAT_AMD_OVERLAP=prio the FMT chain came out wrong from the second window on, and only with this kernel in it)
+__global__ __launch_bounds__(256) void hammer_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n, int lds_bytes) {
+  extern __shared__ unsigned char hl[];
+  if (lds_bytes && threadIdx.x == 0) hl[0] = 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 int main(int argc, char** argv) {
   const int steps = argc > 1 ? atoi(argv[1]) : 50, rows = argc > 2 ? atoi(argv[2]) : 180;
   const int M = steps * rows, N = 51200, K = 1024, KB = K / 32;
@@ -92,6 +100,47 @@ int main(int argc, char** argv) {
   float tail;
   CK(hipMemcpy(&tail, dout + (size_t)M * N + 5, 4, hipMemcpyDeviceToHost));
   printf("big kernel check: rel-L2 %.2e max %.2e bad %d; row M untouched: %s\n", std::sqrt(num / den), mx, bad, std::isnan(tail) || Mp == M ? "yes" : "NO");
+  if (const char* e = getenv("BIG_STRESS")) {
+    const int mode = atoi(e);  // 1: priorities, 2: two plain streams; BIG_STRESS_LDS = dynamic LDS bytes of the other kernel
+    const int hlds = getenv("BIG_STRESS_LDS") ? atoi(getenv("BIG_STRESS_LDS")) : 0;
+    int lo = 0, hi = 0;
+    CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    hipStream_t sh, sl;
+    CK(hipStreamCreateWithPriority(&sh, hipStreamNonBlocking, mode == 1 ? hi : lo));
+    CK(hipStreamCreateWithPriority(&sl, hipStreamNonBlocking, lo));
+    uint4 *hs, *hd;
+    const size_t hn = (size_t)1 << 26;  // 1 GiB each
+    CK(hipMalloc(&hs, hn * 16));
+    CK(hipMalloc(&hd, hn * 16));
+    CK(hipMemset(hs, 1, hn * 16));
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(hammer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int rep = 0; rep < 4; ++rep) {
+      CK(hipMemset(dout, 0xff, out_rows * N * 4));
+      CK(hipDeviceSynchronize());
+      for (int i = 0; i < 40; ++i) hipLaunchKernelGGL(hammer_kernel, dim3(2048), dim3(256), hlds, sl, hs, hd, hn, hlds);
+      usleep(2000);
+      hipLaunchKernelGGL(kern, dim3(grid), dim3(NTHR), smem, sh, g);
+      CK(hipDeviceSynchronize());
+      std::mt19937 r3(11 + rep);
+      int nbad = 0;
+      double worst = 0;
+      for (int t = 0; t < 3000; ++t) {
+        int row = (int)(r3() % M), n = (int)(r3() % N);
+        float got;
+        CK(hipMemcpy(&got, dout + (size_t)row * N + n, 4, hipMemcpyDeviceToHost));
+        double ref = hb[n];
+        for (int k = 0; k < K; ++k) ref += (double)h2f(hA[fmt_pack_off(row, k, KB)]) * h2f(hW[fmt_pack_off(n, k, KB)]);
+        const double d = got - ref;
+        if (!(std::fabs(d) <= 1e-2)) {
+          if (nbad < 8) printf("  stress bad: row %d (%d in block %d) col %d (%d in block %d): got %g want %g\n", row, row % 192, row / 192, n, n % 256, n / 256, got, ref);
+          ++nbad;
+        }
+        worst = std::max(worst, std::fabs(d));
+      }
+      printf("stress mode %d (other kernel's LDS %d B) rep %d: bad %d of 3000, worst %.3g\n", mode, hlds, rep, nbad, worst);
+    }
+    return 0;
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));

@@ -6,7 +6,7 @@ sys.path.insert(0, ".")
 from tests.util import load_pkg
 pkg = load_pkg()
 cfg = pkg.config.FmtConfig()
-hp = pkg.pipeline.FloatHotPath(pkg.weights.synth_fmt_state(cfg, seed=1), pkg.weights.synth_decoder_state(512, seed=1), cfg, "cuda:0", 512, max_frames=32)
+hp = pkg.pipeline.FloatHotPath(pkg.weights.synth_fmt_state(cfg, seed=1), pkg.weights.synth_decoder_state(512, seed=1), cfg, "cuda:0", 512, max_frames=32, use_graph=int(__import__("os").environ.get("OVC_GRAPH", "2")))
 feats = pkg.weights.synth_feats(512, seed=1)
 T = 250
 c = pkg.pipeline.synth_conditions(cfg, T, seed=0, device="cuda:0")
