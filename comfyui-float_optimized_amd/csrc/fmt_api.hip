@@ -57,6 +57,7 @@ struct float_fmt {
   // hipGraph cache for the per-window chain, keyed by (nfe, bc, we_len, method, scales); least recently used entry evicted
   struct GraphKey {
     int nfe, bc, we_len, method, nclip;
+    int prio;  // priority of the stream the graph is launched on (run_mod_all picks its kernel by it)
     float a, r, e;
     bool operator==(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) == 0; }
   };
@@ -68,6 +69,7 @@ struct float_fmt {
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
   hipStream_t cap_stream = nullptr;
+  int cap_prio = 0;  // while capturing: the priority of the stream the graph will be launched on
   // state of an incremental sample (float_fmt_sample_begin / _next)
   struct {
     const float *wr, *wa, *we, *noise;
@@ -97,6 +99,25 @@ int dev_copy(float* dst, const float* src, size_t n, hipStream_t s) { return dev
 int dev_zero(float* dst, size_t n, hipStream_t s) { return dev_copy2d(dst, n, nullptr, n, (int)n, 1, s); }
 
 
+// Weight packing ON THE DEVICE (round 6): the fp32 rows of a Linear cross PCIe once as they are and a kernel writes the
+// fragment-major image - 8 consecutive k of a row = one pack (fmt_pack_off), converted with the conversion every activation
+// store uses (round to nearest even, fp16 saturating at 65504).  On the host the same loop ran at ~5 ns per weight on ONE
+// thread: 0.86 s for the FMT, 1.74 s for the speech-emotion model, 3.4 s per InferenceAgent.to_target(); now the time of the
+// copies (tools/probes/retarget_time.py; INTEGRATION.md "Residency").  FLOAT_PACK_HOST=1 keeps the host loop (the A/B switch;
+// the two images are equal bit for bit for finite weights - tests/test_variants_gpu.py).
+template <class T>
+__global__ __launch_bounds__(256) void fmt_pack_w_kernel(typename T::elem* __restrict__ out, const float* __restrict__ w, int N_each,
+                                                         int K, int KB, int n0) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int gpr = KB * 4;  // packs per row
+  const int n = (int)(idx / gpr), k0 = (int)(idx % gpr) * 8;
+  if (n >= N_each) return;
+  typename T::pack8 p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) T::set(p, i, k0 + i < K ? w[(size_t)n * K + k0 + i] : 0.f);
+  T::store8(out + fmt_pack_off(n0 + n, k0, KB), p);
+}
+
 template <class T>
 int pack_linear_pool(DevicePool* pool, const TensorTable& tt, const std::vector<std::string>& names, int N_each, int K,
                      Lin* out) {
@@ -105,8 +126,21 @@ int pack_linear_pool(DevicePool* pool, const TensorTable& tt, const std::vector<
   constexpr size_t esz = sizeof(E) / sizeof(u16);  // u16 slots per element (Lin::W is typed u16* for every operand type)
   const int Kp = round_up(K, 128);
   const int N = N_each * (int)names.size();
-  std::vector<E> hw((size_t)N * Kp, (E)0);
+  static const bool on_host = getenv("FLOAT_PACK_HOST") && atoi(getenv("FLOAT_PACK_HOST")) != 0;
+  std::vector<E> hw;
+  if (on_host) hw.assign((size_t)N * Kp, (E)0);
   std::vector<float> hb(N, 0.f);
+  int rc;
+  if ((rc = pool->alloc(&out->W, (size_t)N * Kp * esz, false))) return rc;
+  if ((rc = pool->alloc(&out->b, hb.size(), false))) return rc;
+  float* stage = nullptr;  // one Linear's fp32 rows on the device
+  if (!on_host) FH_CHECK_HIP(hipMalloc(&stage, (size_t)N_each * K * sizeof(float)));
+  struct Free {
+    float* p;
+    ~Free() {
+      if (p) (void)hipFree(p);
+    }
+  } free_stage{stage};
   int n0 = 0;
   for (const std::string& nm : names) {
     const float_tensor_t* w = tt.find(nm + ".weight");
@@ -120,18 +154,25 @@ int pack_linear_pool(DevicePool* pool, const TensorTable& tt, const std::vector<
                    (long long)(w->ndim > 1 ? w->shape[1] : 0), N_each, K);
       return FLOAT_E_INVALID;
     }
-    for (int n = 0; n < N_each; ++n) {
-      const float* src = w->data + (size_t)n * K;
-      for (int k = 0; k < K; ++k) hw[fmt_pack_off(n0 + n, k, Kp / 32)] = T::host_from_float(src[k]);
-      hb[n0 + n] = b->data[n];
+    if (on_host) {
+      for (int n = 0; n < N_each; ++n) {
+        const float* src = w->data + (size_t)n * K;
+        for (int k = 0; k < K; ++k) hw[fmt_pack_off(n0 + n, k, Kp / 32)] = T::host_from_float(src[k]);
+      }
+    } else {
+      // (null stream: the copy returns when the rows are on the device, the kernel runs before the next copy into `stage`)
+      FH_CHECK_HIP(hipMemcpy(stage, w->data, (size_t)N_each * K * sizeof(float), hipMemcpyHostToDevice));
+      const size_t packs = (size_t)N_each * (Kp / 8);
+      hipLaunchKernelGGL((fmt_pack_w_kernel<T>), dim3((unsigned)((packs + 255) / 256)), dim3(256), 0, nullptr,
+                         reinterpret_cast<E*>(out->W), stage, N_each, K, Kp / 32, n0);
+      FH_CHECK_HIP(hipGetLastError());
     }
+    for (int n = 0; n < N_each; ++n) hb[n0 + n] = b->data[n];
     n0 += N_each;
   }
-  int rc;
-  if ((rc = pool->alloc(&out->W, hw.size() * esz, false))) return rc;
-  if ((rc = pool->alloc(&out->b, hb.size(), false))) return rc;
-  FH_CHECK_HIP(hipMemcpy(out->W, hw.data(), hw.size() * sizeof(E), hipMemcpyHostToDevice));
+  if (on_host) FH_CHECK_HIP(hipMemcpy(out->W, hw.data(), hw.size() * sizeof(E), hipMemcpyHostToDevice));
   FH_CHECK_HIP(hipMemcpy(out->b, hb.data(), hb.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!on_host) FH_CHECK_HIP(hipDeviceSynchronize());  // the packed image is complete (and `stage` idle) when the call returns
   out->N = N;
   out->K = Kp;
   return FLOAT_OK;
@@ -765,12 +806,26 @@ constexpr int kScSteps = 64;  // evaluations per modulation batch; longer grids 
 int g_fmt_hoist = 1;
 int g_fmt_zgroup = 0;  // FLOAT_FMT_ZGROUP: column blocks of an XCD that share activation tiles through L2; 0 = per kernel: 4 (fmt_gemm_wide_kernel), 2 (fmt_gemm_dma_kernel)
 
+static int stream_priority(hipStream_t s) {
+  int prio = 0;
+  if (hipStreamGetPriority(s, &prio) != hipSuccess) {
+    (void)hipGetLastError();
+    prio = 0;
+  }
+  return prio;
+}
+
 template <class T>
 int run_mod_all(float_fmt* h, int M, int e0, int n, hipStream_t s) {
   const int D = h->D;
   FH_REQUIRE(n >= 1 && n <= kScSteps, "modulation batch of %d evaluations (max %d)", n, kScSteps);
   // dense rows for the persistent kernel (row z * M + r of one packed image), else one padded image per evaluation
-  const bool big = !T::is32 && g_fmt_wide && big_shape_ok(n * M, h->adaln_all.N, h->adaln_all.K, h->n_cu);
+  // Not on a stream of non-default priority: with the chain on a HIGH-priority stream beside a decoder on a second stream
+  // (FLOAT_AMD_OVERLAP=prio) every window after the first came out wrong, and only with this kernel in the chain (round 6:
+  // tools/probes/overlap_check.py; the kernel alone passes the same stress in tools/probes/gemm_big_lab.hip, cause not found -
+  // DESIGN.md section 7).  fmt_gemm_dma_kernel gives the same numbers bit for bit.
+  const int prio = (s == h->cap_stream && s) ? h->cap_prio : stream_priority(s);
+  const bool big = !T::is32 && g_fmt_wide && prio == 0 && big_shape_ok(n * M, h->adaln_all.N, h->adaln_all.K, h->n_cu);
   hipLaunchKernelGGL((fmt_silu_c_kernel<T>), dim3((M * D / 8 + 255) / 256, n), dim3(256), 0, s, h->sc16, h->temb + (size_t)e0 * D,
                      h->ccond, M, D, (size_t)h->Mpad * D, big ? M : 0, h->sat);
   h->mod_zs = big ? (size_t)M * h->Ntot : (size_t)h->Mmod * h->Ntot;
@@ -1332,12 +1387,14 @@ int run_window_steps_graph(float_fmt* h, const CfgMode& m, int we_len, int nfe, 
   key.a = a;
   key.r = r;
   key.e = e;
+  key.prio = stream_priority(s);
   float_fmt::GraphEntry* hit = nullptr;
   for (auto& g : h->graphs)
     if (g.key == key) hit = &g;
   if (!hit) {
     if (!h->cap_stream) FH_CHECK_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
     hipGraph_t graph = nullptr;
+    h->cap_prio = key.prio;
     FH_CHECK_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     int rc = run_window_steps<T>(h, m, nfe, ts, a, r, e, h->cap_stream);
     hipError_t ce = hipStreamEndCapture(h->cap_stream, &graph);

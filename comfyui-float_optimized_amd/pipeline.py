@@ -162,10 +162,13 @@ class FloatHotPath:
                 n_dec = max(8, min(n_cu - 8, int(mode[3:])))
                 with torch.cuda.device(dev):
                     cache[mode] = (native.cu_range_stream(0, n_cu - n_dec, dev), native.cu_range_stream(n_cu - n_dec, n_cu, dev))
-            elif mode in ("prio", "plain"):
-                lo, hi = torch.cuda.Stream.priority_range()  # (least, greatest): greatest priority = the smaller number
-                cache[mode] = ((torch.cuda.Stream(dev, priority=hi), torch.cuda.Stream(dev, priority=lo)) if mode == "prio" else
-                               (torch.cuda.Stream(dev), torch.cuda.Stream(dev)))
+            elif mode in ("prio", "plain", "hi", "lo"):
+                # (least, greatest) priority: the greater priority is the SMALLER number; 0 is the default.  "hi" / "lo" raise the
+                # chain / lower the decoder only (tools/probes/overlap_check.py)
+                lo, hi = torch.cuda.Stream.priority_range()
+                pf = hi if mode in ("prio", "hi") else 0
+                pd = lo if mode in ("prio", "lo") else 0
+                cache[mode] = (torch.cuda.Stream(dev, priority=pf), torch.cuda.Stream(dev, priority=pd))
             else:
                 raise ValueError("overlap mode must be 'prio' or 'cu:N', got %r" % (mode,))
         return cache[mode]

@@ -160,6 +160,8 @@ class InferenceAgent:
         written straight into one pinned buffer and sent by ONE non-blocking copy."""
         c = self.cfg
         shape = (n_chunks, len(seeds), c.num_frames_for_clip, c.dim_w)
+        if os.environ.get("FLOAT_AMD_NOISE", "cpu").lower() == "device":  # per item what _noise_to_device draws for it alone
+            return torch.cat([self._noise_to_device(n_chunks, sd) for sd in seeds], dim=1)
         buf = self.__dict__.get("_noise_pin_b")
         if buf is None or tuple(buf.shape) != shape:
             buf = self._noise_pin_b = torch.empty(shape, dtype=torch.float32, pin_memory=True)
@@ -176,6 +178,13 @@ class InferenceAgent:
         idle behind them.  The buffer is kept until the next clip (which starts after this one was synchronised)."""
         c = self.cfg
         shape = (n_chunks, 1, c.num_frames_for_clip, c.dim_w)
+        if os.environ.get("FLOAT_AMD_NOISE", "cpu").lower() == "device":
+            # "the reference on this device": torch.Generator(self.opt.rank) + randn(..., device=rank) per window (FLOAT.py:203-215) -
+            # the stream a user of the reference on ROCm gets.  Default: the CPU generator's stream (the reference run on the CPU,
+            # what the goldens and the oracle use); the two streams differ, the sampler does not.
+            g = torch.Generator(self.rank)
+            g.manual_seed(int(seed))
+            return torch.stack([torch.randn(1, c.num_frames_for_clip, c.dim_w, device=self.rank, generator=g) for _ in range(n_chunks)])
         buf = self.__dict__.get("_noise_pin")
         if buf is None or tuple(buf.shape) != shape:
             buf = self._noise_pin = torch.empty(shape, dtype=torch.float32, pin_memory=True)

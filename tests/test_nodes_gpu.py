@@ -116,7 +116,20 @@ def test_offload_frees_hbm_and_reload_is_bitwise(pipe):
     with pipe.model_to_target(offload_after=True):   # the reference's policy: offload after every call
         pass
     assert not pipe.resident
+    # what the reference's policy costs per node call here (INTEGRATION.md "Residency"; tools/probes/retarget_time.py: 0.54 s / 45 ms
+    # with the speech-emotion model at its checkpoint shape): the weights are packed on the device since round 6 (3.4 s before)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     pipe.to_target()
+    torch.cuda.synchronize()
+    t_up = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pipe.offload()
+    t_off = time.perf_counter() - t0
+    pipe.to_target()
+    print("to_target() %.0f ms, offload() %.0f ms" % (t_up * 1e3, t_off * 1e3))
+    assert t_up < 1.5 and t_off < 0.5, (t_up, t_off)
 
 
 def test_float_process_batch_runs_stacked_chains(pipe, monkeypatch):
@@ -179,3 +192,23 @@ def test_float_process_batch_of_16_runs_tier3_chain(pipe, monkeypatch):
         assert psnr >= 45.0, (i, psnr)
     print("16 items x 25 frames: batched vs per-item loop, worst item %.1f dB" % worst)
     assert sum(pipe.G.range_counts().values()) == 0
+
+
+def test_device_noise_stream_is_the_reference_on_this_device(pipe, monkeypatch):
+    """FLOAT_AMD_NOISE=device: the noise of a clip is what the reference draws on a GPU - torch.Generator(rank), one
+    randn(B, 50, 512, device=rank) per window (FLOAT.py:203-215) - instead of the CPU generator's stream (the default)."""
+    monkeypatch.setenv("FLOAT_AMD_NOISE", "device")
+    got = pipe._noise_to_device(3, 11)
+    g = torch.Generator(pipe.rank)
+    g.manual_seed(11)
+    want = torch.stack([torch.randn(1, 50, 512, device=pipe.rank, generator=g) for _ in range(3)])
+    assert torch.equal(got, want)
+    both = pipe._noise_batch_to_device(3, [11, 12])
+    assert both.shape == (3, 2, 50, 512) and torch.equal(both[:, :1], want)
+    img, audio = _inputs()
+    node = pkg.NODE_CLASS_MAPPINGS["FloatProcessOpt"]()
+    dev_frames, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    dev_frames = dev_frames.clone()
+    monkeypatch.delenv("FLOAT_AMD_NOISE")
+    cpu_frames, _, _ = node.floatprocess(img, audio, pipe, 2.0, 1.0, 25.0, "happy", False, 7)
+    assert dev_frames.shape == cpu_frames.shape and torch.isfinite(dev_frames).all() and not torch.equal(dev_frames, cpu_frames)

@@ -36,21 +36,24 @@ def test_overlap_and_shard_are_bitwise_sequential():
     assert torch.equal(shard, seq[40:110])
 
 
-@pytest.mark.parametrize("mode", ["prio", "cu:64"])
-def test_overlapped_hand_over_is_bitwise_sequential(mode):
+@pytest.mark.parametrize("mode,nfe", [("prio", 12), ("prio", 6), ("cu:64", 6)])
+def test_overlapped_hand_over_is_bitwise_sequential(mode, nfe):
     """generate_to_host_overlap (FLOAT_AMD_OVERLAP): window k decoded and handed to the host on a second stream - lower
     priority, or a disjoint CU set - while the chain samples window k + 1: bit for bit the frames and latents of
-    generate_to_host, twice in a row (the streams and staging are re-used)."""
+    generate_to_host, twice in a row (the streams and staging are re-used).  nfe = 12 puts the persistent adaLN projection
+    (fmt_gemm_big4_kernel, from 1 536 rows = 9 evaluations on) into the sequential chain: on the high-priority stream the operator must
+    take fmt_gemm_dma_kernel instead (run_mod_all: at full size every window after the first came out wrong otherwise) and the
+    graph cache must not replay the default-priority graph there."""
     cfg, _, _, hp, feats = _hot_path(max_frames=32)
     T = 130
     cond = pkg.pipeline.synth_conditions(cfg, T, seed=3)
     noise = pkg.fmt.draw_noise(hp.n_chunks(T), 1, cfg, seed=15).to("cuda:0")
     a = (cond["r_s"], cond["wa"], cond["we"], cond["s_r"])
-    seq, rd_seq = hp.generate_to_host(*a, feats, 6, noise=noise, return_rd=True)
+    seq, rd_seq = hp.generate_to_host(*a, feats, nfe, noise=noise, return_rd=True)
     torch.cuda.synchronize()
     seq = seq.clone()
     for _ in range(2):
-        ovl, rd_ovl = hp.generate_to_host_overlap(*a, 6, noise=noise, mode=mode, return_rd=True)
+        ovl, rd_ovl = hp.generate_to_host_overlap(*a, nfe, noise=noise, mode=mode, return_rd=True)
         torch.cuda.synchronize()
         assert ovl.is_pinned() and torch.equal(rd_seq, rd_ovl) and torch.equal(seq, ovl)
     with pytest.raises(ValueError):

@@ -13,6 +13,7 @@ c = pkg.pipeline.synth_conditions(cfg, T, seed=0, device="cuda:0")
 noise = pkg.fmt.draw_noise(5, 1, cfg, 15).to("cuda:0")
 a = (c["r_s"], c["wa"], c["we"], c["s_r"])
 nfe = int(sys.argv[1]) if len(sys.argv) > 1 else 51
+print("torch.cuda.Stream.priority_range() =", torch.cuda.Stream.priority_range())
 seq, rd = hp.generate_to_host(*a, feats, nfe, noise=noise, return_rd=True)
 torch.cuda.synchronize()
 seq, rd = seq.clone(), rd.clone()
