@@ -495,7 +495,10 @@ static double ride_weight(int R, int kind) {
   // launch durations (tools/probes/trace_sequence.py on the round-3 kernels: {203,155,61},{178,175,118},{242,226,215},{318,256,336})
   // shifted toward the flow launches, which absorb a share without getting longer while the 512-px convs are stretched by theirs
   // (a trace of the carrying batch: +49 / +56 us there, +6 on the flow launch): 26.35 vs 26.80 ms per 250 frames decode + hand-over
-  static double w[4][3] = {{170, 150, 70}, {178, 175, 125}, {242, 205, 230}, {290, 225, 370}};
+  // round 6 (launches now {178,142,52},{158,155,99},{220,206,175},{277,235,146}: the last level's flow launch is a third of what it
+  // was): decode + hand-over per 250 frames 25.1-25.3 ms with the row below against 26.4-26.9 with round 5's {..,{290,225,370}},
+  // 25.4 / 25.7 / 25.3 / 25.6 for four neighbours, 26.8 with equal shares (tools/probes/dec_host2.py, FLOAT_DEC_RIDE_W)
+  static double w[4][3] = {{170, 140, 50}, {170, 155, 100}, {220, 200, 180}, {300, 250, 120}};
   static const bool tuned = [] {  // tuning aid: FLOAT_DEC_RIDE_W="12 numbers", rows 64 / 128 / 256 / 512 px x (up-conv, conv2, flow)
     const char* e = getenv("FLOAT_DEC_RIDE_W");
     double t[12];

@@ -928,6 +928,10 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
     s_edge = edge;
     const long long org = ((long long)(sf * g.Hi + sty * 16 + g.dymin) * Wi + stx * 16 + g.dxmin) * Cin + (schunk << 5);
     const unsigned char* const Xo = reinterpret_cast<const unsigned char*>(g.X) + org * EB;
+#ifdef DEC_DIAG_NOLOAD  // timing-only build (WRONG frames): halo loads for the workgroup's first item only (the registers keep what they had)
+    if (!first) {
+    } else
+#endif
     if (edge == 0u) {
 #pragma unroll
       for (int i = 0; i < NA; ++i) ra[i] = *reinterpret_cast<const P8*>(Xo + a_off[i]);
@@ -1175,7 +1179,13 @@ __global__ __launch_bounds__(256, (T::is32 || DB) ? 1 : 2) void dec_conv16_kerne
             const int ty = hr - mt;
             if (ty >= 0 && ty < TY) {
 #pragma unroll
-              for (int j = 0; j < NT; ++j) acc[mt][j] = T::mfma(b[ty][j], a, acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+              for (int j = 0; j < NT; ++j) {
+#ifdef DEC_DIAG_NOMFMA  // timing-only build (WRONG frames): one VALU operation that consumes both fragments instead of the MFMA
+                if constexpr (!T::is32) acc[mt][j][0] += __builtin_bit_cast(float, b[ty][j][0] ^ a[mt & 3]);
+#else
+                acc[mt][j] = T::mfma(b[ty][j], a, acc[mt][j]);  // D[channel][pixel], see dec_conv_kernel
+#endif
+              }
             }
           }
         }
