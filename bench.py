@@ -509,11 +509,11 @@ def main():
             mod_roof["frac"] = round(mod_roof["achieved"] / MFMA_PEAK_TFLOPS, 4)
         # HBM traffic per launch / MFMA pipe utilisation from the committed rocprofv3 --pmc passes (tools/profile_round.sh),
         # only when they were taken on these kernel sources
-        pmc = load_profile_json("r05_pmc_traffic.json", warnings)
+        pmc = load_profile_json("r06_pmc_traffic.json", warnings)
         if pmc:
             gemm_roof["traffic"] = pmc.get("fmt_gemm", {}).get("hbm_bytes_per_launch")
             conv_roof["traffic"] = pmc.get("dec_conv", {}).get("hbm_bytes_per_launch")
-        mf = load_profile_json("r05_pmc_mfma.json", warnings)
+        mf = load_profile_json("r06_pmc_mfma.json", warnings)
         if mf:
             gemm_roof["mfma_util_pmc"] = mf.get("fmt_gemm", {}).get("mfma_util")
             conv_roof["mfma_util_pmc"] = mf.get("dec_conv", {}).get("mfma_util")
@@ -710,6 +710,9 @@ def main():
                         rb["adaln_gemm"] = {"launches": bm_n, "avg_launch_us": round(bm_ms * 1e3, 2),
                                             "achieved": round(mflop / (bm_ms * bm_n * 1e-3) / 1e12, 2), "unit": "TFLOP/s"}
                         rb["adaln_gemm"]["frac"] = round(rb["adaln_gemm"]["achieved"] / MFMA_PEAK_TFLOPS, 4)
+                    pmcb = load_profile_json("r06_pmc_traffic.json", [])  # the fmtb pass runs 16 stacked clips (2 880 rows)
+                    if pmcb and batch_done == 16:
+                        rb["traffic"] = pmcb.get("fmt_gemm_rb", {}).get("hbm_bytes_per_launch")
                     variants["roofline_batch"] = rb
 
     cpu = None

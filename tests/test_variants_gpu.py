@@ -138,3 +138,28 @@ def test_channel_block_order_is_bitwise_neutral(tmp_path):
     new = run_child(tmp_path, "dec", "cbnew", {})["frames"]
     old = run_child(tmp_path, "dec", "cbold", {"FLOAT_DEC_CB_ORDER": "0"})["frames"]
     assert torch.equal(new, old)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_device_packed_weights_equal_host_packed(tmp_path, dtype):
+    """Round 6: every Linear's fragment-major 16-bit image is written by fmt_pack_w_kernel from the fp32 rows on the device
+    (to_target 3.4 s -> 0.54 s) instead of a host loop (FLOAT_PACK_HOST=1).  Same rounding (nearest even, fp16 saturating), same
+    layout: the chain's output is bitwise identical."""
+    env = {"CHILD_DTYPE": dtype}
+    dev = run_child(tmp_path, "fmtbig", "packdev_" + dtype, env)
+    host = run_child(tmp_path, "fmtbig", "packhost_" + dtype, dict(env, FLOAT_PACK_HOST="1"))
+    for k in ("r3", "r4", "rb"):
+        assert torch.equal(dev[k], host[k]), k
+
+
+def test_toflow_in_the_conv_epilogue_matches_the_flow_kernel(tmp_path):
+    """Round 6, last level: ToFlow's 1x1 conv as one more MFMA in conv2's epilogue (weights hi + lo * 2^-11, the same 16-bit V
+    values as operands, V itself never stored) + dec_flowlast_kernel, against dec_flow_kernel on the stored V
+    (FLOAT_DEC_FLOW_EPI=0).  Both are fp32 sums of the same exact products in different orders: the frames agree to the rounding
+    of a flow value (one in ~1e5 pixels moves a bilinear tap; parity with the reference is 56 dB)."""
+    epi = run_child(tmp_path, "dec", "flowepi", {})["frames"]
+    old = run_child(tmp_path, "dec", "flowker", {"FLOAT_DEC_FLOW_EPI": "0"})["frames"]
+    d = (epi - old).abs()
+    psnr = float(-10 * torch.log10(((epi - old) ** 2).mean() + 1e-20))
+    print("ToFlow in the epilogue vs flow kernel: %.1f dB, max %.2e, mean %.2e" % (psnr, float(d.max()), float(d.mean())))
+    assert psnr > 80.0 and float(d.mean()) < 5e-5

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Small fixed workload for rocprofv3 counter passes (PMC passes serialise kernels, so the whole
 bench would take minutes): `--what dec` decodes 16 frames at 512x512 twice, `--what fmt` runs one
-50-frame window with 10 Euler evaluations (eager launches), `--what fmtb` the same window for 4 stacked clips (720 rows:
-the row-blocked LDS-DMA GEMM tiles).
+50-frame window with 10 Euler evaluations (eager launches), `--what fmtb` the same window for `--batch` stacked clips (default 16:
+2 880 rows, tier 3 of the row-blocked LDS-DMA GEMM tiles - what bench.py's roofline_batch prices; 4 = 720 rows).
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d out -- python3 tools/profile_hotpath.py --what dec
 """
@@ -20,6 +20,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--what", default="dec", choices=["dec", "fmt", "fmtb"])
 ap.add_argument("--frames", type=int, default=16)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--batch", type=int, default=16)
 args = ap.parse_args()
 pkg = load_pkg()
 cfg = pkg.config.FmtConfig()
@@ -35,7 +36,7 @@ if args.what == "dec":
     torch.cuda.synchronize()
     print("decoded", tuple(out.shape), float(out.mean()))
 elif args.what == "fmtb":
-    B = 4
+    B = args.batch
     sd = pkg.weights.synth_fmt_state(cfg, seed=1)
     fmt = pkg.fmt.FlowMatchingTransformerHIP(sd, cfg, dev, "fp16", use_graph=0, max_batch=B)
     cs = [pkg.pipeline.synth_conditions(cfg, 50, seed=q) for q in range(B)]

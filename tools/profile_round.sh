@@ -1,6 +1,6 @@
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-O=gpurun_out/${1:-r05_prof}; mkdir -p $O
+O=gpurun_out/${1:-r06_prof}; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err; cat $O/bench.json | cut -c1-300
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-bf16 > $O/stats.log 2>&1
 find $O/stats -name "*kernel_trace.csv" -delete
@@ -15,7 +15,7 @@ done
 python tools/make_mfma_json.py $O/pmc_sq_fmt,$O/pmc_sq_fmtb,$O/pmc_sq_dec $O/pmc_mfma.json
 python tools/make_traffic_json.py $O/pmc_FETCH_SIZE_fmt,$O/pmc_FETCH_SIZE_fmtb,$O/pmc_FETCH_SIZE_dec $O/pmc_WRITE_SIZE_fmt,$O/pmc_WRITE_SIZE_fmtb,$O/pmc_WRITE_SIZE_dec $O/pmc_traffic.json
 # the bench line that goes to profiles/: run with THIS round's counter files in place, so its counter-derived fields are live
-P=profiles/${2:-r05}
+P=profiles/${2:-r06}
 cp $O/pmc_mfma.json ${P}_pmc_mfma.json; cp $O/pmc_traffic.json ${P}_pmc_traffic.json
 python bench.py > $O/bench_final.json 2> $O/bench_final.err; cut -c1-300 $O/bench_final.json
 du -sh $O
