@@ -24,6 +24,10 @@ for d in sys.argv[1].split(","):
         for r in csv.DictReader(open(f)):
             n = r["Kernel_Name"]
             for cls, pre in CLASSES:
+                # the stacked-clip pass (..._fmtb) is there for the row-blocked tiles: its step-chain / adaLN launches (2 880 rows)
+                # must not be averaged into the one-clip classes
+                if d.rstrip("/").endswith("_fmtb") and cls != "fmt_gemm_rb":
+                    continue
                 if n.startswith(pre):
                     agg[cls][r["Counter_Name"]] += float(r["Counter_Value"])
                     disp[cls].add((f, r["Dispatch_Id"]))

@@ -26,6 +26,8 @@ def per_class(d):
                    "fmt_gemm_rb" if n.startswith("void fmt_gemm_rbs") else
                    "dec_conv" if n.startswith(("void dec_conv", "void dec_zconv")) else "dec_flow" if n.startswith("void dec_flow") else
                    "dec_zblur" if n.startswith("void dec_zblur") else "dec_other" if n.startswith("void dec_") else None)
+            if cls and d.rstrip("/").endswith("_fmtb") and cls != "fmt_gemm_rb":
+                cls = None  # the stacked-clip pass only speaks for the row-blocked tiles (its other launches run 2 880 rows)
             if cls:
                 # calibrated FETCH_SIZE factor of the launch's dominant read shape (only applied to FETCH_SIZE rows)
                 f = 1.0 if (cls in ("dec_conv", "dec_zblur") and not n.startswith("void dec_conv16_kernel<FP16, 2")) else 2.0

@@ -17,7 +17,8 @@ print("torch.cuda.Stream.priority_range() =", torch.cuda.Stream.priority_range()
 seq, rd = hp.generate_to_host(*a, feats, nfe, noise=noise, return_rd=True)
 torch.cuda.synchronize()
 seq, rd = seq.clone(), rd.clone()
-for mode in sys.argv[2:] or ["prio", "plain", "cu:64"]:
+modes = [m for m in sys.argv[2:] if m != "solo"]
+for mode in modes or ([] if "solo" in sys.argv else ["prio", "plain", "cu:64"]):
     for rep in range(3):
         t0 = time.perf_counter()
         o, r = hp.generate_to_host_overlap(*a, nfe, noise=noise, mode=mode, return_rd=True)
@@ -27,3 +28,18 @@ for mode in sys.argv[2:] or ["prio", "plain", "cu:64"]:
         bad_fr = [k for k in range(5) if not torch.equal(o[k * 50:(k + 1) * 50], seq[k * 50:(k + 1) * 50])]
         nbad = [int((o[k * 50:(k + 1) * 50] != seq[k * 50:(k + 1) * 50]).reshape(50, -1).any(1).sum()) for k in range(5)]
         print(mode, rep, "%.1f ms" % ms, "r_d windows differing:", bad_rd, "frame windows differing:", bad_fr, "frames per window:", nbad, flush=True)
+
+# The chain ALONE on a high-priority stream (no decoder anywhere): does the priority by itself change r_d?  (FLOAT_FMT_PRIO_GUARD=0
+# lets run_mod_all keep the persistent adaLN kernel on that stream - the configuration that failed beside the decoder.)
+if "solo" in sys.argv:
+    lo, hi = torch.cuda.Stream.priority_range()
+    s_hi = torch.cuda.Stream("cuda:0", priority=hi)
+    for rep in range(3):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_hi):
+            ws = pkg.fmt.WindowSampler(hp.fmt, *a[:3], noise, nfe, 2.0, 1.0, 1.0)
+            while ws.left > 0:
+                ws.next()
+        torch.cuda.synchronize()
+        bad = [k for k in range(5) if not torch.equal(ws.r_d[0, k * 50:(k + 1) * 50], rd[0, k * 50:(k + 1) * 50])]
+        print("solo chain on a priority %d stream, rep %d: r_d windows differing: %s" % (hi, rep, bad), flush=True)
