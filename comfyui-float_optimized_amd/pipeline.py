@@ -56,6 +56,15 @@ class FloatHotPath:
         batches run in chunks of that size.  Per clip the chain costs 79 / 52 / 36 / 28 / 24 ms at 1 / 2 / 4 / 8 / 16 clips."""
         cap = max(1, min(16, int(os.environ.get("FLOAT_AMD_FMT_MAX_BATCH", "16"))))
         mb = min(cap, max(1, int(n_clips)))
+        if mb > self.fmt.max_batch and mb not in self.__dict__.get("_fmt_batched", {}):
+            # 3.1 GB of workspace per stacked clip + the weights once more: size the handle for what the device has free (another
+            # model resident in ComfyUI, a smaller GPU) instead of failing with out-of-memory inside the create call
+            free, _ = torch.cuda.mem_get_info(self.device)
+            fit = int((free - (2 << 30)) // int(3.3 * 2**30))
+            if fit < mb:
+                logging.getLogger("float_amd").warning("batched FMT handle: %.1f GB of HBM free, stacking %d clips per chain instead of %d",
+                                                       free / 2**30, max(1, fit), mb)
+                mb = max(1, fit)
         if mb <= self.fmt.max_batch:
             return self.fmt
         cache = self.__dict__.setdefault("_fmt_batched", {})
@@ -125,6 +134,8 @@ class FloatHotPath:
         inflight[:] = [(t, e) for t, e in inflight if not e.query()]
         if out is None:
             out = torch.empty((n, self.size, self.size, 3), dtype=torch.float32, pin_memory=True)
+        # (the frames by hipMemcpyAsync on a second stream instead of copy workgroups inside the next batch's launches: 121.4-122.1 vs
+        # 105.7-106.8 ms per clip on the round-6 kernels, as in round 3 - decoder.decode_into_host(copy_stream=) keeps the form)
         self.dec.decode_into_host(s_r, rd, out, self.staging(n))
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))

@@ -184,3 +184,22 @@ def test_long_grids_cross_the_modulation_batch(method, nfe):
         m.set_method(method)
         got = m.sample(r_s, wa, we, noise, nfe, 2.0, 1.0, 1.0).cpu()
         assert rel_l2(got, ref) < tol, (dtype, rel_l2(got, ref))
+
+
+def test_batched_handle_is_sized_for_the_free_hbm(monkeypatch):
+    """FloatHotPath.batched_fmt: a stacked-clip handle costs 3.1 GB of workspace per clip; with little HBM free (another model
+    resident) it is sized for what fits - the chain then runs the batch in chunks - instead of failing inside float_fmt_create."""
+    cfg = CFG
+    hp = pkg.pipeline.FloatHotPath(W.synth_fmt_state(cfg, seed=1), W.synth_decoder_state(64, seed=1), cfg, "cuda:0", 64, max_frames=8)
+    real = torch.cuda.mem_get_info
+    monkeypatch.setattr(torch.cuda, "mem_get_info", lambda dev=None: (int(9.5 * 2**30), real(dev)[1]))
+    small = hp.batched_fmt(16)
+    assert small.max_batch == 2          # (9.5 - 2) GB // 3.3 GB
+    monkeypatch.setattr(torch.cuda, "mem_get_info", real)
+    assert hp.batched_fmt(2) is small    # cached
+    cs = [pkg.pipeline.synth_conditions(cfg, 60, seed=q) for q in range(3)]
+    noise = pkg.fmt.draw_noise(2, 3, cfg, seed=15)
+    cat = lambda k: torch.cat([c[k] for c in cs])  # noqa: E731
+    got = small.sample(cat("r_s"), cat("wa"), cat("we"), noise, 3).cpu()   # 3 clips on a 2-clip handle: chunks of 2 + 1
+    one = hp.fmt.sample(cs[2]["r_s"], cs[2]["wa"], cs[2]["we"], noise[:, 2:3], 3).cpu()
+    assert got.shape == (3, 60, cfg.dim_w) and rel_l2(got[2:3], one) < 1e-3
