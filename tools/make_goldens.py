@@ -607,7 +607,7 @@ def gen_node_surface(ns):
     import json
     print("[node surface]")
     import sys as _sys
-    st = _sys.modules["seconohe.torch"]
+    st = ref_import.stub("seconohe.torch")
     st.model_to_target = lambda logger, model: contextlib.nullcontext()
     import importlib
     nodes = ref_import.import_ref("src.nodes.nodes")

@@ -28,11 +28,35 @@ def available() -> bool:
     return os.path.isdir(os.path.join(REF_ROOT, "src", "nodes", "models", "float"))
 
 
+_stubs = {}  # every stand-in module this tool created, by name (they leave sys.modules again: see _remove_stubs)
+
+
 def _mod(name, **attrs):
     m = types.ModuleType(name)
     m.__dict__.update(attrs)
     sys.modules[name] = m
+    _stubs[name] = m
     return m
+
+
+def stub(name):
+    """A stand-in module by name, after it has left sys.modules (tools/make_goldens.py patches `seconohe.torch.model_to_target`)."""
+    return _stubs[name]
+
+
+def _remove_stubs():
+    """The stand-ins only have to exist while the reference modules are imported: they bind what they need at import time.
+    Left in sys.modules they would answer imports of code this tool does not own - the product's optional `import
+    face_alignment` and `import folder_paths` (ComfyUI's module: nodes_vadv_loader.models_dir) took the stand-ins for the real
+    thing, which made two CPU tests depend on the order of the test files."""
+    for name, m in _stubs.items():
+        if sys.modules.get(name) is m and not name.startswith("floatref"):  # (the namespace packages of the reference tree stay)
+            del sys.modules[name]
+
+
+def _restore_stubs():
+    for name, m in _stubs.items():
+        sys.modules.setdefault(name, m)
 
 
 def _install_stubs():
@@ -100,29 +124,24 @@ def _install_stubs():
     for name in _EMPTY_STUBS:
         if name not in sys.modules:
             _mod(name)
-            _installed_empty.append(name)
 
 
 # Empty stand-ins that only have to exist while the reference modules are imported (`import cv2` at module scope).  They
 # are taken out of sys.modules again at the end of load(): code this tool does not own (the product's optional
 # `import face_alignment`) must see the package as absent, not as an importable module without attributes.
 _EMPTY_STUBS = ("cv2", "librosa", "face_alignment")
-_installed_empty = []
 _loaded = {}
 
 
 def import_ref(name):
     """importlib.import_module("floatref." + name) for a reference module imported after load() (tools/make_goldens.py): the
-    empty stand-ins exist for the duration of the import only."""
+    stand-ins exist for the duration of the import only."""
     load()
-    added = [n for n in _EMPTY_STUBS if n not in sys.modules]
-    for n in added:
-        _mod(n)
+    _restore_stubs()
     try:
         return importlib.import_module("floatref." + name)
     finally:
-        for n in added:
-            sys.modules.pop(n, None)
+        _remove_stubs()
 
 
 def load():
@@ -156,7 +175,6 @@ def load():
     except Exception as e:  # pragma: no cover - optional
         ns.FLOAT = None
         ns.FLOAT_error = e
-    while _installed_empty:
-        sys.modules.pop(_installed_empty.pop(), None)
+    _remove_stubs()
     _loaded["ns"] = ns
     return ns
