@@ -477,6 +477,8 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
     float o[PIX][3];
 #pragma unroll
     for (int k = 0; k < PIX; ++k) o[k][0] = o[k][1] = o[k][2] = 0.f;
+#ifndef DEC_DIAG_NOFLOWDOT  // timing-only build (WRONG frames): no ToFlow channel loop, no reduction - the ceiling of moving ToFlow into
+    // conv2's epilogue at the levels that keep this kernel
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const float4 w0 = *reinterpret_cast<const float4*>(sw + j * C + c0);
@@ -490,6 +492,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
         o[k][j] = a;
       }
     }
+#endif
 #pragma unroll
     for (int k = 0; k < PIX; ++k) {
       // bias + up-sampled previous flow enter the sum once, in the lane that owns the pixel
@@ -498,6 +501,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
       o[k][1] += mine ? upf[1] + bf1 : 0.f;
       o[k][2] += mine ? upf[2] + bf2 : 0.f;
     }
+#ifndef DEC_DIAG_NOFLOWDOT
     for (int d = 1; d < lpp; d <<= 1) {
 #pragma unroll
       for (int k = 0; k < PIX; ++k) {
@@ -506,6 +510,7 @@ __device__ __forceinline__ void dec_flow_pixels(const FlowArgs& g, const FlowFra
         o[k][2] += __shfl_xor(o[k][2], d, 64);
       }
     }
+#endif
     // Sample position, tap addresses and blend weights of a pixel are the same in all its lanes: lane `sub` forms them for
     // pixel sub & (PIX - 1) ONLY and the group reads them by lane index (ds_bpermute: LDS pipe) - 9 values per pixel instead of
     // ~100 vector instructions per pixel in every lane (r03 listing: a third of the kernel's 1 200 instructions per iteration,
