@@ -76,3 +76,24 @@ def test_torchrun_launch_at_world_1():
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     r = json.loads(lines[-1])
     assert r["n_gpus"] == 1 and r["rccl_ranks"] == 1 and r["value"] > 0
+
+
+def test_torchrun_launch_at_world_2_gloo():
+    """The driver's own N > 1 launch line - `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1
+    --master-port P bench.py --gpus 2` - with two gloo ranks sharing this GPU: the roll call runs against the agent's store, one
+    line comes back with n_gpus = 2 and every rank's stage times."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + SHORT + [
+               "--no-cpu-baseline", "--no-roofline", "--no-extras", "--no-s2e", "--no-variants"]
+    p = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, FLOAT_BENCH_WATCHDOG="500", FLOAT_BENCH_BACKEND="gloo"), capture_output=True, timeout=800)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["value"] > 0 and [e["rank"] for e in r["ranks"]] == [0, 1]
+    assert all(e["boundary_all_gather_us"] > 0 for e in r["ranks"])
