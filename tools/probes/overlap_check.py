@@ -17,8 +17,8 @@ print("torch.cuda.Stream.priority_range() =", torch.cuda.Stream.priority_range()
 seq, rd = hp.generate_to_host(*a, feats, nfe, noise=noise, return_rd=True)
 torch.cuda.synchronize()
 seq, rd = seq.clone(), rd.clone()
-modes = [m for m in sys.argv[2:] if m != "solo"]
-for mode in modes or ([] if "solo" in sys.argv else ["prio", "plain", "cu:64"]):
+modes = [m for m in sys.argv[2:] if m not in ("solo", "torchload", "events", "waits")]
+for mode in modes or ([] if ("solo" in sys.argv or "torchload" in sys.argv) else ["prio", "plain", "cu:64"]):
     for rep in range(3):
         t0 = time.perf_counter()
         o, r = hp.generate_to_host_overlap(*a, nfe, noise=noise, mode=mode, return_rd=True)
@@ -36,10 +36,41 @@ if "solo" in sys.argv:
     s_hi = torch.cuda.Stream("cuda:0", priority=hi)
     for rep in range(3):
         torch.cuda.synchronize()
+        evs = []
         with torch.cuda.stream(s_hi):
             ws = pkg.fmt.WindowSampler(hp.fmt, *a[:3], noise, nfe, 2.0, 1.0, 1.0)
             while ws.left > 0:
                 ws.next()
+                if "events" in sys.argv:  # what the overlapped pipeline does after every window: an event for the decoder's stream
+                    ev = torch.cuda.Event()
+                    ev.record(s_hi)
+                    evs.append(ev)
+                    if "waits" in sys.argv:
+                        s_other = globals().setdefault("_s_other", torch.cuda.Stream("cuda:0"))
+                        s_other.wait_event(ev)
         torch.cuda.synchronize()
         bad = [k for k in range(5) if not torch.equal(ws.r_d[0, k * 50:(k + 1) * 50], rd[0, k * 50:(k + 1) * 50])]
-        print("solo chain on a priority %d stream, rep %d: r_d windows differing: %s" % (hi, rep, bad), flush=True)
+        print("solo chain on a priority %d stream%s, rep %d: r_d windows differing: %s" % (hi, " + event records" if evs else "", rep, bad), flush=True)
+
+# The chain on the high-priority stream beside ANOTHER workload than the decoder on a default-priority stream (plain torch
+# elementwise kernels over 1 GiB): is it the decoder, or any concurrent queue?
+if "torchload" in sys.argv:
+    lo, hi = torch.cuda.Stream.priority_range()
+    s_hi, s_lo = torch.cuda.Stream("cuda:0", priority=hi), torch.cuda.Stream("cuda:0", priority=0)
+    big = torch.zeros(1 << 28, device="cuda:0")
+    for rep in range(3):
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_hi):
+            ws = pkg.fmt.WindowSampler(hp.fmt, *a[:3], noise, nfe, 2.0, 1.0, 1.0)
+        k = 0
+        while ws.left > 0:
+            with torch.cuda.stream(s_hi):
+                ws.next()
+            if k >= 1:
+                with torch.cuda.stream(s_lo):
+                    for _ in range(12):
+                        big.add_(1.0)
+            k += 1
+        torch.cuda.synchronize()
+        bad = [k for k in range(5) if not torch.equal(ws.r_d[0, k * 50:(k + 1) * 50], rd[0, k * 50:(k + 1) * 50])]
+        print("chain on priority %d beside torch elementwise kernels, rep %d: r_d windows differing: %s" % (hi, rep, bad), flush=True)
